@@ -1,0 +1,23 @@
+"""CPU oracle for the VO front-end hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package
+(``visual-odometry-project_amd/``) may import, link or execute anything in this
+directory; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and only as the checker.
+
+Each module restates one piece of the reference's per-frame arithmetic in
+plain NumPy (or plain C under ``oracle/csrc``) and cites the reference
+file:line it follows.  Pinning status per module:
+
+* ``harris_np``   pinned bit-exactly by tests/golden/harris_*.npz (captured by
+                  importing the reference's NumPy code, tools/make_golden.py).
+* ``dlt_np``      pinned to 1e-9 by tests/golden/dlt_*.npz (same capture).
+* ``ransac_np``   pinned by tests/golden/ransac_*.npz (sampler known answers,
+                  iteration-bound table, full parabola trace).
+* ``bookkeeping`` (Matches/State restatement lives in the product shim; the
+                  golden tests/golden/bookkeeping_*.npz pins it.)
+* ``csrc/p3p.c``, ``csrc/klt.c``, ``csrc/match.c``: the reference delegates
+                  this arithmetic to opencv-python==4.8.1.78, which is not in
+                  /root/reference and not installable here: PARITY UNPINNED
+                  against OpenCV; checked against analytic ground truth.
+"""
