@@ -1,0 +1,88 @@
+// Internal (C++) declarations shared by the HIP translation units of libvo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "vo_hip.h"
+
+// A lazily grown device allocation owned by the context.
+struct vo_buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct vo_prof_slot {
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct vo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  char err[512] = {0};
+
+  // profiling
+  bool prof_on = false;
+  int prof_kernel = -1;
+  vo_prof_slot prof[VO_K_COUNT];
+  std::vector<hipEvent_t> ev_free;
+  struct pending_ev { int k; hipEvent_t a, b; };
+  std::vector<pending_ev> ev_pending;
+
+  // workspace (device)
+  vo_buf img, img2, scores, kp, desc;
+  vo_buf nms_keys_l1, nms_idx_l1, nms_keys_a1, nms_idx_a1;   // candidate lists
+  vo_buf nms_keys_c, nms_idx_c;                              // compacted candidates
+  vo_buf nms_hist, nms_ctl, nms_sel;
+  vo_buf scratch[16];
+  // pinned host staging
+  void* h_pin = nullptr;
+  size_t h_pin_cap = 0;
+};
+
+int vo_set_error(vo_ctx* ctx, int code, const char* fmt, ...);
+int vo_ensure(vo_ctx* ctx, vo_buf& b, size_t bytes);
+int vo_ensure_pinned(vo_ctx* ctx, size_t bytes);
+
+#define VO_HIP_TRY(ctx, expr)                                                         \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return vo_set_error((ctx), VO_EHIP, "%s failed: %s (%s:%d)", #expr,             \
+                          hipGetErrorString(e_), __FILE__, __LINE__);                 \
+  } while (0)
+
+#define VO_TRY(expr)                 \
+  do {                               \
+    int s_ = (expr);                 \
+    if (s_ != VO_OK) return s_;      \
+  } while (0)
+
+#define VO_REQUIRE(ctx, cond, ...)                                  \
+  do {                                                              \
+    if (!(cond)) return vo_set_error((ctx), VO_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+// Brackets one kernel launch with an event pair when profiling is enabled for it.
+struct vo_prof_scope {
+  vo_ctx* c;
+  int k;
+  hipEvent_t a = nullptr, b = nullptr;
+  vo_prof_scope(vo_ctx* ctx, int kernel);
+  ~vo_prof_scope();
+};
+
+static inline int vo_check_launch(vo_ctx* ctx, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return vo_set_error(ctx, VO_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return VO_OK;
+}
+
+static inline int vo_cdiv(int a, int b) { return (a + b - 1) / b; }
