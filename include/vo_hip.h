@@ -113,6 +113,64 @@ int vo_patch_descriptors(vo_ctx* ctx, const uint8_t* img, int H, int W,
 int vo_patch_descriptors_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W,
                              const double* d_kp_xy, int N, int r, double* d_desc);
 
+/* ---- pyramidal KLT -----------------------------------------------------------
+ * [ref: src/vo/features/klt.py:233-249]  cv2.calcOpticalFlowPyrLK(prev, next,
+ * prevPts, None, winSize=(win,win), maxLevel=max_level, criteria=(EPS|COUNT,
+ * max_iter, eps)), default minEigThreshold = 1e-4, flags = 0.  Outputs as OpenCV:
+ * next_xy N*2 float32, status N uint8, err N float32 (mean |patch diff| / 32).
+ * Pyramid level l+1 is ((H+1)/2, (W+1)/2); the number of levels actually used is
+ * vo_klt_num_levels (the builder stops when a level is not larger than the
+ * window).  The _dev form takes level 0 (the image) and a buffer holding levels
+ * 1..n-1 back to back, each rounded up to 256 bytes (vo_pyramid_bytes).        */
+int vo_klt_num_levels(int H, int W, int win, int max_level);
+size_t vo_pyramid_bytes(int H, int W, int n_levels);
+int vo_pyr_down(vo_ctx* ctx, const uint8_t* img, int H, int W, uint8_t* out);
+int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_levels,
+                         uint8_t* d_pyr);
+int vo_klt_track(vo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int H, int W,
+                 const float* prev_xy, int N, int win, int max_level, int max_iter,
+                 double eps, double min_eig, float* next_xy, uint8_t* status, float* err);
+int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr,
+                     const uint8_t* d_next, const uint8_t* d_next_pyr, int H, int W,
+                     int n_levels, const float* d_prev_xy, int N, int win, int max_iter,
+                     double eps, double min_eig, float* d_next_xy, uint8_t* d_status,
+                     float* d_err);
+
+/* ---- DLT triangulation --------------------------------------------------------
+ * [ref: src/vo/landmarks/triangulation.py:352-389, 38-86; src/vo/helpers.py:57-83]
+ * per point A = [[x1]_x C1 ; [x2]_x C2] (6x4), smallest right singular vector,
+ * de-homogenised.  x1, x2: n*2 pixels; C1: 3x4 row-major, or n of them when
+ * c1_per_point != 0 (triangulate_candidates); C2: 3x4; X: n*3.                  */
+int vo_triangulate_dlt(vo_ctx* ctx, const double* x1, const double* x2, int n,
+                       const double* C1, int c1_per_point, const double* C2, double* X);
+int vo_triangulate_dlt_dev(vo_ctx* ctx, const double* d_x1, const double* d_x2, int n,
+                           const double* d_C1, int c1_per_point, const double* d_C2,
+                           double* d_X);
+
+/* ---- P3P hypotheses + reprojection scoring -------------------------------------
+ * [ref: src/vo/pose_estimation/p3p.py:51-79]   model_fn: cv2.solvePnP(P3P) on the 4
+ *       sampled correspondences -> (R, t) world->camera, or None
+ * [ref: src/vo/pose_estimation/p3p.py:81-108]  error_fn: squared reprojection error
+ * [ref: src/vo/algorithms/ransac.py:104-106]   inliers = error < thr (strict); count
+ * X: N*3 landmarks, x: N*2 pixels, K: 3x3 row-major (HOST pointer in both forms),
+ * samples: Hyp*4 indices into the N correspondences.  Outputs per hypothesis:
+ * R Hyp*9, t Hyp*3, valid Hyp (0 = the reference's "model is None"), counts Hyp,
+ * masks Hyp*ceil(N/64) 64-bit words (bit i%64 of word i/64 = point i is an inlier;
+ * nullable).  vo_reproj_inliers scores one pose: mask N bytes and/or err N.     */
+int vo_p3p_hypotheses(vo_ctx* ctx, const double* X, const double* x, int N, const double* K,
+                      const int32_t* samples, int Hyp, double thr_sq, double* R, double* t,
+                      uint8_t* valid, int32_t* counts, uint64_t* masks);
+int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N,
+                          const double* K, const int32_t* d_samples, int Hyp, double thr_sq,
+                          double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
+                          uint64_t* d_masks);
+int vo_reproj_inliers(vo_ctx* ctx, const double* X, const double* x, int N, const double* K,
+                      const double* R, const double* t, double thr_sq, uint8_t* mask,
+                      double* err);
+int vo_reproj_inliers_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N,
+                          const double* K, const double* d_Rt, double thr_sq,
+                          uint8_t* d_mask, double* d_err);
+
 #ifdef __cplusplus
 }
 #endif

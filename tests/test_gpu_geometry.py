@@ -1,0 +1,134 @@
+"""-m gpu: HIP DLT / P3P / reprojection / pyramid / KLT kernels through the C ABI
+against the oracle (and, for DLT, the reference golden)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dlt_np, native
+from test_oracle_geometry import scene, shift_image
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vo import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+# ---------------- DLT (parity by tolerance: SVD route differs from LAPACK) ----------------
+def test_dlt_matches_reference_golden(ctx):
+    g = np.load(os.path.join(G, "dlt_cameras.npz"))
+    X = ctx.triangulate_dlt(g["x1"], g["x2"], g["C1"], g["C2"])
+    assert np.allclose(X, g["X_clean"][:, :, 0], rtol=1e-9, atol=1e-9)
+    assert np.allclose(X, g["X_true"][:, :, 0], atol=1e-4)                  # reference bar, test_triangulation.py:229
+    Xn = ctx.triangulate_dlt(g["x1n"], g["x2n"], g["C1"], g["C2"])
+    assert np.allclose(Xn, g["X_noisy"][:, :, 0], rtol=1e-8, atol=1e-8)
+    m = g["cand_mask"]
+    P1, P2 = dlt_np.candidate_projections(g["K"], g["cand_poses"][m], g["cand_current_pose"])
+    Xc = ctx.triangulate_dlt(g["cand_tracks"][m], g["cand_keypoints"][m], P1, P2)
+    assert np.allclose(Xc, g["X_cand"][:, :, 0], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("n", [1, 7, 2000, 8000])
+def test_dlt_matches_oracle_seeded(ctx, n):
+    rng, K, R, t, X, x2 = scene(n, seed=11 + n)
+    x1 = X @ K.T
+    x1 = x1[:, :2] / x1[:, 2:]
+    x1 += rng.normal(0, 0.4, x1.shape)
+    C1 = K @ np.eye(4)[:3]
+    C2 = K @ np.hstack([R, t[:, None]])
+    ref = dlt_np.linear_triangulation(x1, x2, C1, C2)
+    got = ctx.triangulate_dlt(x1, x2, C1, C2)
+    assert np.allclose(got, ref, rtol=1e-8, atol=1e-8)
+
+
+def test_dlt_empty(ctx):
+    assert ctx.triangulate_dlt(np.zeros((0, 2)), np.zeros((0, 2)), np.eye(4)[:3], np.eye(4)[:3]).shape == (0, 3)
+
+
+# ---------------- P3P hypotheses + scoring ----------------
+@pytest.mark.parametrize("n,hyp,noise", [(1000, 1000, 0.0), (2000, 1000, 0.4), (37, 64, 0.2), (8000, 4000, 0.5)])
+def test_p3p_hypotheses_match_oracle(ctx, n, hyp, noise):
+    rng, K, R, t, X, x = scene(n, seed=5 + n)
+    xn = x + rng.normal(0, noise, x.shape) if noise else x.copy()
+    k = n // 6
+    xn[:k] += rng.uniform(-40, 40, size=(k, 2))                              # gross outliers
+    samples = np.stack([rng.choice(n, 4, replace=False) for _ in range(hyp)]).astype(np.int32)
+    thr = 1.0
+    Rr, tr, vr, cr, mr = native.p3p_hypotheses(X, xn, K, samples, thr, want_masks=True)
+    Rg, tg, vg, cg, mg = ctx.p3p_hypotheses(X, xn, K, samples, thr, want_masks=True)
+    assert np.array_equal(vg, vr), "valid flags (reference: model is None) differ"
+    assert np.allclose(Rg, Rr, rtol=0, atol=1e-9) and np.allclose(tg, tr, rtol=0, atol=1e-9)
+    # inlier masks and counts: bit-exact
+    assert np.array_equal(cg, cr)
+    assert np.array_equal(mg, mr.astype(bool))
+    exact = np.array_equal(Rg, Rr) and np.array_equal(tg, tr)
+    print("p3p poses bit-identical to oracle:", exact, "valid:", int(vg.sum()), "/", hyp)
+    b = int(np.argmax(cg))
+    assert np.abs(Rg[b] - R).max() < 1e-2
+
+
+def test_reproj_inliers_match_oracle(ctx):
+    rng, K, R, t, X, x = scene(3000, seed=9)
+    xn = x + rng.normal(0, 0.7, x.shape)
+    for thr in (0.25, 1.0, 1.5625):
+        mask, err = ctx.reproj_inliers(X, xn, K, R, t, thr, want_err=True)
+        ref = native.reproj_errors(X, xn, K, R, t)
+        assert np.array_equal(err, ref), "squared reprojection errors not bit-identical"
+        assert np.array_equal(mask, ref < thr)
+
+
+# ---------------- pyramid + KLT ----------------
+@pytest.mark.parametrize("shape", [(37, 51), (240, 320), (1241, 1376)])
+def test_pyr_down_bit_exact(ctx, shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, size=shape).astype(np.uint8)
+    assert np.array_equal(ctx.pyr_down(img), native.pyr_down(img))
+
+
+@pytest.mark.parametrize("dx,dy,win,lvl", [(1.3, -0.7, 17, 2), (5.6, 3.2, 17, 2), (-9.5, 6.25, 15, 2),
+                                           (2.0, 1.0, 21, 3), (0.4, 0.2, 9, 0)])
+def test_klt_matches_oracle_and_flow(ctx, dx, dy, win, lvl):
+    prev, nxt = shift_image(240, 320, 5, dx, dy)
+    rng = np.random.default_rng(2)
+    pts = np.stack([rng.uniform(-5, 325, 400), rng.uniform(-5, 245, 400)], axis=1).astype(np.float32)
+    ro, rs, re = native.klt_track(prev, nxt, pts, win=win, max_level=lvl)
+    go, gs, ge = ctx.klt_track(prev, nxt, pts, win=win, max_level=lvl)
+    assert np.array_equal(gs, rs), "status flags differ"
+    assert np.array_equal(go, ro), "tracked points not bit-identical to the oracle"
+    assert np.array_equal(ge, re), "error measures not bit-identical"
+    good = gs.astype(bool) & (ge < 100) & (pts[:, 0] > 40) & (pts[:, 0] < 280) & (pts[:, 1] > 40) & (pts[:, 1] < 200)
+    flow = go[good] - pts[good]
+    assert np.abs(np.median(flow[:, 0]) - dx) < 0.1 and np.abs(np.median(flow[:, 1]) - dy) < 0.1
+
+
+def test_klt_full_size(ctx):
+    dx, dy = 3.25, -1.5
+    prev, nxt = shift_image(1241, 1376, 8, dx, dy)
+    rng = np.random.default_rng(4)
+    pts = np.stack([rng.uniform(30, 1340, 2000), rng.uniform(30, 1200, 2000)], axis=1).astype(np.float32)
+    go, gs, ge = ctx.klt_track(prev, nxt, pts, win=15, max_level=2)
+    ro, rs, re = native.klt_track(prev, nxt, pts, win=15, max_level=2)
+    assert np.array_equal(gs, rs) and np.array_equal(go, ro) and np.array_equal(ge, re)
+    good = gs.astype(bool) & (ge < 100)
+    assert good.mean() > 0.95
+    assert np.percentile(np.abs(go[good] - pts[good] - [dx, dy]).max(axis=1), 90) < 0.2
+
+
+def test_klt_edge_cases(ctx):
+    prev, nxt = shift_image(64, 80, 3, 0.5, 0.5)
+    go, gs, ge = ctx.klt_track(prev, nxt, np.zeros((0, 2), np.float32))
+    assert go.shape == (0, 2)
+    flat = np.full((64, 80), 128, np.uint8)                                   # textureless: min-eig test fails
+    go, gs, ge = ctx.klt_track(flat, flat, np.array([[30.0, 30.0]], np.float32))
+    ro, rs, re = native.klt_track(flat, flat, np.array([[30.0, 30.0]], np.float32))
+    assert gs[0] == 0 and rs[0] == 0
+    far = np.array([[-100.0, 20.0], [500.0, 20.0]], np.float32)               # window outside the image
+    go, gs, ge = ctx.klt_track(prev, nxt, far)
+    ro, rs, re = native.klt_track(prev, nxt, far)
+    assert np.array_equal(gs, rs) and not gs.any() and np.array_equal(go, ro)

@@ -1,0 +1,405 @@
+// Batched P3P hypothesis generation and reprojection scoring for gfx950.
+//
+// Reference behaviour (src/vo/pose_estimation/p3p.py, src/vo/algorithms/ransac.py):
+//   model_fn  p3p.py:51-79    pose from 4 sampled 3D-2D correspondences: P3P on the
+//                             first three, the fourth picks among <= 4 solutions
+//   error_fn  p3p.py:81-108   squared reprojection error of every correspondence,
+//                             formed as (sqrt(dx^2 + dy^2))^2 after
+//                             x' = X' * (1/Z'), u = x' * fx + cx
+//   inliers   ransac.py:104-106  error < threshold (strict), counted per hypothesis
+// The reference runs these one RANSAC iteration at a time; here all pre-drawn
+// samples are solved in one launch (one lane per hypothesis) and scored in a second
+// (one workgroup per hypothesis, wave ballots give the inlier bit-mask rows), and
+// the host replays the sequential accept/adapt rule over (valid, count).
+//
+// fp64 throughout, FP contraction off, only + - * / sqrt: same rounding sequence
+// as the CPU oracle.
+#include "vo_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct pose_t {
+  double R[9];
+  double t[3];
+};
+
+__device__ __forceinline__ double cubic_root_bracketed(double A, double B, double C) {
+  // real root in (0, 1 + max|coef|] of m^3 + A m^2 + B m + C for C < 0:
+  // Newton inside a sign-change bracket, bisection when Newton leaves it or stalls
+  double bound = fabs(A);
+  if (fabs(B) > bound) bound = fabs(B);
+  if (fabs(C) > bound) bound = fabs(C);
+  double xl = 0.0, xh = 1.0 + bound;
+  double rts = 0.5 * (xl + xh);
+  double dxold = xh - xl, dx = dxold;
+  double f = ((rts + A) * rts + B) * rts + C;
+  double df = (3.0 * rts + 2.0 * A) * rts + B;
+  for (int it = 0; it < 128; ++it) {
+    if (f == 0.0) break;
+    if (f < 0.0) xl = rts;
+    else xh = rts;
+    const double prev = rts;
+    if ((((rts - xh) * df - f) * ((rts - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
+      dxold = dx;
+      dx = 0.5 * (xh - xl);
+      rts = xl + dx;
+    } else {
+      dxold = dx;
+      dx = f / df;
+      rts = rts - dx;
+    }
+    if (rts == prev) break;
+    f = ((rts + A) * rts + B) * rts + C;
+    df = (3.0 * rts + 2.0 * A) * rts + B;
+  }
+  return rts;
+}
+
+__device__ __forceinline__ int quad_roots(double b, double c, double* r) {
+  const double disc = b * b - 4.0 * c;
+  if (disc < 0.0) return 0;
+  const double sq = sqrt(disc);
+  const double q = (b >= 0.0) ? -0.5 * (b + sq) : -0.5 * (b - sq);
+  r[0] = q;
+  r[1] = (q != 0.0) ? c / q : 0.0;
+  return 2;
+}
+
+__device__ int quartic_roots(double c0, double c1, double c2, double c3, double c4, double* roots) {
+  if (c4 == 0.0) return 0;
+  const double a3 = c3 / c4, a2 = c2 / c4, a1 = c1 / c4, a0 = c0 / c4;
+  const double a3sq = a3 * a3;
+  const double p = a2 - 0.375 * a3sq;
+  const double q = a1 - 0.5 * a2 * a3 + 0.125 * a3sq * a3;
+  const double r = a0 - 0.25 * a1 * a3 + 0.0625 * a2 * a3sq - (3.0 / 256.0) * a3sq * a3sq;
+  double y[4];
+  int n = 0;
+  if (q == 0.0) {
+    double z[2];
+    const int nz = quad_roots(p, r, z);
+    for (int i = 0; i < nz; ++i) {
+      if (z[i] >= 0.0) {
+        const double s = sqrt(z[i]);
+        y[n++] = s;
+        y[n++] = -s;
+      }
+    }
+  } else {
+    const double m = cubic_root_bracketed(p, 0.25 * p * p - r, -0.125 * q * q);
+    if (!(m > 0.0)) return 0;
+    const double s = sqrt(2.0 * m);
+    const double h = 0.5 * p + m;
+    const double g = q / (2.0 * s);
+    n += quad_roots(s, h - g, y + n);
+    n += quad_roots(-s, h + g, y + n);
+  }
+  const double shift = 0.25 * a3;
+  for (int i = 0; i < n; ++i) {
+    double x = y[i] - shift;
+    for (int it = 0; it < 3; ++it) {
+      const double f = (((x + a3) * x + a2) * x + a1) * x + a0;
+      const double df = ((4.0 * x + 3.0 * a3) * x + 2.0 * a2) * x + a1;
+      if (df == 0.0) break;
+      x = x - f / df;
+    }
+    roots[i] = x;
+  }
+  return n;
+}
+
+// orthonormal frame of a point triple; E row-major with the frame vectors as columns
+__device__ __forceinline__ bool frame_of(const double* p1, const double* p2, const double* p3, double* E) {
+  const double ax = p2[0] - p1[0], ay = p2[1] - p1[1], az = p2[2] - p1[2];
+  const double bx = p3[0] - p1[0], by = p3[1] - p1[1], bz = p3[2] - p1[2];
+  const double na = sqrt(ax * ax + ay * ay + az * az);
+  if (!(na > 0.0)) return false;
+  const double e1x = ax / na, e1y = ay / na, e1z = az / na;
+  double e3x = e1y * bz - e1z * by;
+  double e3y = e1z * bx - e1x * bz;
+  double e3z = e1x * by - e1y * bx;
+  const double n3 = sqrt(e3x * e3x + e3y * e3y + e3z * e3z);
+  if (!(n3 > 0.0)) return false;
+  e3x /= n3;
+  e3y /= n3;
+  e3z /= n3;
+  const double e2x = e3y * e1z - e3z * e1y;
+  const double e2y = e3z * e1x - e3x * e1z;
+  const double e2z = e3x * e1y - e3y * e1x;
+  E[0] = e1x; E[1] = e2x; E[2] = e3x;
+  E[3] = e1y; E[4] = e2y; E[5] = e3y;
+  E[6] = e1z; E[7] = e2z; E[8] = e3z;
+  return true;
+}
+
+__device__ __forceinline__ double reproj_sq(const double* R, const double* t, double fx, double fy, double cx,
+                                            double cy, double X, double Y, double Z, double u0, double v0) {
+  const double xc = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+  const double yc = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+  const double zc = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+  const double iz = (zc != 0.0) ? 1.0 / zc : 1.0;
+  const double xn = xc * iz, yn = yc * iz;
+  const double u = xn * fx + cx;
+  const double v = yn * fy + cy;
+  const double dx = u0 - u, dy = v0 - v;
+  const double nrm = sqrt(dx * dx + dy * dy);
+  return nrm * nrm;
+}
+
+__global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
+                                                       const int* __restrict__ samples, int Hyp, double fx,
+                                                       double fy, double cx, double cy, double* __restrict__ Rout,
+                                                       double* __restrict__ tout, uint8_t* __restrict__ valid) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= Hyp) return;
+  double P[4][3], px[4][2];
+  for (int k = 0; k < 4; ++k) {
+    const int idx = samples[4 * h + k];
+    P[k][0] = Xw[3 * idx];
+    P[k][1] = Xw[3 * idx + 1];
+    P[k][2] = Xw[3 * idx + 2];
+    px[k][0] = xi[2 * idx];
+    px[k][1] = xi[2 * idx + 1];
+  }
+  double f[3][3];
+  for (int i = 0; i < 3; ++i) {
+    const double mu = (px[i][0] - cx) / fx, mv = (px[i][1] - cy) / fy;
+    const double nrm = sqrt(mu * mu + mv * mv + 1.0);
+    f[i][0] = mu / nrm;
+    f[i][1] = mv / nrm;
+    f[i][2] = 1.0 / nrm;
+  }
+  double d12s = 0, d13s = 0, d23s = 0;
+  for (int k = 0; k < 3; ++k) {
+    const double a = P[0][k] - P[1][k], b = P[0][k] - P[2][k], c = P[1][k] - P[2][k];
+    d12s += a * a;
+    d13s += b * b;
+    d23s += c * c;
+  }
+  bool found = false;
+  double bestR[9], bestt[3], best = 0.0;
+  double Ew[9];
+  if (d12s > 0.0 && d13s > 0.0 && d23s > 0.0 && frame_of(P[0], P[1], P[2], Ew)) {
+    const double c12 = f[0][0] * f[1][0] + f[0][1] * f[1][1] + f[0][2] * f[1][2];
+    const double c13 = f[0][0] * f[2][0] + f[0][1] * f[2][1] + f[0][2] * f[2][2];
+    const double c23 = f[1][0] * f[2][0] + f[1][1] * f[2][1] + f[1][2] * f[2][2];
+    // depth ratios u = s2/s1, v = s3/s1:  u = Nn(v)/Dd(v), quartic in v (see oracle/csrc/p3p.c header)
+    const double a = d12s / d13s, b = d23s / d13s, g = a - b;
+    const double n2 = 1.0 + g, n1 = -2.0 * g * c13, n0 = g - 1.0;
+    const double e1 = 2.0 * c23, e0 = -2.0 * c12;
+    const double w2 = -a, w1 = 2.0 * a * c13, w0 = 1.0 - a;
+    const double dd2 = e1 * e1, dd1 = 2.0 * e1 * e0, dd0 = e0 * e0;
+    const double nd3 = n2 * e1, nd2 = n2 * e0 + n1 * e1, nd1 = n1 * e0 + n0 * e1, nd0 = n0 * e0;
+    const double tc = 2.0 * c12;
+    const double q4 = n2 * n2 + w2 * dd2;
+    const double q3 = 2.0 * n2 * n1 - tc * nd3 + (w2 * dd1 + w1 * dd2);
+    const double q2 = (2.0 * n2 * n0 + n1 * n1) - tc * nd2 + (w2 * dd0 + w1 * dd1 + w0 * dd2);
+    const double q1 = 2.0 * n1 * n0 - tc * nd1 + (w1 * dd0 + w0 * dd1);
+    const double q0 = n0 * n0 - tc * nd0 + w0 * dd0;
+    double roots[4];
+    const int nr = quartic_roots(q0, q1, q2, q3, q4, roots);
+    for (int i = 0; i < nr; ++i) {
+      const double v = roots[i];
+      if (!(v > 0.0)) continue;
+      const double Dd = e1 * v + e0;
+      if (fabs(Dd) < 1e-12) continue;
+      const double Nn = (n2 * v + n1) * v + n0;
+      const double u = Nn / Dd;
+      if (!(u > 0.0)) continue;
+      const double qv = (v - 2.0 * c13) * v + 1.0;
+      if (!(qv > 0.0)) continue;
+      const double s1 = sqrt(d13s / qv);
+      const double s2 = u * s1, s3 = v * s1;
+      const double C1[3] = {s1 * f[0][0], s1 * f[0][1], s1 * f[0][2]};
+      const double C2[3] = {s2 * f[1][0], s2 * f[1][1], s2 * f[1][2]};
+      const double C3[3] = {s3 * f[2][0], s3 * f[2][1], s3 * f[2][2]};
+      double Ec[9];
+      if (!frame_of(C1, C2, C3, Ec)) continue;
+      double R[9], t[3];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+          R[3 * r + c] = Ec[3 * r + 0] * Ew[3 * c + 0] + Ec[3 * r + 1] * Ew[3 * c + 1] + Ec[3 * r + 2] * Ew[3 * c + 2];
+      for (int r = 0; r < 3; ++r)
+        t[r] = C1[r] - (R[3 * r] * P[0][0] + R[3 * r + 1] * P[0][1] + R[3 * r + 2] * P[0][2]);
+      const double e = reproj_sq(R, t, fx, fy, cx, cy, P[3][0], P[3][1], P[3][2], px[3][0], px[3][1]);
+      if (!(e == e)) continue;
+      if (!found || e < best) {
+        found = true;
+        best = e;
+        for (int k = 0; k < 9; ++k) bestR[k] = R[k];
+        for (int k = 0; k < 3; ++k) bestt[k] = t[k];
+      }
+    }
+  }
+  for (int k = 0; k < 9; ++k) Rout[9 * h + k] = found ? bestR[k] : 0.0;
+  for (int k = 0; k < 3; ++k) tout[3 * h + k] = found ? bestt[k] : 0.0;
+  valid[h] = found ? 1 : 0;
+}
+
+constexpr int SC_T = 256;
+
+// one workgroup per hypothesis; mask row h holds ceil(N/64) 64-bit words
+__global__ __launch_bounds__(SC_T) void p3p_score_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
+                                                         int N, const double* __restrict__ Rall,
+                                                         const double* __restrict__ tall,
+                                                         const uint8_t* __restrict__ valid, double fx, double fy,
+                                                         double cx, double cy, double thr, int* __restrict__ counts,
+                                                         unsigned long long* __restrict__ masks, int words) {
+  const int h = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ int s_cnt[SC_T / 64];
+  double R[9], t[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rall[9 * h + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = tall[3 * h + k];
+  const bool ok = valid[h] != 0;
+  int cnt = 0;
+  for (int base = 0; base < words * 64; base += SC_T) {
+    const int i = base + tid;
+    bool in = false;
+    if (ok && i < N) {
+      const double e = reproj_sq(R, t, fx, fy, cx, cy, Xw[3 * i], Xw[3 * i + 1], Xw[3 * i + 2], xi[2 * i], xi[2 * i + 1]);
+      in = e < thr;
+    }
+    const unsigned long long m = __ballot(in);
+    const int w = i >> 6;
+    if ((tid & 63) == 0 && w < words) {
+      if (masks) masks[(size_t)h * words + w] = m;
+      cnt += __popcll(m);
+    }
+  }
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int s = 0;
+    for (int k = 0; k < SC_T / 64; ++k) s += s_cnt[k];
+    counts[h] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void reproj_kernel(const double* __restrict__ Xw, const double* __restrict__ xi, int N,
+                                                     const double* __restrict__ Rt, double fx, double fy, double cx,
+                                                     double cy, double thr, uint8_t* __restrict__ mask,
+                                                     double* __restrict__ err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double R[9], t[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rt[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = Rt[9 + k];
+  const double e = reproj_sq(R, t, fx, fy, cx, cy, Xw[3 * i], Xw[3 * i + 1], Xw[3 * i + 2], xi[2 * i], xi[2 * i + 1]);
+  if (mask) mask[i] = e < thr ? 1 : 0;
+  if (err) err[i] = e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const double* K,
+                          const int32_t* d_samples, int Hyp, double thr_sq, double* d_R, double* d_t,
+                          uint8_t* d_valid, int32_t* d_counts, uint64_t* d_masks) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, d_X && d_x && K && d_samples && d_R && d_t && d_valid && d_counts, "p3p_hypotheses: null pointer");
+  VO_REQUIRE(ctx, N >= 4 && Hyp >= 1, "p3p_hypotheses: need N >= 4 and Hyp >= 1");
+  VO_REQUIRE(ctx, K[0] != 0.0 && K[4] != 0.0, "p3p_hypotheses: singular intrinsics");
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  {
+    vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
+    hipLaunchKernelGGL(p3p_solve_kernel, dim3(vo_cdiv(Hyp, 64)), dim3(64), 0, ctx->stream, d_X, d_x, d_samples, Hyp,
+                       fx, fy, cx, cy, d_R, d_t, d_valid);
+  }
+  VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
+  const int words = vo_cdiv(N, 64);
+  {
+    vo_prof_scope ps(ctx, VO_K_P3P_SCORE);
+    hipLaunchKernelGGL(p3p_score_kernel, dim3(Hyp), dim3(SC_T), 0, ctx->stream, d_X, d_x, N, d_R, d_t, d_valid, fx,
+                       fy, cx, cy, thr_sq, d_counts, (unsigned long long*)d_masks, words);
+  }
+  return vo_check_launch(ctx, "p3p_score_kernel");
+}
+
+int vo_reproj_inliers_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const double* K,
+                          const double* d_Rt /* 9 + 3 */, double thr_sq, uint8_t* d_mask, double* d_err) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, d_X && d_x && K && d_Rt && (d_mask || d_err), "reproj_inliers: null pointer");
+  VO_REQUIRE(ctx, N >= 0, "reproj_inliers: bad N");
+  if (N == 0) return VO_OK;
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    vo_prof_scope ps(ctx, VO_K_REPROJ);
+    hipLaunchKernelGGL(reproj_kernel, dim3(vo_cdiv(N, 256)), dim3(256), 0, ctx->stream, d_X, d_x, N, d_Rt, K[0], K[4],
+                       K[2], K[5], thr_sq, d_mask, d_err);
+  }
+  return vo_check_launch(ctx, "reproj_kernel");
+}
+
+// ---- host-buffer wrappers ------------------------------------------------------------
+
+int vo_p3p_hypotheses(vo_ctx* ctx, const double* X, const double* x, int N, const double* K, const int32_t* samples,
+                      int Hyp, double thr_sq, double* R, double* t, uint8_t* valid, int32_t* counts,
+                      uint64_t* masks /* nullable, Hyp*ceil(N/64) */) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, X && x && K && samples && R && t && valid && counts, "p3p_hypotheses: null pointer");
+  VO_REQUIRE(ctx, N >= 4 && Hyp >= 1, "p3p_hypotheses: need N >= 4 and Hyp >= 1");
+  for (int i = 0; i < 4 * Hyp; ++i)
+    VO_REQUIRE(ctx, samples[i] >= 0 && samples[i] < N, "p3p_hypotheses: sample index %d out of range", samples[i]);
+  const int words = vo_cdiv(N, 64);
+  vo_buf* s = ctx->scratch;
+  VO_TRY(vo_ensure(ctx, s[0], (size_t)N * 24));
+  VO_TRY(vo_ensure(ctx, s[1], (size_t)N * 16));
+  VO_TRY(vo_ensure(ctx, s[2], (size_t)Hyp * 16));
+  VO_TRY(vo_ensure(ctx, s[3], (size_t)Hyp * 72));
+  VO_TRY(vo_ensure(ctx, s[4], (size_t)Hyp * 24));
+  VO_TRY(vo_ensure(ctx, s[5], (size_t)Hyp));
+  VO_TRY(vo_ensure(ctx, s[6], (size_t)Hyp * 4));
+  VO_TRY(vo_ensure(ctx, s[7], (size_t)Hyp * words * 8));
+  hipStream_t st = ctx->stream;
+  VO_HIP_TRY(ctx, hipMemcpyAsync(s[0].p, X, (size_t)N * 24, hipMemcpyHostToDevice, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(s[1].p, x, (size_t)N * 16, hipMemcpyHostToDevice, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(s[2].p, samples, (size_t)Hyp * 16, hipMemcpyHostToDevice, st));
+  VO_TRY(vo_p3p_hypotheses_dev(ctx, (const double*)s[0].p, (const double*)s[1].p, N, K, (const int32_t*)s[2].p, Hyp,
+                               thr_sq, (double*)s[3].p, (double*)s[4].p, (uint8_t*)s[5].p, (int32_t*)s[6].p,
+                               (uint64_t*)s[7].p));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(R, s[3].p, (size_t)Hyp * 72, hipMemcpyDeviceToHost, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(t, s[4].p, (size_t)Hyp * 24, hipMemcpyDeviceToHost, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(valid, s[5].p, (size_t)Hyp, hipMemcpyDeviceToHost, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(counts, s[6].p, (size_t)Hyp * 4, hipMemcpyDeviceToHost, st));
+  if (masks) VO_HIP_TRY(ctx, hipMemcpyAsync(masks, s[7].p, (size_t)Hyp * words * 8, hipMemcpyDeviceToHost, st));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  return VO_OK;
+}
+
+int vo_reproj_inliers(vo_ctx* ctx, const double* X, const double* x, int N, const double* K, const double* R,
+                      const double* t, double thr_sq, uint8_t* mask, double* err) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, X && x && K && R && t && (mask || err), "reproj_inliers: null pointer");
+  VO_REQUIRE(ctx, N >= 0, "reproj_inliers: bad N");
+  if (N == 0) return VO_OK;
+  vo_buf* s = ctx->scratch;
+  VO_TRY(vo_ensure(ctx, s[0], (size_t)N * 24));
+  VO_TRY(vo_ensure(ctx, s[1], (size_t)N * 16));
+  VO_TRY(vo_ensure(ctx, s[2], 96));
+  VO_TRY(vo_ensure(ctx, s[5], (size_t)N));
+  VO_TRY(vo_ensure(ctx, s[3], (size_t)N * 8));
+  double Rt[12];
+  memcpy(Rt, R, 72);
+  memcpy(Rt + 9, t, 24);
+  hipStream_t st = ctx->stream;
+  VO_HIP_TRY(ctx, hipMemcpyAsync(s[0].p, X, (size_t)N * 24, hipMemcpyHostToDevice, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(s[1].p, x, (size_t)N * 16, hipMemcpyHostToDevice, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(s[2].p, Rt, 96, hipMemcpyHostToDevice, st));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(st));   // Rt is a stack buffer
+  VO_TRY(vo_reproj_inliers_dev(ctx, (const double*)s[0].p, (const double*)s[1].p, N, K, (const double*)s[2].p, thr_sq,
+                               mask ? (uint8_t*)s[5].p : nullptr, err ? (double*)s[3].p : nullptr));
+  if (mask) VO_HIP_TRY(ctx, hipMemcpyAsync(mask, s[5].p, (size_t)N, hipMemcpyDeviceToHost, st));
+  if (err) VO_HIP_TRY(ctx, hipMemcpyAsync(err, s[3].p, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  return VO_OK;
+}
+
+}  // extern "C"

@@ -53,6 +53,18 @@ _SIGS = {
     "vo_nms_keypoints_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vo_patch_descriptors": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "vo_patch_descriptors_dev": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "vo_klt_num_levels": (_i, [_i, _i, _i, _i]),
+    "vo_pyramid_bytes": (_sz, [_i, _i, _i]),
+    "vo_pyr_down": (_i, [_vp, _vp, _i, _i, _vp]),
+    "vo_pyramid_build_dev": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "vo_klt_track": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp]),
+    "vo_klt_track_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _d, _d, _vp, _vp, _vp]),
+    "vo_triangulate_dlt": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "vo_triangulate_dlt_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "vo_p3p_hypotheses": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "vo_p3p_hypotheses_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "vo_reproj_inliers": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),
+    "vo_reproj_inliers_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
 }
 
 
@@ -198,7 +210,107 @@ class Context:
         self._chk(self._lib.vo_patch_descriptors(self._h, _ptr(img), H, W, _ptr(kp), n, int(r), _ptr(out)))
         return out
 
+    # ---- KLT ----
+    def klt_num_levels(self, H, W, win, max_level):
+        return self._lib.vo_klt_num_levels(int(H), int(W), int(win), int(max_level))
+
+    def pyramid_bytes(self, H, W, n_levels):
+        return self._lib.vo_pyramid_bytes(int(H), int(W), int(n_levels))
+
+    def pyr_down(self, img):
+        img = _c(img, np.uint8)
+        H, W = img.shape
+        out = np.empty(((H + 1) // 2, (W + 1) // 2), np.uint8)
+        self._chk(self._lib.vo_pyr_down(self._h, _ptr(img), H, W, _ptr(out)))
+        return out
+
+    def klt_track(self, prev, nxt, prev_xy, win=17, max_level=2, max_iter=10, eps=0.03, min_eig=1e-4):
+        prev = _c(prev, np.uint8)
+        nxt = _c(nxt, np.uint8)
+        assert prev.shape == nxt.shape and prev.ndim == 2
+        H, W = prev.shape
+        pts = _c(np.asarray(prev_xy).reshape(-1, 2), np.float32)
+        n = pts.shape[0]
+        out = np.empty((n, 2), np.float32)
+        status = np.empty(n, np.uint8)
+        err = np.empty(n, np.float32)
+        self._chk(self._lib.vo_klt_track(self._h, _ptr(prev), _ptr(nxt), H, W, _ptr(pts), n, int(win), int(max_level),
+                                         int(max_iter), float(eps), float(min_eig), _ptr(out), _ptr(status), _ptr(err)))
+        return out, status, err
+
+    # ---- DLT ----
+    def triangulate_dlt(self, x1, x2, C1, C2):
+        x1 = _c(np.asarray(x1).reshape(-1, 2), np.float64)
+        x2 = _c(np.asarray(x2).reshape(-1, 2), np.float64)
+        n = x1.shape[0]
+        C1 = _c(C1, np.float64)
+        C2 = _c(C2, np.float64).reshape(3, 4)
+        per_point = 1 if C1.ndim == 3 else 0
+        assert C1.shape[-2:] == (3, 4) and (not per_point or C1.shape[0] == n)
+        X = np.empty((n, 3), np.float64)
+        self._chk(self._lib.vo_triangulate_dlt(self._h, _ptr(x1), _ptr(x2), n, _ptr(C1), per_point, _ptr(C2), _ptr(X)))
+        return X
+
+    # ---- P3P ----
+    def p3p_hypotheses(self, X, x, K, samples, thr_sq, want_masks=False):
+        X = _c(np.asarray(X).reshape(-1, 3), np.float64)
+        x = _c(np.asarray(x).reshape(-1, 2), np.float64)
+        K = _c(K, np.float64).reshape(3, 3)
+        samples = _c(np.asarray(samples).reshape(-1, 4), np.int32)
+        n, h = X.shape[0], samples.shape[0]
+        R = np.empty((h, 3, 3), np.float64)
+        t = np.empty((h, 3), np.float64)
+        valid = np.empty(h, np.uint8)
+        counts = np.empty(h, np.int32)
+        words = (n + 63) // 64
+        masks = np.empty((h, words), np.uint64) if want_masks else None
+        self._chk(self._lib.vo_p3p_hypotheses(self._h, _ptr(X), _ptr(x), n, _ptr(K), _ptr(samples), h, float(thr_sq),
+                                              _ptr(R), _ptr(t), _ptr(valid), _ptr(counts), _ptr(masks)))
+        if want_masks:
+            bits = np.unpackbits(masks.view(np.uint8).reshape(h, words * 8), axis=1, bitorder="little")[:, :n]
+            return R, t, valid, counts, bits.astype(bool)
+        return R, t, valid, counts
+
+    def reproj_inliers(self, X, x, K, R, t, thr_sq, want_err=False):
+        X = _c(np.asarray(X).reshape(-1, 3), np.float64)
+        x = _c(np.asarray(x).reshape(-1, 2), np.float64)
+        K = _c(K, np.float64).reshape(3, 3)
+        R = _c(R, np.float64).reshape(3, 3)
+        t = _c(np.asarray(t).reshape(3), np.float64)
+        n = X.shape[0]
+        mask = np.empty(n, np.uint8)
+        err = np.empty(n, np.float64) if want_err else None
+        self._chk(self._lib.vo_reproj_inliers(self._h, _ptr(X), _ptr(x), n, _ptr(K), _ptr(R), _ptr(t), float(thr_sq),
+                                              _ptr(mask), _ptr(err)))
+        return (mask.astype(bool), err) if want_err else mask.astype(bool)
+
     # ---- device-pointer variants (async on the context's stream) ----
+    def pyramid_build_dev(self, d_img, H, W, n_levels, d_pyr):
+        self._chk(self._lib.vo_pyramid_build_dev(self._h, C.c_void_p(d_img), H, W, int(n_levels), C.c_void_p(d_pyr)))
+
+    def klt_track_dev(self, d_prev, d_prev_pyr, d_next, d_next_pyr, H, W, n_levels, d_prev_xy, N, win, max_iter, eps,
+                      min_eig, d_next_xy, d_status, d_err):
+        self._chk(self._lib.vo_klt_track_dev(self._h, C.c_void_p(d_prev), C.c_void_p(d_prev_pyr), C.c_void_p(d_next),
+                                             C.c_void_p(d_next_pyr), H, W, int(n_levels), C.c_void_p(d_prev_xy), int(N),
+                                             int(win), int(max_iter), float(eps), float(min_eig),
+                                             C.c_void_p(d_next_xy), C.c_void_p(d_status), C.c_void_p(d_err)))
+
+    def triangulate_dlt_dev(self, d_x1, d_x2, n, d_C1, per_point, d_C2, d_X):
+        self._chk(self._lib.vo_triangulate_dlt_dev(self._h, C.c_void_p(d_x1), C.c_void_p(d_x2), int(n),
+                                                   C.c_void_p(d_C1), int(per_point), C.c_void_p(d_C2), C.c_void_p(d_X)))
+
+    def p3p_hypotheses_dev(self, d_X, d_x, N, K, d_samples, Hyp, thr_sq, d_R, d_t, d_valid, d_counts, d_masks):
+        K = _c(K, np.float64).reshape(3, 3)
+        self._chk(self._lib.vo_p3p_hypotheses_dev(self._h, C.c_void_p(d_X), C.c_void_p(d_x), int(N), _ptr(K),
+                                                  C.c_void_p(d_samples), int(Hyp), float(thr_sq), C.c_void_p(d_R),
+                                                  C.c_void_p(d_t), C.c_void_p(d_valid), C.c_void_p(d_counts),
+                                                  C.c_void_p(d_masks)))
+
+    def reproj_inliers_dev(self, d_X, d_x, N, K, d_Rt, thr_sq, d_mask, d_err):
+        K = _c(K, np.float64).reshape(3, 3)
+        self._chk(self._lib.vo_reproj_inliers_dev(self._h, C.c_void_p(d_X), C.c_void_p(d_x), int(N), _ptr(K),
+                                                  C.c_void_p(d_Rt), float(thr_sq), C.c_void_p(d_mask), C.c_void_p(d_err)))
+
     def harris_response_dev(self, d_img, H, W, patch, kappa, d_scores):
         self._chk(self._lib.vo_harris_response_dev(self._h, C.c_void_p(d_img), H, W, int(patch), float(kappa),
                                                    C.c_void_p(d_scores)))
