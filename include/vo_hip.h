@@ -77,6 +77,7 @@ enum {
   VO_K_P3P_SCORE = 10,
   VO_K_REPROJ = 11,
   VO_K_MATCH = 12,
+  VO_K_GATHER = 13,
   VO_K_COUNT = 32
 };
 int vo_prof_enable(vo_ctx* ctx, int kernel_id);
@@ -170,6 +171,78 @@ int vo_reproj_inliers(vo_ctx* ctx, const double* X, const double* x, int N, cons
 int vo_reproj_inliers_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N,
                           const double* K, const double* d_Rt, double thr_sq,
                           uint8_t* d_mask, double* d_err);
+
+/* ---- RANSAC control (host-side, bit-compatible with the reference) --------------
+ * [ref: src/vo/algorithms/ransac.py:52, 92-94]  the sample stream of
+ *   np.random.default_rng(2023).choice(np.arange(pop), replace=False, size=s)
+ * vo_pcg64 is NumPy's PCG64 bit-generator state (Generator.bit_generator.state:
+ * 128-bit state and increment split into 64-bit halves, plus the buffered 32-bit
+ * half).  vo_rng_choice draws `count` samples of s indices and advances the state.
+ * [ref: src/vo/algorithms/ransac.py:58-67, 90-121]  vo_ransac_replay walks
+ * pre-computed hypotheses (valid, inlier count) through the reference's sequential
+ * accept / adaptive-iteration rule; vo_ransac_state holds the fields that persist
+ * on the reference's RANSAC object between calls.  max_iterations < 0 = unbounded. */
+typedef struct vo_pcg64 {
+  uint64_t state_hi, state_lo, inc_hi, inc_lo;
+  uint32_t has_uint32, uinteger;
+} vo_pcg64;
+typedef struct vo_ransac_state {
+  double outlier_ratio, confidence;
+  int64_t max_iterations, n_iterations;
+  int32_t s, adaptive;
+} vo_ransac_state;
+int vo_rng_choice(vo_pcg64* rng, int pop, int s, int count, int32_t* out);
+int64_t vo_ransac_num_iterations(double confidence, double outlier_ratio, int s);
+int vo_ransac_replay(vo_ransac_state* st, const uint8_t* valid, const int32_t* counts, int B,
+                     int N, int64_t* n_done, int32_t* best_count, int32_t* best_idx,
+                     int idx_offset, int* consumed, int* finished);
+
+/* ---- device-resident frame pipeline ------------------------------------------------
+ * One vo_pipeline keeps a synthetic stream (images, per-pixel depth, camera poses)
+ * resident in HBM and runs the per-frame front-end of the reference driver
+ * [ref: src/main.py:248-286] as one call per frame:
+ *   pyramid(next) -> KLT prev->next (klt.py:233-249, keep status & err < thr)
+ *   -> Harris response + NMS on next (harris.py:86-158; the detector that feeds the
+ *      following step)
+ *   -> P3P-RANSAC on (landmark, tracked point) pairs: `hyp` samples drawn with the
+ *      reference's generator, solved and scored on the GPU, sequential rule replayed
+ *      (p3p.py:123-186 with use_opencv=False, nonlinear refinement excluded)
+ *   -> DLT triangulation of the tracked pairs (triangulation.py:352-389).
+ * Landmarks of the previous frame's keypoints come from the stream's depth maps
+ * (the synthetic stand-in for the map the reference accumulates in State).       */
+typedef struct vo_pipeline vo_pipeline;
+typedef struct vo_pipeline_config {
+  int32_t H, W, n_frames;
+  int32_t n_keypoints, harris_patch, nms_radius;
+  double harris_kappa;
+  int32_t klt_win, klt_max_level, klt_max_iter, hyp;
+  double klt_eps, klt_min_eig, klt_err_threshold;
+  double p3p_thr_sq, ransac_outlier_ratio, ransac_confidence;
+  int64_t ransac_max_iterations;
+  double K[9];
+} vo_pipeline_config;
+typedef struct vo_step_result {
+  double R[9], t[3];            /* world -> camera pose of `next` (best hypothesis)   */
+  int32_t n_tracked;            /* correspondences surviving the KLT filter           */
+  int32_t n_inliers;            /* inliers of the returned pose                       */
+  int32_t best_index;           /* index of the accepted hypothesis                   */
+  int32_t hyp_valid;            /* hypotheses with a P3P solution among those scored  */
+  int64_t ransac_iterations;    /* iterations the reference loop would have counted   */
+  int32_t draws_consumed;       /* samples consumed from the generator                */
+  int32_t pad;
+} vo_step_result;
+int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out);
+void vo_pipeline_destroy(vo_pipeline* p);
+int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img, const float* depth,
+                          const double* T_world_cam /* 4x4 row-major */);
+int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng);
+int vo_pipeline_prime(vo_pipeline* p, int idx);
+int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out);
+/* copies of the last step's device arrays: keypoints of `next` (n_keypoints*2 f64),
+ * tracked pairs (n_tracked: prev xy f64, next xy f64, landmark xyz f64), triangulated
+ * points (n_tracked*3 f64), inlier mask (n_tracked bytes).  Any pointer may be NULL. */
+int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* next_xy,
+                      double* landmarks, double* triangulated, uint8_t* inliers);
 
 #ifdef __cplusplus
 }

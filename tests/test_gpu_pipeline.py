@@ -1,0 +1,75 @@
+"""-m gpu: the device-resident frame pipeline (vo_pipeline_*) against the same
+stages composed from the CPU oracles, frame by frame."""
+import numpy as np
+import pytest
+
+from oracle import dlt_np, harris_np, native, ransac_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vo import _native
+    c = _native.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_step(stream, prev, nxt, kp_prev, rs, cfg):
+    """One frame of the front-end with CPU oracles; rs = persistent oracle Ransac object."""
+    K = stream.K
+    out, status, err = native.klt_track(stream.image(prev), stream.image(nxt), kp_prev.astype(np.float32),
+                                        win=cfg["win"], max_level=cfg["lvl"])
+    keep = status.astype(bool) & (err < 100.0)
+    p_c, n_c = kp_prev[keep], out[keep].astype(np.float64)
+    z = stream.depth(prev)[p_c[:, 1].astype(int), p_c[:, 0].astype(int)].astype(np.float64)
+    xc = (p_c[:, 0] - K[0, 2]) / K[0, 0] * z
+    yc = (p_c[:, 1] - K[1, 2]) / K[1, 1] * z
+    T = stream.T_world_cam(prev)
+    land = np.stack([T[r, 0] * xc + T[r, 1] * yc + T[r, 2] * z + T[r, 3] for r in range(3)], axis=1)
+    sc = harris_np.harris_scores(stream.image(nxt), 9, 0.09)
+    kp_next = harris_np.nms_keypoints_fast(sc, cfg["N"], 5)[:, :, 0]
+    # re-bind the oracle RANSAC to this frame's correspondences (the estimator object persists)
+    rs.model_fn = lambda idx: native.p3p_solve(land[np.asarray(idx).reshape(-1)], n_c[np.asarray(idx).reshape(-1)], K)
+    rs.error_fn = lambda m, pop: native.reproj_errors(land, n_c, K, m[0], m[1])
+    n0 = len(rs.trace)
+    (R, t), inl = rs.find_best_model(np.arange(len(land)))
+    Tcw = np.linalg.inv(T)
+    tri = dlt_np.linear_triangulation(p_c, n_c, K @ Tcw[:3], K @ np.hstack([R, t[:, None]]))
+    return dict(kp_next=kp_next, prev_xy=p_c, next_xy=n_c, landmarks=land, R=R, t=t, inliers=inl, tri=tri,
+                draws=len(rs.trace) - n0, iters=rs.iterations_done)
+
+
+@pytest.mark.parametrize("H,W,N,hyp", [(240, 320, 300, 256), (480, 640, 500, 1000)])
+def test_pipeline_matches_oracle_composition(ctx, H, W, N, hyp):
+    from vo import _native, synthetic
+    F = 4
+    stream = synthetic.Stream(F, H, W)
+    cfg = dict(win=15, lvl=2, N=N)
+    pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp,
+                            p3p_threshold=1.0, max_iterations=1000)
+    for i in range(F):
+        pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
+    order = stream.order(6)
+    pipe.prime(order[0])
+    kp = harris_np.nms_keypoints_fast(harris_np.harris_scores(stream.image(order[0]), 9, 0.09), N, 5)[:, :, 0]
+    rs = ransac_np.Ransac(4, np.arange(4), None, None, 1.0, 0.9, 0.99, 1000, adaptive=True, p3p=True)
+    for a, b in zip(order[:-1], order[1:]):
+        ref = oracle_step(stream, a, b, kp, rs, cfg)
+        r = pipe.step(a, b)
+        got = pipe.fetch(r.n_tracked)
+        assert r.n_tracked == len(ref["prev_xy"])
+        assert np.array_equal(got["kp_next"], ref["kp_next"])
+        assert np.array_equal(got["prev_xy"], ref["prev_xy"]) and np.array_equal(got["next_xy"], ref["next_xy"])
+        assert np.allclose(got["landmarks"], ref["landmarks"], rtol=1e-12, atol=1e-12)
+        assert r.draws_consumed == ref["draws"] and r.ransac_iterations == ref["iters"]
+        R, t = np.array(r.R).reshape(3, 3), np.array(r.t)
+        assert np.allclose(R, ref["R"], atol=1e-9) and np.allclose(t, ref["t"], atol=1e-9)
+        assert np.array_equal(got["inliers"], ref["inliers"]) and r.n_inliers == ref["inliers"].sum()
+        assert np.allclose(got["triangulated"], ref["tri"], rtol=1e-6, atol=1e-6)
+        # against analytic ground truth of the stream
+        Tcw = np.linalg.inv(stream.T_world_cam(b))
+        assert np.abs(R - Tcw[:3, :3]).max() < 5e-3 and np.abs(t - Tcw[:3, 3]).max() < 0.1
+        kp = ref["kp_next"]
+    pipe.close()

@@ -1,0 +1,421 @@
+// Device-resident per-frame front-end (vo_pipeline_*): the call sequence of the
+// reference driver's steady-state loop (src/main.py:248-286) with every array kept in
+// HBM between stages.  See include/vo_hip.h for the stage list.
+//
+// Stream plan for one step (single HIP stream, two host waits):
+//   pyramid(next) -> KLT -> gather/compact  --event A-->  host reads n_tracked
+//   Harris response + NMS on next            (runs while the host draws the samples)
+//   H2D samples -> P3P solve -> P3P score -> D2H (valid, counts)  --event B-->  host
+//   replays the sequential RANSAC rule, fetches the winning pose, queues the DLT.
+#include "vo_internal.h"
+
+#pragma clang fp contract(off)
+
+struct vo_pipeline {
+  vo_ctx* ctx = nullptr;
+  vo_pipeline_config cfg;
+  int n_levels = 1;
+  size_t pyr_bytes = 0;
+  // resident stream
+  std::vector<uint8_t*> d_img;
+  std::vector<float*> d_depth;
+  std::vector<double> T_wc;          // n_frames * 16 (camera -> world)
+  double* d_T_wc = nullptr;          // same, on the device
+  // per-step state (double-buffered where the next step reads the previous one's output)
+  uint8_t* d_pyr[2] = {nullptr, nullptr};
+  double* d_kp[2] = {nullptr, nullptr};
+  int cur = 0;                       // buffer index holding `prev`'s pyramid / keypoints
+  int prev_frame = -1;
+  double* d_scores = nullptr;
+  float *d_prev_f32 = nullptr, *d_next_f32 = nullptr, *d_err = nullptr;
+  uint8_t* d_status = nullptr;
+  double *d_prev_c = nullptr, *d_next_c = nullptr, *d_land_c = nullptr, *d_tri = nullptr;
+  int32_t* d_ntracked = nullptr;
+  int32_t* d_samples = nullptr;
+  double *d_R = nullptr, *d_t = nullptr, *d_C = nullptr;
+  uint8_t* d_valid = nullptr;
+  int32_t* d_counts = nullptr;
+  uint64_t* d_masks = nullptr;
+  // pinned host
+  int32_t* h_ntracked = nullptr;
+  int32_t* h_samples = nullptr;
+  uint8_t* h_valid = nullptr;
+  int32_t* h_counts = nullptr;
+  double* h_pose = nullptr;          // 12
+  double* h_C = nullptr;             // 24 (C1, C2)
+  hipEvent_t evA = nullptr, evB = nullptr;
+  // RANSAC object state (persists across frames like the reference's estimator)
+  vo_pcg64 rng;
+  vo_ransac_state rs;
+  bool seeded = false;
+  // last step
+  int last_ntracked = 0, last_best = -1, last_words = 0;
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void kp_to_f32_kernel(const double* __restrict__ kp, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * n) out[i] = (float)kp[i];
+}
+
+// Keeps tracks with status != 0 and err < thr in their original order (the boolean
+// mask of klt.py:244-269), converts to float64 and looks the landmark of each
+// previous keypoint up in the depth map:  X_w = T_wc * (depth * K^-1 (x, y, 1)).
+__global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __restrict__ kp_prev,
+                                                             const float* __restrict__ next_xy,
+                                                             const uint8_t* __restrict__ status,
+                                                             const float* __restrict__ err, int N, float err_thr,
+                                                             const float* __restrict__ depth, int H, int W, double fx,
+                                                             double fy, double cx, double cy,
+                                                             const double* __restrict__ T_wc,
+                                                             double* __restrict__ prev_c, double* __restrict__ next_c,
+                                                             double* __restrict__ land_c, int32_t* __restrict__ n_out,
+                                                             int32_t* __restrict__ n_out_host) {
+  __shared__ int s_w[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < N; b0 += 1024) {
+    const int i = b0 + tid;
+    const bool keep = i < N && status[i] != 0 && err[i] < err_thr;
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wv] = __popcll(m);
+    __syncthreads();
+    int off = s_base, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wv) off += s_w[w];
+      tot += s_w[w];
+    }
+    if (keep) {
+      const int o = off + before;
+      const double x = kp_prev[2 * i], y = kp_prev[2 * i + 1];
+      prev_c[2 * o] = x;
+      prev_c[2 * o + 1] = y;
+      next_c[2 * o] = (double)next_xy[2 * i];
+      next_c[2 * o + 1] = (double)next_xy[2 * i + 1];
+      int xi = (int)x, yi = (int)y;
+      xi = min(max(xi, 0), W - 1);
+      yi = min(max(yi, 0), H - 1);
+      const double z = (double)depth[(size_t)yi * W + xi];
+      const double xc = (x - cx) / fx * z, yc = (y - cy) / fy * z;
+      land_c[3 * o] = T_wc[0] * xc + T_wc[1] * yc + T_wc[2] * z + T_wc[3];
+      land_c[3 * o + 1] = T_wc[4] * xc + T_wc[5] * yc + T_wc[6] * z + T_wc[7];
+      land_c[3 * o + 2] = T_wc[8] * xc + T_wc[9] * yc + T_wc[10] * z + T_wc[11];
+    }
+    __syncthreads();
+    if (tid == 0) s_base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *n_out = s_base;
+    *n_out_host = s_base;   // mapped pinned host memory
+  }
+}
+
+template <typename T>
+int dev_alloc(vo_ctx* ctx, T** p, size_t count) {
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T) ? count * sizeof(T) : 256);
+  if (e != hipSuccess) return vo_set_error(ctx, VO_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+  return VO_OK;
+}
+
+template <typename T>
+int pin_alloc(vo_ctx* ctx, T** p, size_t count) {
+  hipError_t e = hipHostMalloc((void**)p, count * sizeof(T), hipHostMallocMapped);
+  if (e != hipSuccess) return vo_set_error(ctx, VO_ENOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+  return VO_OK;
+}
+
+void rigid_inverse(const double* T, double* Ti) {
+  // T = [R t; 0 1] -> [R^T  -R^T t]
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Ti[4 * r + c] = T[4 * c + r];
+  for (int r = 0; r < 3; ++r) Ti[4 * r + 3] = -(Ti[4 * r] * T[3] + Ti[4 * r + 1] * T[7] + Ti[4 * r + 2] * T[11]);
+  Ti[12] = Ti[13] = Ti[14] = 0.0;
+  Ti[15] = 1.0;
+}
+
+void k_times_rt(const double* K, const double* Rt34, double* C) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c)
+      C[4 * r + c] = K[3 * r] * Rt34[c] + K[3 * r + 1] * Rt34[4 + c] + K[3 * r + 2] * Rt34[8 + c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int vo_klt_num_levels(int H, int W, int win, int max_level);
+size_t vo_pyramid_bytes(int H, int W, int n_levels);
+
+int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out) {
+  if (!ctx || !cfg || !out) return VO_EINVAL;
+  *out = nullptr;
+  VO_REQUIRE(ctx, cfg->H > 0 && cfg->W > 0 && cfg->n_frames >= 2, "pipeline: bad stream shape");
+  VO_REQUIRE(ctx, cfg->n_keypoints >= 4 && cfg->n_keypoints <= 16384, "pipeline: n_keypoints must be in 4..16384");
+  VO_REQUIRE(ctx, cfg->hyp >= 1, "pipeline: hyp must be >= 1");
+  VO_REQUIRE(ctx, cfg->K[0] != 0.0 && cfg->K[4] != 0.0, "pipeline: singular intrinsics");
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  vo_pipeline* p = new (std::nothrow) vo_pipeline();
+  if (!p) return VO_ENOMEM;
+  p->ctx = ctx;
+  p->cfg = *cfg;
+  const int N = cfg->n_keypoints, Hyp = cfg->hyp;
+  const size_t px = (size_t)cfg->H * cfg->W;
+  p->n_levels = vo_klt_num_levels(cfg->H, cfg->W, cfg->klt_win, cfg->klt_max_level);
+  p->pyr_bytes = vo_pyramid_bytes(cfg->H, cfg->W, p->n_levels);
+  p->d_img.assign(cfg->n_frames, nullptr);
+  p->d_depth.assign(cfg->n_frames, nullptr);
+  p->T_wc.assign((size_t)cfg->n_frames * 16, 0.0);
+  int rc = VO_OK;
+#define PA(expr) do { if (rc == VO_OK) rc = (expr); } while (0)
+  for (int f = 0; f < cfg->n_frames; ++f) {
+    PA(dev_alloc(ctx, &p->d_img[f], px));
+    PA(dev_alloc(ctx, &p->d_depth[f], px));
+  }
+  PA(dev_alloc(ctx, &p->d_T_wc, (size_t)cfg->n_frames * 16));
+  for (int k = 0; k < 2; ++k) {
+    PA(dev_alloc(ctx, &p->d_pyr[k], p->pyr_bytes));
+    PA(dev_alloc(ctx, &p->d_kp[k], (size_t)N * 2));
+  }
+  PA(dev_alloc(ctx, &p->d_scores, px));
+  PA(dev_alloc(ctx, &p->d_prev_f32, (size_t)N * 2));
+  PA(dev_alloc(ctx, &p->d_next_f32, (size_t)N * 2));
+  PA(dev_alloc(ctx, &p->d_err, (size_t)N));
+  PA(dev_alloc(ctx, &p->d_status, (size_t)N));
+  PA(dev_alloc(ctx, &p->d_prev_c, (size_t)N * 2));
+  PA(dev_alloc(ctx, &p->d_next_c, (size_t)N * 2));
+  PA(dev_alloc(ctx, &p->d_land_c, (size_t)N * 3));
+  PA(dev_alloc(ctx, &p->d_tri, (size_t)N * 3));
+  PA(dev_alloc(ctx, &p->d_ntracked, 1));
+  PA(dev_alloc(ctx, &p->d_samples, (size_t)Hyp * 4));
+  PA(dev_alloc(ctx, &p->d_R, (size_t)Hyp * 9));
+  PA(dev_alloc(ctx, &p->d_t, (size_t)Hyp * 3));
+  PA(dev_alloc(ctx, &p->d_C, 24));
+  PA(dev_alloc(ctx, &p->d_valid, (size_t)Hyp));
+  PA(dev_alloc(ctx, &p->d_counts, (size_t)Hyp));
+  PA(dev_alloc(ctx, &p->d_masks, (size_t)Hyp * vo_cdiv(N, 64)));
+  PA(pin_alloc(ctx, &p->h_ntracked, 4));
+  PA(pin_alloc(ctx, &p->h_samples, (size_t)Hyp * 4));
+  PA(pin_alloc(ctx, &p->h_valid, (size_t)Hyp));
+  PA(pin_alloc(ctx, &p->h_counts, (size_t)Hyp));
+  PA(pin_alloc(ctx, &p->h_pose, 12));
+  PA(pin_alloc(ctx, &p->h_C, 24));
+#undef PA
+  if (rc == VO_OK && (hipEventCreateWithFlags(&p->evA, hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evB, hipEventDisableTiming) != hipSuccess))
+    rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
+  if (rc != VO_OK) {
+    vo_pipeline_destroy(p);
+    return rc;
+  }
+  p->rs.outlier_ratio = cfg->ransac_outlier_ratio;
+  p->rs.confidence = cfg->ransac_confidence;
+  p->rs.max_iterations = cfg->ransac_max_iterations;
+  p->rs.s = 4;
+  p->rs.adaptive = 1;
+  const int64_t k0 = vo_ransac_num_iterations(p->rs.confidence, p->rs.outlier_ratio, 4);
+  p->rs.n_iterations = (p->rs.max_iterations >= 0 && p->rs.max_iterations < k0) ? p->rs.max_iterations : k0;
+  memset(&p->rng, 0, sizeof(p->rng));
+  *out = p;
+  return VO_OK;
+}
+
+void vo_pipeline_destroy(vo_pipeline* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  for (auto q : p->d_img) (void)hipFree(q);
+  for (auto q : p->d_depth) (void)hipFree(q);
+  void* dev[] = {p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_prev_f32,
+                 p->d_next_f32, p->d_err, p->d_status, p->d_prev_c, p->d_next_c, p->d_land_c, p->d_tri,
+                 p->d_ntracked, p->d_samples, p->d_R, p->d_t, p->d_C, p->d_valid, p->d_counts, p->d_masks};
+  for (void* q : dev)
+    if (q) (void)hipFree(q);
+  void* pin[] = {p->h_ntracked, p->h_samples, p->h_valid, p->h_counts, p->h_pose, p->h_C};
+  for (void* q : pin)
+    if (q) (void)hipHostFree(q);
+  if (p->evA) (void)hipEventDestroy(p->evA);
+  if (p->evB) (void)hipEventDestroy(p->evB);
+  delete p;
+}
+
+int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img, const float* depth, const double* T_wc) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, idx >= 0 && idx < p->cfg.n_frames && img && depth && T_wc, "pipeline_set_frame: bad arguments");
+  const size_t px = (size_t)p->cfg.H * p->cfg.W;
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_img[idx], img, px, hipMemcpyHostToDevice, ctx->stream));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_depth[idx], depth, px * 4, hipMemcpyHostToDevice, ctx->stream));
+  memcpy(&p->T_wc[(size_t)idx * 16], T_wc, 16 * sizeof(double));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_T_wc + (size_t)idx * 16, T_wc, 128, hipMemcpyHostToDevice, ctx->stream));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return VO_OK;
+}
+
+int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
+  if (!p || !rng) return VO_EINVAL;
+  p->rng = *rng;
+  p->seeded = true;
+  return VO_OK;
+}
+
+static int detect(vo_pipeline* p, int frame, double* d_kp) {
+  const vo_pipeline_config& c = p->cfg;
+  VO_TRY(vo_harris_response_dev(p->ctx, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores));
+  return vo_nms_keypoints_dev(p->ctx, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, d_kp);
+}
+
+int vo_pipeline_prime(vo_pipeline* p, int idx) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, idx >= 0 && idx < p->cfg.n_frames, "pipeline_prime: bad frame index");
+  VO_REQUIRE(ctx, p->seeded, "pipeline_prime: call vo_pipeline_seed first");
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  p->cur = 0;
+  VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[idx], p->cfg.H, p->cfg.W, p->n_levels, p->d_pyr[0]));
+  VO_TRY(detect(p, idx, p->d_kp[0]));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  p->prev_frame = idx;
+  return VO_OK;
+}
+
+int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out) {
+  if (!p || !out) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  const vo_pipeline_config& c = p->cfg;
+  VO_REQUIRE(ctx, next_idx >= 0 && next_idx < c.n_frames, "pipeline_step: bad frame index");
+  VO_REQUIRE(ctx, prev_idx == p->prev_frame, "pipeline_step: prev frame %d is not the frame last processed (%d)",
+             prev_idx, p->prev_frame);
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int N = c.n_keypoints, a = p->cur, b = 1 - p->cur;
+  const double fx = c.K[0], fy = c.K[4], cx = c.K[2], cy = c.K[5];
+  memset(out, 0, sizeof(*out));
+  out->best_index = -1;
+
+  // ---- tracking ----
+  VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
+  hipLaunchKernelGGL(kp_to_f32_kernel, dim3(vo_cdiv(2 * N, 256)), dim3(256), 0, st, p->d_kp[a], N, p->d_prev_f32);
+  VO_TRY(vo_check_launch(ctx, "kp_to_f32_kernel"));
+  VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
+                          p->n_levels, p->d_prev_f32, N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
+                          p->d_next_f32, p->d_status, p->d_err));
+  {
+    int32_t* n_host_dev = nullptr;
+    VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&n_host_dev, p->h_ntracked, 0));
+    vo_prof_scope ps(ctx, VO_K_GATHER);
+    hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, st, p->d_kp[a], p->d_next_f32, p->d_status,
+                       p->d_err, N, (float)c.klt_err_threshold, p->d_depth[prev_idx], c.H, c.W, fx, fy, cx, cy,
+                       p->d_T_wc + (size_t)prev_idx * 16, p->d_prev_c, p->d_next_c, p->d_land_c, p->d_ntracked,
+                       n_host_dev);
+  }
+  VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evA, st));
+
+  // ---- detection on the new frame (feeds the next step); overlaps the host-side sampling ----
+  VO_TRY(detect(p, next_idx, p->d_kp[b]));
+
+  VO_HIP_TRY(ctx, hipEventSynchronize(p->evA));
+  const int n = *p->h_ntracked;
+  out->n_tracked = n;
+  p->last_ntracked = n;
+  p->last_best = -1;
+  p->last_words = vo_cdiv(n > 0 ? n : 1, 64);
+
+  if (n >= 4) {
+    // ---- P3P-RANSAC: bulk hypotheses on the GPU, sequential rule replayed on the host ----
+    vo_pcg64 g = p->rng;                 // speculative copy; the real generator advances by what is consumed
+    int64_t n_done = 0;
+    int32_t best_count = -1, best_idx = -1;
+    int total_consumed = 0, finished = 0, batches = 0, hyp_valid = 0;
+    while (!finished) {
+      VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, p->h_samples));
+      VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_samples, p->h_samples, (size_t)c.hyp * 16, hipMemcpyHostToDevice, st));
+      VO_TRY(vo_p3p_hypotheses_dev(ctx, p->d_land_c, p->d_next_c, n, c.K, p->d_samples, c.hyp, c.p3p_thr_sq, p->d_R,
+                                   p->d_t, p->d_valid, p->d_counts, p->d_masks));
+      VO_HIP_TRY(ctx, hipMemcpyAsync(p->h_valid, p->d_valid, (size_t)c.hyp, hipMemcpyDeviceToHost, st));
+      VO_HIP_TRY(ctx, hipMemcpyAsync(p->h_counts, p->d_counts, (size_t)c.hyp * 4, hipMemcpyDeviceToHost, st));
+      VO_HIP_TRY(ctx, hipEventRecord(p->evB, st));
+      VO_HIP_TRY(ctx, hipEventSynchronize(p->evB));
+      int consumed = 0;
+      const int32_t before = best_idx;
+      VO_TRY(vo_ransac_replay(&p->rs, p->h_valid, p->h_counts, c.hyp, n, &n_done, &best_count, &best_idx,
+                              batches * c.hyp, &consumed, &finished));
+      for (int i = 0; i < c.hyp; ++i) hyp_valid += p->h_valid[i] ? 1 : 0;
+      total_consumed += consumed;
+      if (best_idx != before) {
+        // the winner so far lives in this batch: fetch its pose before the buffers are reused
+        const int local = best_idx - batches * c.hyp;
+        VO_HIP_TRY(ctx, hipMemcpyAsync(p->h_pose, p->d_R + (size_t)local * 9, 72, hipMemcpyDeviceToHost, st));
+        VO_HIP_TRY(ctx, hipMemcpyAsync(p->h_pose + 9, p->d_t + (size_t)local * 3, 24, hipMemcpyDeviceToHost, st));
+        VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+        memcpy(out->R, p->h_pose, 72);
+        memcpy(out->t, p->h_pose + 9, 24);
+        p->last_best = local;
+      } else if (batches > 0) {
+        p->last_best = -1;   // winner's mask row was overwritten by a later batch
+      }
+      ++batches;
+      if (batches > 64) break;   // safety: the reference would still be looping
+    }
+    // advance the real generator by exactly the draws the reference loop consumed
+    {
+      std::vector<int32_t> tmp((size_t)4 * (total_consumed > 0 ? total_consumed : 1));
+      VO_TRY(vo_rng_choice(&p->rng, n, 4, total_consumed, tmp.data()));
+    }
+    out->n_inliers = best_count > 0 ? best_count : 0;
+    out->best_index = best_idx;
+    out->ransac_iterations = n_done;
+    out->draws_consumed = total_consumed;
+    out->hyp_valid = hyp_valid;
+
+    // ---- DLT triangulation of the tracked pairs: C1 = K T_cw(prev) (stream pose), C2 = K [R | t] ----
+    if (best_idx >= 0) {
+      double Tcw[16], Rt[12];
+      rigid_inverse(&p->T_wc[(size_t)prev_idx * 16], Tcw);
+      k_times_rt(c.K, Tcw, p->h_C);
+      for (int r = 0; r < 3; ++r) {
+        Rt[4 * r] = out->R[3 * r];
+        Rt[4 * r + 1] = out->R[3 * r + 1];
+        Rt[4 * r + 2] = out->R[3 * r + 2];
+        Rt[4 * r + 3] = out->t[r];
+      }
+      k_times_rt(c.K, Rt, p->h_C + 12);
+      VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_C, p->h_C, 192, hipMemcpyHostToDevice, st));
+      VO_TRY(vo_triangulate_dlt_dev(ctx, p->d_prev_c, p->d_next_c, n, p->d_C, 0, p->d_C + 12, p->d_tri));
+    }
+  }
+  p->cur = b;
+  p->prev_frame = next_idx;
+  return VO_OK;
+}
+
+int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* next_xy, double* landmarks,
+                      double* triangulated, uint8_t* inliers) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  hipStream_t st = ctx->stream;
+  const int n = p->last_ntracked, N = p->cfg.n_keypoints;
+  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (kp_next) VO_HIP_TRY(ctx, hipMemcpy(kp_next, p->d_kp[p->cur], (size_t)N * 16, hipMemcpyDeviceToHost));
+  if (n > 0) {
+    if (prev_xy) VO_HIP_TRY(ctx, hipMemcpy(prev_xy, p->d_prev_c, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (next_xy) VO_HIP_TRY(ctx, hipMemcpy(next_xy, p->d_next_c, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (landmarks) VO_HIP_TRY(ctx, hipMemcpy(landmarks, p->d_land_c, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (triangulated) VO_HIP_TRY(ctx, hipMemcpy(triangulated, p->d_tri, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (inliers) {
+      VO_REQUIRE(ctx, p->last_best >= 0, "pipeline_fetch: no inlier mask for the last step");
+      std::vector<uint64_t> row(p->last_words);
+      VO_HIP_TRY(ctx, hipMemcpy(row.data(), p->d_masks + (size_t)p->last_best * p->last_words,
+                                (size_t)p->last_words * 8, hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; ++i) inliers[i] = (uint8_t)((row[i >> 6] >> (i & 63)) & 1ull);
+    }
+  }
+  return VO_OK;
+}
+
+}  // extern "C"

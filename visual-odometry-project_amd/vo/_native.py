@@ -29,6 +29,50 @@ class VoError(RuntimeError):
 _lib = None
 _lib_lock = threading.Lock()
 
+
+class Pcg64(C.Structure):
+    """NumPy PCG64 bit-generator state (vo_pcg64)."""
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64), ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64),
+                ("has_uint32", C.c_uint32), ("uinteger", C.c_uint32)]
+
+    @classmethod
+    def from_generator(cls, gen):
+        st = gen.bit_generator.state
+        assert st["bit_generator"] == "PCG64"
+        s, inc = st["state"]["state"], st["state"]["inc"]
+        m = (1 << 64) - 1
+        return cls(s >> 64, s & m, inc >> 64, inc & m, st["has_uint32"], st["uinteger"])
+
+    def to_generator(self, gen):
+        st = gen.bit_generator.state
+        st["state"]["state"] = (self.state_hi << 64) | self.state_lo
+        st["state"]["inc"] = (self.inc_hi << 64) | self.inc_lo
+        st["has_uint32"] = int(self.has_uint32)
+        st["uinteger"] = int(self.uinteger)
+        gen.bit_generator.state = st
+
+
+class RansacState(C.Structure):
+    _fields_ = [("outlier_ratio", C.c_double), ("confidence", C.c_double), ("max_iterations", C.c_int64),
+                ("n_iterations", C.c_int64), ("s", C.c_int32), ("adaptive", C.c_int32)]
+
+
+class PipelineConfig(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("n_frames", C.c_int32),
+                ("n_keypoints", C.c_int32), ("harris_patch", C.c_int32), ("nms_radius", C.c_int32),
+                ("harris_kappa", C.c_double),
+                ("klt_win", C.c_int32), ("klt_max_level", C.c_int32), ("klt_max_iter", C.c_int32), ("hyp", C.c_int32),
+                ("klt_eps", C.c_double), ("klt_min_eig", C.c_double), ("klt_err_threshold", C.c_double),
+                ("p3p_thr_sq", C.c_double), ("ransac_outlier_ratio", C.c_double), ("ransac_confidence", C.c_double),
+                ("ransac_max_iterations", C.c_int64),
+                ("K", C.c_double * 9)]
+
+
+class StepResult(C.Structure):
+    _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("n_tracked", C.c_int32), ("n_inliers", C.c_int32),
+                ("best_index", C.c_int32), ("hyp_valid", C.c_int32), ("ransac_iterations", C.c_int64),
+                ("draws_consumed", C.c_int32), ("pad", C.c_int32)]
+
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 _SIGS = {
     "vo_create": (_i, [_i, _vp, C.POINTER(_vp)]),
@@ -65,6 +109,16 @@ _SIGS = {
     "vo_p3p_hypotheses_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "vo_reproj_inliers": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),
     "vo_reproj_inliers_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
+    "vo_rng_choice": (_i, [_vp, _i, _i, _i, _vp]),
+    "vo_ransac_num_iterations": (C.c_int64, [_d, _d, _i]),
+    "vo_ransac_replay": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "vo_pipeline_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "vo_pipeline_destroy": (None, [_vp]),
+    "vo_pipeline_set_frame": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "vo_pipeline_seed": (_i, [_vp, _vp]),
+    "vo_pipeline_prime": (_i, [_vp, _i]),
+    "vo_pipeline_step": (_i, [_vp, _i, _i, _vp]),
+    "vo_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -322,6 +376,76 @@ class Context:
     def patch_descriptors_dev(self, d_img, H, W, d_kp, N, r, d_desc):
         self._chk(self._lib.vo_patch_descriptors_dev(self._h, C.c_void_p(d_img), H, W, C.c_void_p(d_kp), int(N),
                                                      int(r), C.c_void_p(d_desc)))
+
+
+def rng_choice(pcg, pop, s, count):
+    """`count` draws of Generator.choice(arange(pop), replace=False, size=s); advances `pcg` (host only)."""
+    out = np.empty((count, s), np.int32)
+    rc = load().vo_rng_choice(C.byref(pcg), int(pop), int(s), int(count), _ptr(out))
+    if rc != VO_OK:
+        raise VoError(rc, "vo_rng_choice(pop=%d, s=%d)" % (pop, s))
+    return out
+
+
+def ransac_num_iterations(confidence, outlier_ratio, s):
+    return int(load().vo_ransac_num_iterations(float(confidence), float(outlier_ratio), int(s)))
+
+
+class Pipeline:
+    """Device-resident frame pipeline (vo_pipeline_*)."""
+
+    def __init__(self, ctx, H, W, n_frames, K, n_keypoints=2000, harris_patch=9, harris_kappa=0.09, nms_radius=5,
+                 klt_win=15, klt_max_level=2, klt_max_iter=10, klt_eps=0.03, klt_min_eig=1e-4,
+                 klt_err_threshold=100.0, hyp=1000, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99,
+                 max_iterations=1000, seed=2023):
+        self.ctx = ctx
+        self.cfg = PipelineConfig()
+        c = self.cfg
+        c.H, c.W, c.n_frames = H, W, n_frames
+        c.n_keypoints, c.harris_patch, c.nms_radius, c.harris_kappa = n_keypoints, harris_patch, nms_radius, harris_kappa
+        c.klt_win, c.klt_max_level, c.klt_max_iter, c.hyp = klt_win, klt_max_level, klt_max_iter, hyp
+        c.klt_eps, c.klt_min_eig, c.klt_err_threshold = klt_eps, klt_min_eig, klt_err_threshold
+        c.p3p_thr_sq = p3p_threshold
+        c.ransac_outlier_ratio, c.ransac_confidence = outlier_ratio, confidence
+        c.ransac_max_iterations = -1 if max_iterations is None or max_iterations == np.inf else int(max_iterations)
+        for i, v in enumerate(np.asarray(K, np.float64).reshape(9)):
+            c.K[i] = v
+        h = C.c_void_p()
+        ctx._chk(ctx._lib.vo_pipeline_create(ctx._h, C.byref(c), C.byref(h)))
+        self._h = h
+        pcg = Pcg64.from_generator(np.random.default_rng(seed))
+        ctx._chk(ctx._lib.vo_pipeline_seed(self._h, C.byref(pcg)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.vo_pipeline_destroy(self._h)
+            self._h = None
+
+    def set_frame(self, idx, img, depth, T_world_cam):
+        img = _c(img, np.uint8)
+        depth = _c(depth, np.float32)
+        T = _c(T_world_cam, np.float64).reshape(4, 4)
+        assert img.shape == (self.cfg.H, self.cfg.W) and depth.shape == img.shape
+        self.ctx._chk(self.ctx._lib.vo_pipeline_set_frame(self._h, int(idx), _ptr(img), _ptr(depth), _ptr(T)))
+
+    def prime(self, idx):
+        self.ctx._chk(self.ctx._lib.vo_pipeline_prime(self._h, int(idx)))
+
+    def step(self, prev_idx, next_idx):
+        r = StepResult()
+        self.ctx._chk(self.ctx._lib.vo_pipeline_step(self._h, int(prev_idx), int(next_idx), C.byref(r)))
+        return r
+
+    def fetch(self, n_tracked, want_inliers=True):
+        N = self.cfg.n_keypoints
+        kp = np.empty((N, 2))
+        prev_xy, next_xy = np.empty((n_tracked, 2)), np.empty((n_tracked, 2))
+        land, tri = np.empty((n_tracked, 3)), np.empty((n_tracked, 3))
+        inl = np.empty(n_tracked, np.uint8) if want_inliers else None
+        self.ctx._chk(self.ctx._lib.vo_pipeline_fetch(self._h, _ptr(kp), _ptr(prev_xy), _ptr(next_xy), _ptr(land),
+                                                      _ptr(tri), _ptr(inl)))
+        return dict(kp_next=kp, prev_xy=prev_xy, next_xy=next_xy, landmarks=land, triangulated=tri,
+                    inliers=None if inl is None else inl.astype(bool))
 
 
 _default_ctx = None
