@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark: VO front-end frames/s on the BASELINE.json config-2 workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+One "step" = the whole per-frame front-end on one 1376x1241 frame that is already
+resident in HBM: pyramid -> KLT (3 levels, 15x15) of 2000 keypoints -> Harris
+response + exact NMS (2000 keypoints) on the new frame -> P3P-RANSAC (1000
+hypotheses solved + scored on the GPU, reference-exact sampler and accept rule)
+-> DLT triangulation.  Each rank runs its own synthetic sequence (weak scaling,
+frame streams shard at sequence granularity); with N > 1 every step all-gathers the
+ranks' {pose, landmarks} records over RCCL on a side stream.  Rank 0 prints ONE
+JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "visual-odometry-project_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+H, W, N_KP, HYP, WIN, MAX_LEVEL = 1241, 1376, 2000, 1000, 15, 2
+N_FRAMES = 8
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(kernel_name, n_tracked):
+    """Compulsory HBM traffic per launch (DESIGN.md 'Kernels')."""
+    px = H * W
+    levels = MAX_LEVEL + 1
+    table = {
+        "harris_response": px * 1 + px * 8,                   # image read once, fp64 map written once
+        "nms_candidates": px * 8,                             # fp64 map read once
+        "nms_threshold": 65536 * 4 * 2,
+        "nms_compact": 0,                                     # list traffic is not compulsory
+        "nms_select": N_KP * 16,
+        "pyr_down": None,                                     # per level, filled below
+        "klt_track": N_KP * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + N_KP * (8 + 8 + 1 + 4),
+        "track_gather": N_KP * (8 + 1 + 4 + 16) + n_tracked * (16 + 16 + 24 + 4),
+        "p3p_solve": HYP * (16 + 4 * 40 + 96 + 1),
+        "p3p_score": n_tracked * 40 + HYP * (96 + 1 + 4 + ((n_tracked + 63) // 64) * 8),
+        "dlt_triangulate": n_tracked * (16 + 16 + 24) + 192,
+    }
+    return table.get(kernel_name)
+
+
+def cpu_baseline(stream, frames=3):
+    """The oracle (CPU restatement of the reference path) timed on this host, 1 thread."""
+    from oracle import dlt_np, harris_np, native, ransac_np
+    K = stream.K
+    kp = harris_np.nms_keypoints_fast(harris_np.harris_scores(stream.image(0), 9, 0.09), N_KP, 5)[:, :, 0]
+    rs = ransac_np.Ransac(4, np.arange(4), None, None, 1.0, 0.9, 0.99, 1000, adaptive=True, p3p=True)
+    order = stream.order(frames)
+    t0 = time.perf_counter()
+    for a, b in zip(order[:-1], order[1:]):
+        out, status, err = native.klt_track(stream.image(a), stream.image(b), kp.astype(np.float32), win=WIN,
+                                            max_level=MAX_LEVEL)
+        keep = status.astype(bool) & (err < 100.0)
+        p_c, n_c = kp[keep], out[keep].astype(np.float64)
+        z = stream.depth(a)[p_c[:, 1].astype(int), p_c[:, 0].astype(int)].astype(np.float64)
+        T = stream.T_world_cam(a)
+        xc, yc = (p_c[:, 0] - K[0, 2]) / K[0, 0] * z, (p_c[:, 1] - K[1, 2]) / K[1, 1] * z
+        land = np.stack([T[r, 0] * xc + T[r, 1] * yc + T[r, 2] * z + T[r, 3] for r in range(3)], axis=1)
+        # the reference's own NMS loop: 2*N full-map argmax passes (harris.py:148-152)
+        kp = harris_np.nms_keypoints(harris_np.harris_scores(stream.image(b), 9, 0.09), N_KP, 5)[:, :, 0]
+        rs.model_fn = lambda idx: native.p3p_solve(land[np.asarray(idx).reshape(-1)], n_c[np.asarray(idx).reshape(-1)], K)
+        rs.error_fn = lambda m, pop: native.reproj_errors(land, n_c, K, m[0], m[1])
+        (R, t), inl = rs.find_best_model(np.arange(len(land)))
+        dlt_np.linear_triangulation(p_c, n_c, K @ np.linalg.inv(T)[:3], K @ np.hstack([R, t[:, None]]))
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same 1376x1241 stream through oracle/ (NumPy Harris + the reference's "
+                      "2N-argmax NMS loop, C KLT/P3P, NumPy RANSAC/DLT), single thread" % frames}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node=%d" % args.gpus
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from vo import _native, synthetic
+    comp = torch.cuda.Stream()
+    comm = torch.cuda.Stream()
+    ctx = _native.Context(local, stream=comp.cuda_stream)
+    stream = synthetic.Stream(N_FRAMES, H, W, seed=2023 + rank)
+    pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
+                            hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000)
+    for i in range(N_FRAMES):
+        pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
+
+    cap = N_KP
+    rec_len = 17 + 3 * cap
+    recs = [torch.zeros(rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
+    gathered = [torch.zeros(world * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
+    comm_done = [None, None]
+
+    order = stream.order(args.warmup + args.steps + 64)
+    pipe.prime(order[0])
+    pos = 0
+    stats = {"tracked": [], "inliers": [], "rot_err": [], "trans_err": [], "iters": [], "tri_err": []}
+
+    def run(n, record=False):
+        nonlocal pos
+        for k in range(n):
+            a, b = order[pos], order[pos + 1]
+            pos += 1
+            r = pipe.step(a, b)
+            if world > 1:
+                s = k & 1
+                if comm_done[s] is not None:
+                    comp.wait_event(comm_done[s])           # record buffer free again
+                pipe.export_state_dev(r, cap, recs[s].data_ptr())
+                ev = torch.cuda.Event()
+                ev.record(comp)
+                comm.wait_event(ev)
+                with torch.cuda.stream(comm):
+                    dist.all_gather_into_tensor(gathered[s], recs[s])
+                    comm_done[s] = torch.cuda.Event()
+                    comm_done[s].record(comm)
+            if record:
+                Tcw = np.linalg.inv(stream.T_world_cam(b))
+                R, t = np.array(r.R).reshape(3, 3), np.array(r.t)
+                stats["tracked"].append(r.n_tracked)
+                stats["inliers"].append(r.n_inliers)
+                stats["iters"].append(r.ransac_iterations)
+                stats["rot_err"].append(float(np.linalg.norm(R - Tcw[:3, :3])))
+                stats["trans_err"].append(float(np.linalg.norm(t - Tcw[:3, 3])))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    # untimed: warmup, and one all-kernel event profile to find the dominant kernel
+    run(args.warmup)
+    ctx.prof_enable(-1)
+    ctx.prof_reset()
+    run(8)
+    per_kernel = {}
+    for kid in range(_native.K_COUNT):
+        ms, n = ctx.prof_read(kid)
+        if n:
+            per_kernel[ctx.kernel_name(kid)] = (ms, n)
+    ctx.prof_disable()
+    dom_name = max(per_kernel, key=lambda k: per_kernel[k][0])
+    dom_id = [k for k in range(_native.K_COUNT) if ctx.kernel_name(k) == dom_name][0]
+
+    # timed region: exactly K steps, events only around the dominant kernel
+    ctx.prof_reset()
+    ctx.prof_enable(dom_id)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, record=False)
+    fence()
+    dt = time.perf_counter() - t0
+    dom_ms, dom_n = ctx.prof_read(dom_id)
+    ctx.prof_disable()
+
+    # untimed: accuracy against the analytic ground truth of the stream
+    run(16, record=True)
+    fence()
+    last = pipe.step(order[pos], order[pos + 1])
+    ntr = last.n_tracked
+
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt_max = float(dt_t.item())
+
+    if rank == 0:
+        avg_us = dom_ms / max(dom_n, 1) * 1e3
+        ab = algorithmic_bytes(dom_name, ntr)
+        roof = {"bound": "hbm", "kernel": dom_name, "avg_launch_us": round(avg_us, 3), "launches": dom_n,
+                "algorithmic_bytes_per_launch": ab, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        if ab:
+            ach = ab / (avg_us * 1e-6) / 1e9
+            roof["achieved"] = round(ach, 2)
+            roof["frac"] = round(ach / HBM_PEAK_GBS, 5)
+        else:
+            roof["achieved"] = None
+            roof["frac"] = None
+        out = {
+            "metric": "VO frames/sec at 1376x1241, 2k keypoints; pose err vs reference",
+            "value": round(world * args.steps / dt_max, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "cfg-2: 1376x1241 KITTI-shaped synthetic stream, Harris+NMS 2000 kp -> KLT 3-level "
+                                   "15x15 -> P3P-RANSAC 1000 hyps -> DLT; one independent sequence per GPU",
+                       "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP,
+                       "parallelism": "sequence-sharded x%d%s" % (world, ", RCCL all-gather of {pose, landmarks} per frame" if world > 1 else "")},
+            "roofline": roof,
+            "per_kernel_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(per_kernel.items())},
+            "pose_err": {"rot_fro_median": float(np.median(stats["rot_err"])), "trans_m_median": float(np.median(stats["trans_err"])),
+                         "tracked_median": float(np.median(stats["tracked"])), "inliers_median": float(np.median(stats["inliers"])),
+                         "ransac_iters_median": float(np.median(stats["iters"])),
+                         "note": "vs analytic ground truth of the synthetic stream; best RANSAC hypothesis, no refinement"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(stream)
+        print(json.dumps(out), flush=True)
+    pipe.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,8 @@ enum {
   VO_K_REPROJ = 11,
   VO_K_MATCH = 12,
   VO_K_GATHER = 13,
+  VO_K_NMS_ROUND = 14,
+  VO_K_NMS_COLLECT = 15,
   VO_K_COUNT = 32
 };
 int vo_prof_enable(vo_ctx* ctx, int kernel_id);
@@ -238,6 +240,11 @@ int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img, const flo
 int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng);
 int vo_pipeline_prime(vo_pipeline* p, int idx);
 int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out);
+/* Writes this rank's shared-map record for the last step into DEVICE memory (async):
+ * [T_cw 4x4 row-major (16) | n (1) | n triangulated landmarks x 3, n <= cap], all f64,
+ * 17 + 3*cap doubles.  The caller all-gathers the records over RCCL (bench.py).     */
+int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int cap,
+                                 double* d_record);
 /* copies of the last step's device arrays: keypoints of `next` (n_keypoints*2 f64),
  * tracked pairs (n_tracked: prev xy f64, next xy f64, landmark xyz f64), triangulated
  * points (n_tracked*3 f64), inlier mask (n_tracked bytes).  Any pointer may be NULL. */

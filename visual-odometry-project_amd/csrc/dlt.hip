@@ -25,7 +25,7 @@ __device__ __forceinline__ bool rotate_pair(double (&A)[6][4], double (&V)[4][4]
     beta += A[r][Q] * A[r][Q];
     gamma += A[r][P] * A[r][Q];
   }
-  if (gamma == 0.0 || fabs(gamma) <= 1e-16 * sqrt(alpha * beta)) return false;
+  if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) return false;
   const double zeta = (beta - alpha) / (2.0 * gamma);
   const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
   const double c = 1.0 / sqrt(1.0 + tt * tt);

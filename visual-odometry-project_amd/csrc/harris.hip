@@ -19,9 +19,15 @@
 //   T            = a score bound with at least N L1 pixels at or above it
 //                  (65536-bin histogram of the IEEE bit pattern).  Pixels below T
 //                  cannot be among the first N picks.
-//   select       = candidates {L1, A1 : score >= T} sorted by priority, walked by
-//                  one workgroup: L1 entries pass, A1 entries run the greedy test
-//                  against previously selected A1 entries only.
+//   rounds       = the A1 pixels at or above T are resolved by a few launches of the
+//                  greedy rule itself, in parallel: a live pixel that sees no live
+//                  higher-priority pixel in its window is selected and kills its
+//                  window; one that sees a selected pixel dies.  State changes are
+//                  monotone (live -> selected | dead), so a stale read only delays a
+//                  decision to the next launch.  ~3.5x fewer live pixels per round.
+//   select       = {L1 >= T} + round-selected + the few pixels still live, sorted by
+//                  priority and walked by one workgroup: decided entries pass, live
+//                  entries run the greedy test against selected live entries only.
 // The first N selected, in priority order, are the reference's keypoints; the
 // reference's slicing corner cases are applied when writing out.
 #include "vo_internal.h"
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
 struct nms_ctl {
   unsigned n_l1, n_a1, n_c, overflow;
   unsigned long long t_bits;
-  unsigned n_sel, pad;
+  unsigned n_sel, n_cand;
 };
 
 constexpr int HIST_SHIFT = 47;           // 65536 bins over non-negative doubles
@@ -254,43 +260,56 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
 // NMS stage 2: score bound with >= N L1 entries above it; clears the histogram
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void nms_threshold_kernel(unsigned* __restrict__ hist, nms_ctl* ctl, int N) {
-  __shared__ unsigned s_part[1024];
-  __shared__ unsigned s_suffix[1025];
-  const int tid = threadIdx.x;
-  constexpr int PER = HIST_BINS / 1024;
-  unsigned local[PER];
-  unsigned sum = 0;
+  // wave w owns bins [4096 w, 4096 w + 4096); lane l holds bins 4096 w + 64 j + l, j = 0..63 (coalesced rows)
+  __shared__ unsigned s_wave[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  unsigned v[64];
+  unsigned part = 0;
+  unsigned* base = hist + wv * 4096 + lane;
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    local[k] = hist[tid * PER + k];
-    hist[tid * PER + k] = 0;
-    sum += local[k];
+  for (int j = 0; j < 64; ++j) {
+    v[j] = base[64 * j];
+    base[64 * j] = 0;
+    part += v[j];
   }
-  s_part[tid] = sum;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if (lane == 0) s_wave[wv] = part;
   __syncthreads();
-  if (tid == 0) {
-    unsigned acc = 0;
-    s_suffix[1024] = 0;
-    for (int t = 1023; t >= 0; --t) {
-      acc += s_part[t];
-      s_suffix[t] = acc;
-    }
+  unsigned above = 0, total = 0;
+  for (int w = 15; w >= 0; --w) {
+    if (w > wv) above += s_wave[w];
+    total += s_wave[w];
   }
-  __syncthreads();
-  unsigned above = s_suffix[tid + 1], incl = s_suffix[tid];
-  if (tid == 0 && incl < (unsigned)N) ctl->t_bits = 1ull;   // fewer than N strict maxima: keep everything
-  if (above < (unsigned)N && incl >= (unsigned)N) {
+  if (tid == 0 && total < (unsigned)N) ctl->t_bits = 1ull;   // fewer than N strict maxima: keep everything
+  if (total >= (unsigned)N && above < (unsigned)N && above + s_wave[wv] >= (unsigned)N) {
+    // the crossing lies in this wave's 4096 bins: walk its rows from the top
     unsigned acc = above;
-    int bin = tid * PER;
-    for (int k = PER - 1; k >= 0; --k) {
-      acc += local[k];
-      if (acc >= (unsigned)N) {
-        bin = tid * PER + k;
-        break;
+    int bin = -1;
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+      unsigned row = v[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) row += __shfl_xor(row, off);
+      if (bin < 0 && acc + row >= (unsigned)N) {
+        // inside row j: suffix over lanes (higher lane = higher bin)
+        unsigned suf = v[j];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          unsigned o = __shfl_down(suf, off);
+          if (lane + off < 64) suf += o;
+        }
+        // suf = sum of v[j] over lanes >= lane; crossing lane = highest lane with acc + suf >= N
+        unsigned long long m = __ballot(acc + suf >= (unsigned)N);
+        int hl = 63 - __builtin_clzll(m);
+        bin = wv * 4096 + 64 * j + hl;
       }
+      if (bin < 0) acc += row;
     }
-    unsigned long long t = (unsigned long long)bin << HIST_SHIFT;
-    ctl->t_bits = t ? t : 1ull;
+    if (lane == 0) {
+      unsigned long long t = (unsigned long long)bin << HIST_SHIFT;
+      ctl->t_bits = t ? t : 1ull;
+    }
   }
 }
 
@@ -302,24 +321,115 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
                                                          const unsigned long long* __restrict__ keys_a1,
                                                          const unsigned* __restrict__ idx_a1,
                                                          unsigned long long* __restrict__ keys_c,
-                                                         unsigned* __restrict__ idx_c, nms_ctl* ctl,
-                                                         unsigned cap_c) {
+                                                         unsigned* __restrict__ idx_c, unsigned* __restrict__ cand,
+                                                         uint8_t* __restrict__ alive, nms_ctl* ctl, unsigned cap_c,
+                                                         unsigned cap_cand) {
+  // L1 entries at or above the bound are selected outright; A1 entries become live candidates
   const unsigned n_l1 = ctl->n_l1, n_a1 = ctl->n_a1;
   const unsigned long long t = ctl->t_bits;
   const unsigned total = n_l1 + n_a1;
   for (unsigned i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
-    bool a = i >= n_l1;
-    unsigned j = a ? i - n_l1 : i;
-    unsigned long long key = a ? keys_a1[j] : keys_l1[j];
+    const bool a = i >= n_l1;
+    const unsigned j = a ? i - n_l1 : i;
+    const unsigned long long key = a ? keys_a1[j] : keys_l1[j];
     if (key < t) continue;
-    unsigned idx = a ? idx_a1[j] : idx_l1[j];
-    unsigned pos = atomicAdd(&ctl->n_c, 1u);
-    if (pos >= cap_c) {
-      ctl->overflow = 1;
+    const unsigned idx = a ? idx_a1[j] : idx_l1[j];
+    if (a) {
+      const unsigned pos = atomicAdd(&ctl->n_cand, 1u);
+      if (pos >= cap_cand) {
+        ctl->overflow = 1;
+        continue;
+      }
+      cand[pos] = idx;
+      alive[idx] = 1;
+    } else {
+      const unsigned pos = atomicAdd(&ctl->n_c, 1u);
+      if (pos >= cap_c) {
+        ctl->overflow = 1;
+        continue;
+      }
+      keys_c[pos] = key;
+      idx_c[pos] = idx << 1;
+    }
+  }
+}
+
+// One parallel round of the greedy rule on the live candidates (alive: 0 dead / not a
+// candidate, 1 live, 2 selected).  Safe under stale reads: see the file header.
+__global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict__ sc, uint8_t* alive,
+                                                       const unsigned* __restrict__ cand,
+                                                       unsigned long long* __restrict__ keys_c,
+                                                       unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c,
+                                                       unsigned cap_cand, int H, int W, int r) {
+  const unsigned n = min(ctl->n_cand, cap_cand);
+  for (unsigned i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    const unsigned idx = cand[i];
+    if (alive[idx] != 1) continue;
+    const int py = (int)(idx / (unsigned)W), px = (int)(idx - (unsigned)py * (unsigned)W);
+    const double s = sc[idx];
+    const int ya = max(py - r, 0), yb = min(py + r, H - 1);
+    const int xa = max(px - r, 0), xb = min(px + r, W - 1);
+    bool dead = false, blocked = false;
+    for (int y = ya; y <= yb && !dead; ++y) {
+      const uint8_t* arow = alive + (size_t)y * W;
+      const double* srow = sc + (size_t)y * W;
+      for (int x = xa; x <= xb; ++x) {
+        const uint8_t av = arow[x];
+        if (av == 0 || (y == py && x == px)) continue;
+        if (av == 2) {
+          dead = true;
+          break;
+        }
+        if (!blocked) {
+          const double q = srow[x];
+          const bool before = (y < py) || (y == py && x < px);
+          if (before ? (q >= s) : (q > s)) blocked = true;
+        }
+      }
+    }
+    if (dead) {
+      alive[idx] = 0;
       continue;
     }
-    keys_c[pos] = key;
-    idx_c[pos] = (idx << 1) | (a ? 1u : 0u);
+    if (blocked) continue;
+    alive[idx] = 2;
+    const unsigned pos = atomicAdd(&ctl->n_c, 1u);
+    if (pos < cap_c) {
+      keys_c[pos] = (unsigned long long)__double_as_longlong(s);
+      idx_c[pos] = idx << 1;
+    } else {
+      ctl->overflow = 1;
+    }
+    for (int y = ya; y <= yb; ++y) {
+      uint8_t* arow = alive + (size_t)y * W;
+      for (int x = xa; x <= xb; ++x)
+        if (arow[x] == 1) arow[x] = 0;
+    }
+  }
+}
+
+// After the rounds: candidates still live join the list as undecided entries (bit 0 set);
+// every candidate's mark is cleared so the map is all-zero for the next call.
+__global__ __launch_bounds__(NT) void nms_collect_kernel(const double* __restrict__ sc, uint8_t* alive,
+                                                         const unsigned* __restrict__ cand,
+                                                         unsigned long long* __restrict__ keys_c,
+                                                         unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c,
+                                                         unsigned cap_cand) {
+  const unsigned n = min(ctl->n_cand, cap_cand);
+  for (unsigned i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+    const unsigned idx = cand[i];
+    const uint8_t a = alive[idx];
+    if (a == 0) continue;
+    alive[idx] = 0;
+    if (a == 1) {
+      const unsigned pos = atomicAdd(&ctl->n_c, 1u);
+      if (pos < cap_c) {
+        keys_c[pos] = (unsigned long long)__double_as_longlong(sc[idx]);
+        idx_c[pos] = (idx << 1) | 1u;
+      } else {
+        ctl->overflow = 1;
+      }
+    }
   }
 }
 
@@ -329,6 +439,7 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
 constexpr int SEL_T = 1024;       // threads
 constexpr int CHUNK = 8192;       // entries sorted in LDS at a time
 constexpr int MAX_N = 16384;      // keypoints
+constexpr int NMS_ROUNDS = 6;     // parallel greedy rounds before the single-workgroup walk
 
 __device__ __forceinline__ bool prio_before(unsigned long long ka, unsigned ia, unsigned long long kb,
                                             unsigned ib) {
@@ -643,6 +754,12 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   VO_TRY(vo_ensure(ctx, ctx->nms_keys_c, (size_t)cap_c * 8));
   VO_TRY(vo_ensure(ctx, ctx->nms_idx_c, (size_t)cap_c * 4));
   VO_TRY(vo_ensure(ctx, ctx->nms_sel, (size_t)MAX_N * 4));
+  VO_TRY(vo_ensure(ctx, ctx->nms_cand, (size_t)cap * 4));
+  if (ctx->nms_alive.cap < (size_t)cap || ctx->nms_alive_dirty) {
+    VO_TRY(vo_ensure(ctx, ctx->nms_alive, (size_t)cap));
+    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_alive.p, 0, ctx->nms_alive.cap, ctx->stream));
+    ctx->nms_alive_dirty = false;
+  }
   if (!ctx->nms_hist.p) {
     VO_TRY(vo_ensure(ctx, ctx->nms_hist, (size_t)HIST_BINS * 4));
     VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_hist.p, 0, (size_t)HIST_BINS * 4, ctx->stream));
@@ -652,6 +769,10 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   VO_HIP_TRY(ctx, hipMemsetAsync(ctl, 0, sizeof(nms_ctl), ctx->stream));
 
   dim3 grid(vo_cdiv(W, TX), vo_cdiv(H, TY));
+  unsigned long long* keys_c = (unsigned long long*)ctx->nms_keys_c.p;
+  unsigned* idx_c = (unsigned*)ctx->nms_idx_c.p;
+  unsigned* cand = (unsigned*)ctx->nms_cand.p;
+  uint8_t* alive = (uint8_t*)ctx->nms_alive.p;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_CANDIDATES);
     hipLaunchKernelGGL(nms_candidates_kernel, grid, dim3(NT), candidates_lds_bytes(r), ctx->stream, d_scores,
@@ -666,18 +787,31 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
                        ctl, N);
   }
   VO_TRY(vo_check_launch(ctx, "nms_threshold_kernel"));
+  ctx->nms_alive_dirty = true;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_COMPACT);
     hipLaunchKernelGGL(nms_compact_kernel, dim3(512), dim3(NT), 0, ctx->stream,
                        (const unsigned long long*)ctx->nms_keys_l1.p, (const unsigned*)ctx->nms_idx_l1.p,
-                       (const unsigned long long*)ctx->nms_keys_a1.p, (const unsigned*)ctx->nms_idx_a1.p,
-                       (unsigned long long*)ctx->nms_keys_c.p, (unsigned*)ctx->nms_idx_c.p, ctl, cap_c);
+                       (const unsigned long long*)ctx->nms_keys_a1.p, (const unsigned*)ctx->nms_idx_a1.p, keys_c,
+                       idx_c, cand, alive, ctl, cap_c, cap);
   }
   VO_TRY(vo_check_launch(ctx, "nms_compact_kernel"));
+  for (int round = 0; round < NMS_ROUNDS; ++round) {
+    vo_prof_scope ps(ctx, VO_K_NMS_ROUND);
+    hipLaunchKernelGGL(nms_round_kernel, dim3(512), dim3(NT), 0, ctx->stream, d_scores, alive, cand, keys_c, idx_c,
+                       ctl, cap_c, cap, H, W, r);
+  }
+  VO_TRY(vo_check_launch(ctx, "nms_round_kernel"));
+  {
+    vo_prof_scope ps(ctx, VO_K_NMS_COLLECT);
+    hipLaunchKernelGGL(nms_collect_kernel, dim3(512), dim3(NT), 0, ctx->stream, d_scores, alive, cand, keys_c, idx_c,
+                       ctl, cap_c, cap);
+  }
+  VO_TRY(vo_check_launch(ctx, "nms_collect_kernel"));
+  ctx->nms_alive_dirty = false;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_SELECT);
-    hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_T), 0, ctx->stream,
-                       (unsigned long long*)ctx->nms_keys_c.p, (unsigned*)ctx->nms_idx_c.p, ctl, cap_c, W, N, r,
+    hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_T), 0, ctx->stream, keys_c, idx_c, ctl, cap_c, W, N, r,
                        (unsigned*)ctx->nms_sel.p, d_kp_xy);
   }
   return vo_check_launch(ctx, "nms_select_kernel");

@@ -115,6 +115,19 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
   }
 }
 
+struct pose17 {
+  double v[17];
+};
+
+// record = [T_cw 4x4 row-major | n | landmarks cap x 3]: what one rank contributes to the shared map
+__global__ __launch_bounds__(256) void export_state_kernel(pose17 head, const double* __restrict__ tri, int n, int cap,
+                                                           double* __restrict__ rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 17) rec[i] = head.v[i];
+  const int m = min(n, cap) * 3;
+  if (i < m) rec[17 + i] = tri[i];
+}
+
 template <typename T>
 int dev_alloc(vo_ctx* ctx, T** p, size_t count) {
   hipError_t e = hipMalloc((void**)p, count * sizeof(T) ? count * sizeof(T) : 256);
@@ -392,6 +405,25 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   p->cur = b;
   p->prev_frame = next_idx;
   return VO_OK;
+}
+
+int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record) {
+  if (!p || !r || !d_record) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, cap >= 0, "pipeline_export_state: bad capacity");
+  pose17 h;
+  for (int row = 0; row < 3; ++row) {
+    for (int c = 0; c < 3; ++c) h.v[4 * row + c] = r->R[3 * row + c];
+    h.v[4 * row + 3] = r->t[row];
+  }
+  h.v[12] = h.v[13] = h.v[14] = 0.0;
+  h.v[15] = 1.0;
+  const int n = r->best_index >= 0 ? (r->n_tracked < cap ? r->n_tracked : cap) : 0;
+  h.v[16] = (double)n;
+  const int threads = n * 3 > 17 ? n * 3 : 17;
+  hipLaunchKernelGGL(export_state_kernel, dim3(vo_cdiv(threads, 256)), dim3(256), 0, ctx->stream, h, p->d_tri, n, cap,
+                     d_record);
+  return vo_check_launch(ctx, "export_state_kernel");
 }
 
 int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* next_xy, double* landmarks,

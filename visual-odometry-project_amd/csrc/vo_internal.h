@@ -39,7 +39,8 @@ struct vo_ctx {
   vo_buf img, img2, scores, kp, desc;
   vo_buf nms_keys_l1, nms_idx_l1, nms_keys_a1, nms_idx_a1;   // candidate lists
   vo_buf nms_keys_c, nms_idx_c;                              // compacted candidates
-  vo_buf nms_hist, nms_ctl, nms_sel;
+  vo_buf nms_hist, nms_ctl, nms_sel, nms_cand, nms_alive;
+  bool nms_alive_dirty = false;
   vo_buf scratch[16];
   // pinned host staging
   void* h_pin = nullptr;

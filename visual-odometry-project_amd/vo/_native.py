@@ -119,6 +119,7 @@ _SIGS = {
     "vo_pipeline_prime": (_i, [_vp, _i]),
     "vo_pipeline_step": (_i, [_vp, _i, _i, _vp]),
     "vo_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vo_pipeline_export_state_dev": (_i, [_vp, _vp, _i, _vp]),
 }
 
 
@@ -435,6 +436,9 @@ class Pipeline:
         r = StepResult()
         self.ctx._chk(self.ctx._lib.vo_pipeline_step(self._h, int(prev_idx), int(next_idx), C.byref(r)))
         return r
+
+    def export_state_dev(self, result, cap, d_record):
+        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_dev(self._h, C.byref(result), int(cap), C.c_void_p(d_record)))
 
     def fetch(self, n_tracked, want_inliers=True):
         N = self.cfg.n_keypoints
