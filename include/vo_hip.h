@@ -80,6 +80,8 @@ enum {
   VO_K_GATHER = 13,
   VO_K_NMS_ROUND = 14,
   VO_K_NMS_COLLECT = 15,
+  VO_K_NMS_RANK = 16,
+  VO_K_NMS_EMIT = 17,
   VO_K_COUNT = 32
 };
 int vo_prof_enable(vo_ctx* ctx, int kernel_id);

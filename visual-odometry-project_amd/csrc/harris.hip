@@ -131,137 +131,193 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
 }
 
 // ---------------------------------------------------------------------------------
-// NMS stage 1: L1 / A1 candidate lists + histogram of L1 scores
+// NMS stage 1: per-tile L1 / A1 lists + histogram of L1 scores
 // ---------------------------------------------------------------------------------
 struct nms_ctl {
-  unsigned n_l1, n_a1, n_c, overflow;
+  unsigned n_c, n_rem, overflow, n_sel;
   unsigned long long t_bits;
-  unsigned n_sel, n_cand;
+  unsigned pad[2];
 };
 
 constexpr int HIST_SHIFT = 47;           // 65536 bins over non-negative doubles
 constexpr int HIST_BINS = 1 << 16;
+constexpr int CX = 64, CY = 32;          // candidate tile
+constexpr int SEG = CX * CY;             // capacity of one tile's list segment
+constexpr int RANK_MAX = 32768;          // entries the rank kernel orders (above: sort path)
 
-__global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __restrict__ sc, int H, int W, int r,
-                                                            unsigned long long* __restrict__ keys_l1,
-                                                            unsigned* __restrict__ idx_l1,
-                                                            unsigned long long* __restrict__ keys_a1,
-                                                            unsigned* __restrict__ idx_a1,
-                                                            unsigned* __restrict__ hist, nms_ctl* ctl,
-                                                            unsigned cap) {
+// State word of a pixel in the candidate map: 0 = dead / not a candidate, 1 = selected,
+// >= 3 = live, holding the top 32 bits of its score (a monotone 32-bit view of the
+// priority: a larger word means a larger score, equal words need the full compare).
+__device__ __forceinline__ unsigned live_code(unsigned long long key) {
+  const unsigned hi = (unsigned)(key >> 32);
+  return hi < 3u ? 3u : hi;
+}
+
+// compacting append inside a workgroup: one LDS atomic per wave
+__device__ __forceinline__ unsigned wave_slot(bool take, unsigned* counter) {
+  const unsigned long long m = __ballot(take);
+  if (m == 0ull) return 0u;
+  const int lane = threadIdx.x & 63;
+  const int leader = __builtin_ctzll(m);
+  unsigned base = 0;
+  if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+  base = __shfl(base, leader);
+  return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// R_T > 0: radius known at compile time (window loops unroll); R_T == 0: runtime radius.
+template <int R_T>
+__global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __restrict__ sc, int H, int W, int r_arg,
+                                                            unsigned long long* __restrict__ seg_keys_l1,
+                                                            unsigned* __restrict__ seg_idx_l1,
+                                                            unsigned long long* __restrict__ seg_keys_a1,
+                                                            unsigned* __restrict__ seg_idx_a1,
+                                                            uint4* __restrict__ seg_cnt,
+                                                            unsigned* __restrict__ hist, int dbg, unsigned long long* stamps) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int RW = TX + 4 * r, RH = TY + 4 * r;   // score region (2r halo)
-  const int LW = TX + 2 * r, LH = TY + 2 * r;   // region where L1 flags are needed
+  const int r = R_T > 0 ? R_T : r_arg;
+  const int RW = CX + 4 * r, RH = CY + 4 * r;   // score region (2r halo)
+  const int LW = CX + 2 * r, LH = CY + 2 * r;   // region where L1 flags are needed
+  const int WN = 2 * r + 1;
   double* s_sc = reinterpret_cast<double*>(smem);
-  uint8_t* s_l1 = smem + (size_t)RW * RH * sizeof(double);
-  uint8_t* s_cov = s_l1 + ((LW * LH + 15) & ~15);
-  __shared__ unsigned s_cnt[2], s_base[2];
+  double* s_rm = s_sc + RW * RH;                // row maxima, RH x LW
+  unsigned* s_mask = reinterpret_cast<unsigned*>(s_rm + RH * LW);   // LH rows x 4 words (LW <= 128 bits)
+  unsigned* s_comb = s_mask + LH * 4;                               // CY rows x 4 words
+  __shared__ unsigned s_cnt[2];
 
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int x0 = blockIdx.x * CX, y0 = blockIdx.y * CY;
+  const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
   if (tid < 2) s_cnt[tid] = 0;
+#define STAMP(k) do { if (stamps && tid == 0) stamps[(size_t)blk * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  STAMP(0);
 
   for (int i = tid; i < RW * RH; i += NT) {
-    int ly = i / RW, lx = i - ly * RW;
-    int gy = y0 - 2 * r + ly, gx = x0 - 2 * r + lx;
+    const int ly = i / RW, lx = i - ly * RW;
+    const int gy = y0 - 2 * r + ly, gx = x0 - 2 * r + lx;
     double v = 0.0;
     if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = sc[(size_t)gy * W + gx];
     s_sc[i] = v;
   }
-  for (int i = tid; i < TX * TY; i += NT) s_cov[i] = 0;
+  for (int i = tid; i < LH * 4; i += NT) s_mask[i] = 0;
   __syncthreads();
+  STAMP(1);
 
-  // L1 flags on the tile + r halo
+  // separable window maximum: rows, then columns (no data-dependent branches)
+  if (!(dbg & 1))
+  for (int i = tid; i < RH * LW; i += NT) {
+    const int ly = i / LW, lx = i - ly * LW;
+    const double* row = s_sc + ly * RW + lx;
+    double m = row[0];
+#pragma unroll
+    for (int d = 1; d < (R_T > 0 ? 2 * R_T + 1 : 1); ++d) m = fmax(m, row[d]);
+    if (R_T == 0)
+      for (int d = 1; d < WN; ++d) m = fmax(m, row[d]);
+    s_rm[i] = m;
+  }
+  __syncthreads();
+  STAMP(2);
+  if (!(dbg & 2))
   for (int i = tid; i < LW * LH; i += NT) {
-    int ly = i / LW, lx = i - ly * LW;
+    const int ly = i / LW, lx = i - ly * LW;
+    const double* col = s_rm + ly * LW + lx;
+    double m = col[0];
+#pragma unroll
+    for (int d = 1; d < (R_T > 0 ? 2 * R_T + 1 : 1); ++d) m = fmax(m, col[d * LW]);
+    if (R_T == 0)
+      for (int d = 1; d < WN; ++d) m = fmax(m, col[d * LW]);
     const double* c = s_sc + (ly + r) * RW + (lx + r);
-    double s = *c;
-    bool is = s > 0.0;
-    if (is && r > 0) {
-      // cheap 3x3 pre-test, then the full window
-      is = !(c[-RW - 1] >= s || c[-RW] >= s || c[-RW + 1] >= s || c[-1] >= s || c[1] > s ||
-             c[RW - 1] > s || c[RW] > s || c[RW + 1] > s);
-      for (int dy = -r; is && dy <= r; ++dy) {
-        const double* row = c + dy * RW;
-        for (int dx = -r; dx <= r; ++dx) {
-          double q = row[dx];
-          bool before = (dy < 0) || (dy == 0 && dx < 0);   // q precedes p in flat order
-          if (before ? (q >= s) : (q > s && !(dy == 0 && dx == 0))) {
-            is = false;
-            break;
-          }
+    const double sv = *c;
+    bool is = sv > 0.0 && sv == m;
+    if (is) {
+      // window maximum by value: it loses only to an equal score earlier in flat order.
+      // All window loads are issued before any is tested (no dependent-load chain).
+      if (R_T > 0) {
+        bool tie = false;
+#pragma unroll
+        for (int dy = -R_T; dy <= 0; ++dy) {
+#pragma unroll
+          for (int dx = -R_T; dx <= R_T; ++dx)
+            if (dy < 0 || dx < 0) tie |= (c[dy * RW + dx] == sv);
+        }
+        is = !tie;
+      } else {
+        for (int dy = -r; dy <= 0 && is; ++dy) {
+          const double* rowp = c + dy * RW;
+          const int dx_end = dy < 0 ? r : -1;
+          for (int dx = -r; dx <= dx_end; ++dx)
+            if (rowp[dx] == sv) {
+              is = false;
+              break;
+            }
         }
       }
     }
-    s_l1[i] = is ? 1 : 0;
+    if (is) atomicOr(&s_mask[ly * 4 + (lx >> 5)], 1u << (lx & 31));
   }
   __syncthreads();
+  STAMP(3);
 
-  // every L1 pixel covers its window
-  for (int i = tid; i < LW * LH; i += NT) {
-    if (!s_l1[i]) continue;
-    int ly = i / LW - r, lx = i % LW - r;   // tile coords of the L1 pixel
-    int ya = max(ly - r, 0), yb = min(ly + r, TY - 1);
-    int xa = max(lx - r, 0), xb = min(lx + r, TX - 1);
-    for (int y = ya; y <= yb; ++y)
-      for (int x = xa; x <= xb; ++x) s_cov[y * TX + x] = 1;
+  // L1 flags are bit rows (4 words per L row); a tile row's cover mask is the OR of 2r+1 of them
+  for (int i = tid; i < CY * 4; i += NT) {
+    const int ly = i >> 2, w = i & 3;
+    unsigned m = 0;
+    for (int d = 0; d < WN; ++d) m |= s_mask[(ly + d) * 4 + w];
+    s_comb[i] = m;
   }
   __syncthreads();
+  STAMP(4);
 
-  // classify the tile's own pixels
-  constexpr int PER = TX * TY / NT;
-  int kind[PER];
-  unsigned slot[PER];
-  const int lx = tid & (TX - 1);
+  // classify the tile's own pixels and append them to the tile's segments
+  const int lx = tid & (CX - 1);
+  const size_t seg0 = (size_t)blk * SEG;
+  if (!(dbg & 8))
 #pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    int ly = tid / TX + k * (NT / TX);
-    int gy = y0 + ly, gx = x0 + lx;
-    kind[k] = -1;
+  for (int k = 0; k < SEG / NT; ++k) {
+    const int ly = tid / CX + k * (NT / CX);
+    const int gy = y0 + ly, gx = x0 + lx;
+    int kind = -1;
+    double sv = 0.0;
     if (gy < H && gx < W) {
-      double s = s_sc[(ly + 2 * r) * RW + (lx + 2 * r)];
-      if (s > 0.0) {
-        if (s_l1[(ly + r) * LW + (lx + r)]) kind[k] = 0;
-        else if (!s_cov[ly * TX + lx]) kind[k] = 1;
+      sv = s_sc[(ly + 2 * r) * RW + (lx + 2 * r)];
+      if (sv > 0.0) {
+        const int bx = lx + r;                                   // own bit in the L row
+        const bool own = (s_mask[(ly + r) * 4 + (bx >> 5)] >> (bx & 31)) & 1u;
+        // any L1 bit in columns lx .. lx + 2r of the combined row?
+        const unsigned* cw = s_comb + ly * 4;
+        const unsigned long long lo = cw[0] | ((unsigned long long)cw[1] << 32);
+        const unsigned long long hi = cw[2] | ((unsigned long long)cw[3] << 32);
+        const unsigned long long win = lx == 0 ? lo : ((lo >> lx) | (hi << (64 - lx)));
+        const bool covered = (win & ((1ull << WN) - 1ull)) != 0ull;
+        if (own) kind = 0;
+        else if (!covered) kind = 1;
       }
     }
-    if (kind[k] >= 0) slot[k] = atomicAdd(&s_cnt[kind[k]], 1u);
-  }
-  __syncthreads();
-  if (tid < 2) {
-    unsigned n = s_cnt[tid];
-    s_base[tid] = n ? atomicAdd(tid == 0 ? &ctl->n_l1 : &ctl->n_a1, n) : 0u;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    if (kind[k] < 0) continue;
-    int ly = tid / TX + k * (NT / TX);
-    int gy = y0 + ly, gx = x0 + lx;
-    unsigned long long key = (unsigned long long)__double_as_longlong(s_sc[(ly + 2 * r) * RW + (lx + 2 * r)]);
-    unsigned idx = (unsigned)gy * (unsigned)W + (unsigned)gx;
-    unsigned pos = s_base[kind[k]] + slot[k];
-    if (pos >= cap) {
-      ctl->overflow = 1;
-      continue;
-    }
-    if (kind[k] == 0) {
-      keys_l1[pos] = key;
-      idx_l1[pos] = idx;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(sv);
+    const unsigned idx = (unsigned)gy * (unsigned)W + (unsigned)gx;
+    const unsigned s0 = wave_slot(kind == 0, &s_cnt[0]);
+    const unsigned s1 = wave_slot(kind == 1, &s_cnt[1]);
+    if (kind == 0) {
+      seg_keys_l1[seg0 + s0] = key;
+      seg_idx_l1[seg0 + s0] = idx;
       atomicAdd(&hist[key >> HIST_SHIFT], 1u);
-    } else {
-      keys_a1[pos] = key;
-      idx_a1[pos] = idx;
+    } else if (kind == 1) {
+      seg_keys_a1[seg0 + s1] = key;
+      seg_idx_a1[seg0 + s1] = idx;
     }
   }
+  __syncthreads();
+  STAMP(5);
+  if (tid == 0) seg_cnt[blk] = make_uint4(s_cnt[0], s_cnt[1], 0u, 0u);
 }
 
 // ---------------------------------------------------------------------------------
 // NMS stage 2: score bound with >= N L1 entries above it; clears the histogram
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void nms_threshold_kernel(unsigned* __restrict__ hist, nms_ctl* ctl, int N) {
-  // wave w owns bins [4096 w, 4096 w + 4096); lane l holds bins 4096 w + 64 j + l, j = 0..63 (coalesced rows)
+  // wave w owns bins [4096 w, 4096 w + 4096) as 64 rows of 64 bins; lane l loads bin 64 j + l of row j
   __shared__ unsigned s_wave[16];
+  __shared__ unsigned s_t[64 * 65];   // the crossing wave's bins, row stride 65 (conflict-free column walks)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   unsigned v[64];
   unsigned part = 0;
@@ -283,145 +339,320 @@ __global__ __launch_bounds__(1024) void nms_threshold_kernel(unsigned* __restric
   }
   if (tid == 0 && total < (unsigned)N) ctl->t_bits = 1ull;   // fewer than N strict maxima: keep everything
   if (total >= (unsigned)N && above < (unsigned)N && above + s_wave[wv] >= (unsigned)N) {
-    // the crossing lies in this wave's 4096 bins: walk its rows from the top
-    unsigned acc = above;
-    int bin = -1;
+    // exactly one wave gets here.  Transpose through LDS: lane j then owns row j.
 #pragma unroll
-    for (int j = 63; j >= 0; --j) {
-      unsigned row = v[j];
+    for (int j = 0; j < 64; ++j) s_t[j * 65 + lane] = v[j];
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave's own LDS writes have landed
+    unsigned row = 0;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) row += __shfl_xor(row, off);
-      if (bin < 0 && acc + row >= (unsigned)N) {
-        // inside row j: suffix over lanes (higher lane = higher bin)
-        unsigned suf = v[j];
+    for (int l = 0; l < 64; ++l) row += s_t[lane * 65 + l];
+    // suffix sums over rows (higher row = higher bins)
+    unsigned suf = row;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          unsigned o = __shfl_down(suf, off);
-          if (lane + off < 64) suf += o;
-        }
-        // suf = sum of v[j] over lanes >= lane; crossing lane = highest lane with acc + suf >= N
-        unsigned long long m = __ballot(acc + suf >= (unsigned)N);
-        int hl = 63 - __builtin_clzll(m);
-        bin = wv * 4096 + 64 * j + hl;
-      }
-      if (bin < 0) acc += row;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_down(suf, off);
+      if (lane + off < 64) suf += o;
     }
+    const unsigned long long mr = __ballot(above + suf >= (unsigned)N);
+    const int jr = 63 - __builtin_clzll(mr);                 // crossing row
+    const unsigned suf_next = __shfl(suf, (jr + 1) & 63);
+    const unsigned acc = above + (jr < 63 ? suf_next : 0u);  // count strictly above row jr
+    // inside row jr: lane l holds bin l
+    unsigned sb = s_t[jr * 65 + lane];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_down(sb, off);
+      if (lane + off < 64) sb += o;
+    }
+    const unsigned long long mb = __ballot(acc + sb >= (unsigned)N);
+    const int bin = wv * 4096 + 64 * jr + (63 - __builtin_clzll(mb));
     if (lane == 0) {
-      unsigned long long t = (unsigned long long)bin << HIST_SHIFT;
+      const unsigned long long t = (unsigned long long)bin << HIST_SHIFT;
       ctl->t_bits = t ? t : 1ull;
     }
   }
 }
 
 // ---------------------------------------------------------------------------------
-// NMS stage 3: candidates at or above the bound -> one list (bit 0 of idx = "is A1")
+// NMS stage 3 (one workgroup per tile): L1 >= T -> selected list; A1 >= T -> live candidates
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long long* __restrict__ keys_l1,
-                                                         const unsigned* __restrict__ idx_l1,
-                                                         const unsigned long long* __restrict__ keys_a1,
-                                                         const unsigned* __restrict__ idx_a1,
+__global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long long* __restrict__ seg_keys_l1,
+                                                         const unsigned* __restrict__ seg_idx_l1,
+                                                         const unsigned long long* __restrict__ seg_keys_a1,
+                                                         const unsigned* __restrict__ seg_idx_a1,
+                                                         uint4* __restrict__ seg_cnt, unsigned* __restrict__ seg_cand,
                                                          unsigned long long* __restrict__ keys_c,
-                                                         unsigned* __restrict__ idx_c, unsigned* __restrict__ cand,
-                                                         uint8_t* __restrict__ alive, nms_ctl* ctl, unsigned cap_c,
-                                                         unsigned cap_cand) {
-  // L1 entries at or above the bound are selected outright; A1 entries become live candidates
-  const unsigned n_l1 = ctl->n_l1, n_a1 = ctl->n_a1;
+                                                         unsigned* __restrict__ idx_c, unsigned* __restrict__ alive,
+                                                         nms_ctl* ctl, unsigned cap_c) {
+  __shared__ unsigned s_n;
+  const unsigned blk = blockIdx.x;
+  const size_t seg0 = (size_t)blk * SEG;
+  const uint4 cnt = seg_cnt[blk];
   const unsigned long long t = ctl->t_bits;
-  const unsigned total = n_l1 + n_a1;
-  for (unsigned i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
-    const bool a = i >= n_l1;
-    const unsigned j = a ? i - n_l1 : i;
-    const unsigned long long key = a ? keys_a1[j] : keys_l1[j];
-    if (key < t) continue;
-    const unsigned idx = a ? idx_a1[j] : idx_l1[j];
-    if (a) {
-      const unsigned pos = atomicAdd(&ctl->n_cand, 1u);
-      if (pos >= cap_cand) {
-        ctl->overflow = 1;
-        continue;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (unsigned b0 = 0; b0 < cnt.x; b0 += NT) {
+    const unsigned i = b0 + tid;
+    if (i < cnt.x) {
+      const unsigned long long key = seg_keys_l1[seg0 + i];
+      if (key >= t) {
+        const unsigned pos = atomicAdd(&ctl->n_c, 1u);
+        if (pos < cap_c) {
+          keys_c[pos] = key;
+          idx_c[pos] = seg_idx_l1[seg0 + i] << 1;
+        } else {
+          ctl->overflow = 1;
+        }
       }
-      cand[pos] = idx;
-      alive[idx] = 1;
-    } else {
-      const unsigned pos = atomicAdd(&ctl->n_c, 1u);
-      if (pos >= cap_c) {
-        ctl->overflow = 1;
-        continue;
-      }
-      keys_c[pos] = key;
-      idx_c[pos] = idx << 1;
     }
+  }
+  for (unsigned b0 = 0; b0 < cnt.y; b0 += NT) {
+    const unsigned i = b0 + tid;
+    const unsigned long long key = i < cnt.y ? seg_keys_a1[seg0 + i] : 0ull;
+    const bool keep = i < cnt.y && key >= t;
+    const unsigned slot = wave_slot(keep, &s_n);
+    if (keep) {
+      const unsigned idx = seg_idx_a1[seg0 + i];
+      seg_cand[seg0 + slot] = idx;
+      alive[idx] = live_code(key);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    seg_cnt[blk].z = s_n;
+    seg_cnt[blk].w = s_n;   // live candidates left in this tile
   }
 }
 
-// One parallel round of the greedy rule on the live candidates (alive: 0 dead / not a
-// candidate, 1 live, 2 selected).  Safe under stale reads: see the file header.
-__global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict__ sc, uint8_t* alive,
-                                                       const unsigned* __restrict__ cand,
+// Parallel rounds of the greedy rule, one workgroup per tile.  The tile's part of the
+// state map (tile + r halo) is staged in LDS and the tile iterates locally:
+//   1. M = (2r+1)^2 window maximum of the state words (separable, dense over the tile);
+//   2. a live candidate whose word equals M has no live neighbour with a larger 32-bit
+//      view of the score; it scans its window once for equal words (settled by the full
+//      score and the index) and, if it still stands, is selected: own word := 1, every
+//      other word of its window := 0, in LDS and in the global map.
+// Halo words are a snapshot taken at kernel start; state only moves live -> selected |
+// dead, so a stale word can only postpone a decision to the next launch.
+constexpr int ROUND_ITERS = 12;
+
+template <int R_T>
+__global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict__ sc, unsigned* alive,
+                                                       uint4* __restrict__ seg_cnt,
+                                                       const unsigned* __restrict__ seg_cand,
                                                        unsigned long long* __restrict__ keys_c,
                                                        unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c,
-                                                       unsigned cap_cand, int H, int W, int r) {
-  const unsigned n = min(ctl->n_cand, cap_cand);
-  for (unsigned i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-    const unsigned idx = cand[i];
-    if (alive[idx] != 1) continue;
+                                                       int H, int W, int r_arg, int tiles_x,
+                                                       unsigned long long* stamps) {
+  extern __shared__ __align__(16) unsigned s_dyn[];
+  const int r = R_T > 0 ? R_T : r_arg;
+  const int WN = 2 * r + 1;
+  const int LW = CX + 2 * r, LH = CY + 2 * r;
+  unsigned* s_state = s_dyn;                     // LH x LW
+  unsigned* s_rmax = s_state + LW * LH;          // LH x CX   row maxima
+  unsigned* s_m = s_rmax + LH * CX;              // CY x CX   window maxima
+  __shared__ unsigned short s_cell[SEG];         // LDS cell of candidate i
+  __shared__ unsigned short s_pass[SEG];         // candidates that top their window this iteration
+  __shared__ unsigned short s_sel[SEG];          // candidates selected in this launch
+  __shared__ unsigned s_npass, s_nsel;
+  const unsigned blk = blockIdx.x;
+  const unsigned n = seg_cnt[blk].z;
+  const int tid = threadIdx.x;
+  if (stamps && tid == 0) { for (int k = 0; k < 24; ++k) stamps[(size_t)blk * 24 + k] = 0; stamps[(size_t)blk * 24] = __builtin_amdgcn_s_memtime(); stamps[(size_t)blk*24+23] = n; }
+  if (n == 0 || seg_cnt[blk].w == 0) return;
+  const int x0 = (int)(blk % (unsigned)tiles_x) * CX, y0 = (int)(blk / (unsigned)tiles_x) * CY;
+  const size_t seg0 = (size_t)blk * SEG;
+  {
+    // all loads of the snapshot are issued before the first is stored
+    constexpr int PER = R_T > 0 ? ((CX + 2 * R_T) * (CY + 2 * R_T) + NT - 1) / NT : 1;
+    if (R_T > 0) {
+      unsigned v[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * NT;
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = y0 - r + ly, gx = x0 - r + lx;
+        const bool in = i < LW * LH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        v[k] = in ? alive[(size_t)(in ? gy : 0) * W + (in ? gx : 0)] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * NT;
+        if (i < LW * LH) s_state[i] = v[k];
+      }
+    } else {
+      for (int i = tid; i < LW * LH; i += NT) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = y0 - r + ly, gx = x0 - r + lx;
+        unsigned v = 0u;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = alive[(size_t)gy * W + gx];
+        s_state[i] = v;
+      }
+    }
+  }
+  for (unsigned i = tid; i < n; i += NT) {
+    const unsigned idx = seg_cand[seg0 + i];
     const int py = (int)(idx / (unsigned)W), px = (int)(idx - (unsigned)py * (unsigned)W);
-    const double s = sc[idx];
-    const int ya = max(py - r, 0), yb = min(py + r, H - 1);
-    const int xa = max(px - r, 0), xb = min(px + r, W - 1);
-    bool dead = false, blocked = false;
-    for (int y = ya; y <= yb && !dead; ++y) {
-      const uint8_t* arow = alive + (size_t)y * W;
-      const double* srow = sc + (size_t)y * W;
-      for (int x = xa; x <= xb; ++x) {
-        const uint8_t av = arow[x];
-        if (av == 0 || (y == py && x == px)) continue;
-        if (av == 2) {
-          dead = true;
-          break;
+    s_cell[i] = (unsigned short)((py - y0 + r) * LW + (px - x0 + r));
+  }
+  if (tid == 0) s_nsel = 0;
+  __syncthreads();
+  if (stamps && tid == 0) stamps[(size_t)blk * 24 + 1] = __builtin_amdgcn_s_memtime();
+  for (int iter = 0; iter < ROUND_ITERS; ++iter) {
+    // ---- window maximum of the state words, rows then columns ----
+    for (int it = tid; it < LH * (CX / 8); it += NT) {
+      const int ly = it / (CX / 8), xs = (it - ly * (CX / 8)) * 8;
+      const unsigned* row = s_state + ly * LW + xs;
+      if (R_T > 0) {
+        unsigned v[8 + 2 * R_T];
+#pragma unroll
+        for (int k = 0; k < 8 + 2 * R_T; ++k) v[k] = row[k];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          unsigned m = v[o];
+#pragma unroll
+          for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
+          s_rmax[ly * CX + xs + o] = m;
         }
-        if (!blocked) {
-          const double q = srow[x];
-          const bool before = (y < py) || (y == py && x < px);
-          if (before ? (q >= s) : (q > s)) blocked = true;
+      } else {
+        for (int o = 0; o < 8; ++o) {
+          unsigned m = row[o];
+          for (int d = 1; d < WN; ++d) m = max(m, row[o + d]);
+          s_rmax[ly * CX + xs + o] = m;
         }
       }
     }
-    if (dead) {
-      alive[idx] = 0;
-      continue;
+    __syncthreads();
+    for (int it = tid; it < CX * (CY / 8); it += NT) {
+      const int lx = it & (CX - 1), ys = (it / CX) * 8;
+      const unsigned* col = s_rmax + ys * CX + lx;
+      if (R_T > 0) {
+        unsigned v[8 + 2 * R_T];
+#pragma unroll
+        for (int k = 0; k < 8 + 2 * R_T; ++k) v[k] = col[k * CX];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          unsigned m = v[o];
+#pragma unroll
+          for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
+          s_m[(ys + o) * CX + lx] = m;
+        }
+      } else {
+        for (int o = 0; o < 8; ++o) {
+          unsigned m = col[o * CX];
+          for (int d = 1; d < WN; ++d) m = max(m, col[(o + d) * CX]);
+          s_m[(ys + o) * CX + lx] = m;
+        }
+      }
     }
-    if (blocked) continue;
-    alive[idx] = 2;
-    const unsigned pos = atomicAdd(&ctl->n_c, 1u);
+    __syncthreads();
+    // ---- candidates whose word tops their window ----
+    if (tid == 0) s_npass = 0;
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += NT) {
+      const int cell = s_cell[i];
+      const unsigned cp = s_state[cell];
+      if (cp < 3u) continue;                                   // selected or dead
+      const int ly = cell / LW, lx = cell - ly * LW;
+      if (s_m[(ly - r) * CX + (lx - r)] != cp) continue;       // a live neighbour has a larger word
+      s_pass[atomicAdd(&s_npass, 1u)] = (unsigned short)cell;
+    }
+    __syncthreads();
+    const unsigned npass = s_npass;
+    // ---- one wave per passing candidate: lanes share the window ----
+    // Equal words are settled by the full score, then the flat index (a total order, so of
+    // two tied neighbours exactly one proceeds).  The winner is selected and kills the live
+    // words of its window, in LDS and in the global map.
+    const int lane = tid & 63;
+    for (unsigned k = tid >> 6; k < npass; k += NT / 64) {
+      const int cell = s_pass[k];
+      unsigned* c = s_state + cell;
+      const unsigned cp = *c;
+      if (cp < 3u) continue;                                   // killed by a tied winner meanwhile
+      const int ly = cell / LW, lx = cell - ly * LW;
+      const int py = y0 - r + ly, px = x0 - r + lx;
+      bool blocked = false;
+      for (int t = lane; t < WN * WN; t += 64) {
+        const int j = t / WN - r, d = t - (t / WN) * WN - r;
+        if (j == 0 && d == 0) continue;
+        const unsigned v = c[j * LW + d];
+        if (v == 1u) blocked = true;                           // a tied neighbour was selected first
+        if (v == cp) {
+          const double s = sc[(size_t)py * W + px];
+          const double q = sc[(size_t)(py + j) * W + (px + d)];
+          const bool before = (j < 0) || (j == 0 && d < 0);
+          if (before ? (q >= s) : (q > s)) blocked = true;
+        }
+      }
+      if (__ballot(blocked) != 0ull) continue;
+      for (int t = lane; t < WN * WN; t += 64) {
+        const int j = t / WN - r, d = t - (t / WN) * WN - r;
+        if (j == 0 && d == 0) continue;
+        unsigned* q = c + j * LW + d;
+        if (*q >= 3u) {                                        // live words only (always inside the image)
+          *q = 0u;
+          alive[(size_t)(py + j) * W + (px + d)] = 0u;
+        }
+      }
+      if (lane == 0) {
+        *c = 1u;
+        alive[(size_t)py * W + px] = 1u;
+        s_sel[atomicAdd(&s_nsel, 1u)] = (unsigned short)cell;   // flushed to the global list at the end
+      }
+    }
+    const bool progress = npass != 0;
+    const int any = __syncthreads_or(progress ? 1 : 0);
+    if (stamps && tid == 0) stamps[(size_t)blk * 24 + 2 + iter] = __builtin_amdgcn_s_memtime();
+    if (!any) break;
+  }
+  // append this launch's selections to the global list: one atomic per tile
+  __syncthreads();
+  {
+    if (tid == 0) s_npass = 0;
+    __syncthreads();
+    unsigned live = 0;
+    for (unsigned i = tid; i < n; i += NT) live += s_state[s_cell[i]] >= 3u ? 1u : 0u;
+    if (live) atomicAdd(&s_npass, live);
+    __syncthreads();
+    if (tid == 0) seg_cnt[blk].w = s_npass;
+    __syncthreads();
+  }
+  const unsigned nsel = s_nsel;
+  if (nsel == 0) return;
+  if (tid == 0) s_npass = atomicAdd(&ctl->n_c, nsel);
+  __syncthreads();
+  const unsigned base = s_npass;
+  for (unsigned k = tid; k < nsel; k += NT) {
+    const int cell = s_sel[k];
+    const int ly = cell / LW, lx = cell - ly * LW;
+    const unsigned idx = (unsigned)(y0 - r + ly) * (unsigned)W + (unsigned)(x0 - r + lx);
+    const unsigned pos = base + k;
     if (pos < cap_c) {
-      keys_c[pos] = (unsigned long long)__double_as_longlong(s);
+      keys_c[pos] = (unsigned long long)__double_as_longlong(sc[idx]);
       idx_c[pos] = idx << 1;
     } else {
       ctl->overflow = 1;
-    }
-    for (int y = ya; y <= yb; ++y) {
-      uint8_t* arow = alive + (size_t)y * W;
-      for (int x = xa; x <= xb; ++x)
-        if (arow[x] == 1) arow[x] = 0;
     }
   }
 }
 
 // After the rounds: candidates still live join the list as undecided entries (bit 0 set);
 // every candidate's mark is cleared so the map is all-zero for the next call.
-__global__ __launch_bounds__(NT) void nms_collect_kernel(const double* __restrict__ sc, uint8_t* alive,
-                                                         const unsigned* __restrict__ cand,
+__global__ __launch_bounds__(NT) void nms_collect_kernel(const double* __restrict__ sc, unsigned* alive,
+                                                         const uint4* __restrict__ seg_cnt,
+                                                         const unsigned* __restrict__ seg_cand,
                                                          unsigned long long* __restrict__ keys_c,
-                                                         unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c,
-                                                         unsigned cap_cand) {
-  const unsigned n = min(ctl->n_cand, cap_cand);
-  for (unsigned i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
-    const unsigned idx = cand[i];
-    const uint8_t a = alive[idx];
-    if (a == 0) continue;
-    alive[idx] = 0;
-    if (a == 1) {
+                                                         unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c) {
+  const unsigned blk = blockIdx.x;
+  const unsigned n = seg_cnt[blk].z;
+  const size_t seg0 = (size_t)blk * SEG;
+  for (unsigned i = threadIdx.x; i < n; i += NT) {
+    const unsigned idx = seg_cand[seg0 + i];
+    const unsigned a = alive[idx];
+    if (a == 0u) continue;
+    alive[idx] = 0u;
+    if (a >= 3u) {
+      atomicAdd(&ctl->n_rem, 1u);
       const unsigned pos = atomicAdd(&ctl->n_c, 1u);
       if (pos < cap_c) {
         keys_c[pos] = (unsigned long long)__double_as_longlong(sc[idx]);
@@ -434,12 +665,11 @@ __global__ __launch_bounds__(NT) void nms_collect_kernel(const double* __restric
 }
 
 // ---------------------------------------------------------------------------------
-// NMS stage 4 (one workgroup): sort by priority, greedy walk, write keypoints
+// NMS stage 4, usual case (nothing left undecided): rank by counting, then emit
 // ---------------------------------------------------------------------------------
-constexpr int SEL_T = 1024;       // threads
-constexpr int CHUNK = 8192;       // entries sorted in LDS at a time
-constexpr int MAX_N = 16384;      // keypoints
-constexpr int NMS_ROUNDS = 6;     // parallel greedy rounds before the single-workgroup walk
+constexpr int RK_I = 256;     // entries ranked per tile (one per thread)
+constexpr int RK_J = 128;     // entries compared against per tile
+constexpr int RK_BLOCKS = 1024;
 
 __device__ __forceinline__ bool prio_before(unsigned long long ka, unsigned ia, unsigned long long kb,
                                             unsigned ib) {
@@ -447,6 +677,86 @@ __device__ __forceinline__ bool prio_before(unsigned long long ka, unsigned ia, 
   return ka > kb || (ka == kb && ia < ib);
 }
 
+__global__ __launch_bounds__(NT) void nms_rank_kernel(const unsigned long long* __restrict__ keys_c,
+                                                      const unsigned* __restrict__ idx_c, const nms_ctl* ctl,
+                                                      unsigned* __restrict__ rank) {
+  __shared__ unsigned long long s_k[RK_J];
+  __shared__ unsigned s_i[RK_J];
+  const unsigned M = ctl->n_c;
+  if (ctl->n_rem != 0 || M > (unsigned)RANK_MAX) return;
+  const unsigned ti = (M + RK_I - 1) / RK_I, tj = (M + RK_J - 1) / RK_J;
+  const int tid = threadIdx.x;
+  for (unsigned tile = blockIdx.x; tile < ti * tj; tile += gridDim.x) {
+    const unsigned i0 = (tile / tj) * RK_I, j0 = (tile % tj) * RK_J;
+    __syncthreads();
+    if (tid < RK_J) {
+      const unsigned j = j0 + tid;
+      s_k[tid] = j < M ? keys_c[j] : 0ull;
+      s_i[tid] = j < M ? idx_c[j] : 0xffffffffu;
+    }
+    const unsigned i = i0 + tid;
+    const unsigned long long ka = i < M ? keys_c[i] : ~0ull;
+    const unsigned xa = i < M ? idx_c[i] : 0u;
+    __syncthreads();
+    unsigned c = 0;
+#pragma unroll 16
+    for (int k = 0; k < RK_J; ++k) c += prio_before(s_k[k], s_i[k], ka, xa) ? 1u : 0u;
+    if (i < M && c) atomicAdd(&rank[i], c);
+  }
+}
+
+constexpr int SEL_T = 1024;       // threads of the single-workgroup kernels
+constexpr int CHUNK = 8192;       // entries sorted in LDS at a time
+constexpr int MAX_N = 16384;      // keypoints
+constexpr int NMS_ROUNDS = 4;     // launches of the tile-local greedy rounds before the final stage
+
+__device__ __forceinline__ void write_keypoints(const unsigned* sel, unsigned nsel, unsigned edge, int W, int N,
+                                                double* __restrict__ kp_xy) {
+  // reference slicing corner cases: a pick with y < r or x < r suppresses nothing and is
+  // returned for every later slot; once the scores are exhausted the picks are (0, 0)
+  for (unsigned i = threadIdx.x; i < (unsigned)N; i += SEL_T) {
+    double x = 0.0, y = 0.0;
+    unsigned src = i;
+    if (edge != 0xffffffffu && i > edge) src = edge;
+    if (src < nsel) {
+      const unsigned idx = sel[src];
+      const unsigned yy = idx / (unsigned)W;
+      y = (double)yy;
+      x = (double)(idx - yy * (unsigned)W);
+    }
+    kp_xy[2 * i] = x;
+    kp_xy[2 * i + 1] = y;
+  }
+}
+
+__global__ __launch_bounds__(SEL_T) void nms_emit_kernel(const unsigned* __restrict__ idx_c, nms_ctl* ctl,
+                                                         unsigned* __restrict__ rank, int W, int N, int r,
+                                                         unsigned* sel, double* __restrict__ kp_xy) {
+  __shared__ unsigned s_edge;
+  const unsigned M = ctl->n_c;
+  if (ctl->n_rem != 0 || M > (unsigned)RANK_MAX) return;
+  if (threadIdx.x == 0) s_edge = 0xffffffffu;
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < M; i += SEL_T) {
+    const unsigned rk = rank[i];
+    rank[i] = 0;
+    if (rk < (unsigned)N) {
+      const unsigned idx = idx_c[i] >> 1;
+      sel[rk] = idx;
+      const unsigned py = idx / (unsigned)W, px = idx - py * (unsigned)W;
+      if ((int)py < r || (int)px < r) atomicMin(&s_edge, rk);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const unsigned nsel = min(M, (unsigned)N);
+  write_keypoints(sel, nsel, s_edge, W, N, kp_xy);
+  if (threadIdx.x == 0) ctl->n_sel = nsel;
+}
+
+// ---------------------------------------------------------------------------------
+// NMS stage 4, general case (one workgroup): sort by priority, greedy walk, write keypoints
+// ---------------------------------------------------------------------------------
 // bitonic steps j = j_hi .. 1 for merge size k on one LDS-resident chunk starting at global offset g0
 __device__ void bitonic_lds_steps(unsigned long long* sk, unsigned* si, int n, unsigned g0, unsigned k,
                                   unsigned j_hi) {
@@ -480,6 +790,7 @@ __global__ __launch_bounds__(SEL_T) void nms_select_kernel(unsigned long long* _
   __shared__ unsigned s_nsel, s_nsela, s_nalist, s_flag, s_edge;
   const int tid = threadIdx.x;
 
+  if (ctl->n_rem == 0 && ctl->n_c <= (unsigned)RANK_MAX) return;   // the rank/emit kernels handle this call
   const unsigned M = min(ctl->n_c, cap_pow2);
   unsigned Mp = 1;
   while (Mp < M) Mp <<= 1;
@@ -658,22 +969,8 @@ __global__ __launch_bounds__(SEL_T) void nms_select_kernel(unsigned long long* _
   }
   __syncthreads();
 
-  // ---- keypoints (x, y) as float64, with the reference's slicing corner cases ----
   const unsigned nsel = min(s_nsel, (unsigned)N);
-  const unsigned edge = s_edge;
-  for (unsigned i = tid; i < (unsigned)N; i += SEL_T) {
-    double x = 0.0, y = 0.0;
-    unsigned src = i;
-    if (edge != 0xffffffffu && i > edge) src = edge;   // same pixel re-selected forever
-    if (src < nsel) {
-      unsigned idx = sel[src];
-      unsigned yy = idx / (unsigned)W;
-      y = (double)yy;
-      x = (double)(idx - yy * (unsigned)W);
-    }
-    kp_xy[2 * i] = x;
-    kp_xy[2 * i + 1] = y;
-  }
+  write_keypoints(sel, nsel, s_edge, W, N, kp_xy);
   if (tid == 0) ctl->n_sel = nsel;
 }
 
@@ -705,9 +1002,9 @@ size_t response_lds_bytes(int p) {
 }
 
 size_t candidates_lds_bytes(int r) {
-  int RW = TX + 4 * r, RH = TY + 4 * r;
-  int LW = TX + 2 * r, LH = TY + 2 * r;
-  return (size_t)RW * RH * 8 + (size_t)((LW * LH + 15) & ~15) + (size_t)TX * TY;
+  const int RW = CX + 4 * r, RH = CY + 4 * r;
+  const int LW = CX + 2 * r, LH = CY + 2 * r;
+  return (size_t)RW * RH * 8 + (size_t)RH * LW * 8 + (size_t)LH * 16 + (size_t)CY * 16;
 }
 
 unsigned next_pow2(unsigned v) {
@@ -747,71 +1044,113 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const unsigned cap = (unsigned)H * (unsigned)W;
   const unsigned cap_c = next_pow2(2u * cap);
-  VO_TRY(vo_ensure(ctx, ctx->nms_keys_l1, (size_t)cap * 8));
-  VO_TRY(vo_ensure(ctx, ctx->nms_idx_l1, (size_t)cap * 4));
-  VO_TRY(vo_ensure(ctx, ctx->nms_keys_a1, (size_t)cap * 8));
-  VO_TRY(vo_ensure(ctx, ctx->nms_idx_a1, (size_t)cap * 4));
+  const dim3 grid(vo_cdiv(W, CX), vo_cdiv(H, CY));
+  const unsigned nblk = grid.x * grid.y;
+  const size_t seg_total = (size_t)nblk * SEG;
+  VO_TRY(vo_ensure(ctx, ctx->nms_keys_l1, seg_total * 8));
+  VO_TRY(vo_ensure(ctx, ctx->nms_idx_l1, seg_total * 4));
+  VO_TRY(vo_ensure(ctx, ctx->nms_keys_a1, seg_total * 8));
+  VO_TRY(vo_ensure(ctx, ctx->nms_idx_a1, seg_total * 4));
+  VO_TRY(vo_ensure(ctx, ctx->nms_cand, seg_total * 4));
+  VO_TRY(vo_ensure(ctx, ctx->nms_segcnt, (size_t)nblk * sizeof(uint4)));
   VO_TRY(vo_ensure(ctx, ctx->nms_keys_c, (size_t)cap_c * 8));
   VO_TRY(vo_ensure(ctx, ctx->nms_idx_c, (size_t)cap_c * 4));
   VO_TRY(vo_ensure(ctx, ctx->nms_sel, (size_t)MAX_N * 4));
-  VO_TRY(vo_ensure(ctx, ctx->nms_cand, (size_t)cap * 4));
-  if (ctx->nms_alive.cap < (size_t)cap || ctx->nms_alive_dirty) {
-    VO_TRY(vo_ensure(ctx, ctx->nms_alive, (size_t)cap));
-    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_alive.p, 0, ctx->nms_alive.cap, ctx->stream));
-    ctx->nms_alive_dirty = false;
-  }
   if (!ctx->nms_hist.p) {
     VO_TRY(vo_ensure(ctx, ctx->nms_hist, (size_t)HIST_BINS * 4));
     VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_hist.p, 0, (size_t)HIST_BINS * 4, ctx->stream));
+  }
+  if (!ctx->nms_rank.p) {
+    VO_TRY(vo_ensure(ctx, ctx->nms_rank, (size_t)RANK_MAX * 4));
+    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_rank.p, 0, (size_t)RANK_MAX * 4, ctx->stream));
+  }
+  if (ctx->nms_alive.cap < (size_t)cap * 4 || ctx->nms_alive_dirty) {
+    VO_TRY(vo_ensure(ctx, ctx->nms_alive, (size_t)cap * 4));
+    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_alive.p, 0, ctx->nms_alive.cap, ctx->stream));
+    ctx->nms_alive_dirty = false;
   }
   VO_TRY(vo_ensure(ctx, ctx->nms_ctl, sizeof(nms_ctl)));
   nms_ctl* ctl = (nms_ctl*)ctx->nms_ctl.p;
   VO_HIP_TRY(ctx, hipMemsetAsync(ctl, 0, sizeof(nms_ctl), ctx->stream));
 
-  dim3 grid(vo_cdiv(W, TX), vo_cdiv(H, TY));
+  unsigned long long* keys_l1 = (unsigned long long*)ctx->nms_keys_l1.p;
+  unsigned long long* keys_a1 = (unsigned long long*)ctx->nms_keys_a1.p;
+  unsigned* idx_l1 = (unsigned*)ctx->nms_idx_l1.p;
+  unsigned* idx_a1 = (unsigned*)ctx->nms_idx_a1.p;
   unsigned long long* keys_c = (unsigned long long*)ctx->nms_keys_c.p;
   unsigned* idx_c = (unsigned*)ctx->nms_idx_c.p;
   unsigned* cand = (unsigned*)ctx->nms_cand.p;
-  uint8_t* alive = (uint8_t*)ctx->nms_alive.p;
+  uint4* segcnt = (uint4*)ctx->nms_segcnt.p;
+  unsigned* alive = (unsigned*)ctx->nms_alive.p;
+  unsigned* hist = (unsigned*)ctx->nms_hist.p;
+  unsigned* rank = (unsigned*)ctx->nms_rank.p;
+  hipStream_t st = ctx->stream;
   {
+    static bool lds_opt_in = false;   // dynamic LDS above 64 KiB must be requested per kernel
+    if (!lds_opt_in) {
+      VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_candidates_kernel<5>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_candidates_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      lds_opt_in = true;
+    }
     vo_prof_scope ps(ctx, VO_K_NMS_CANDIDATES);
-    hipLaunchKernelGGL(nms_candidates_kernel, grid, dim3(NT), candidates_lds_bytes(r), ctx->stream, d_scores,
-                       H, W, r, (unsigned long long*)ctx->nms_keys_l1.p, (unsigned*)ctx->nms_idx_l1.p,
-                       (unsigned long long*)ctx->nms_keys_a1.p, (unsigned*)ctx->nms_idx_a1.p,
-                       (unsigned*)ctx->nms_hist.p, ctl, cap);
+    const size_t lds = candidates_lds_bytes(r);
+    if (r == 5)
+      hipLaunchKernelGGL(nms_candidates_kernel<5>, grid, dim3(NT), lds, st, d_scores, H, W, r, keys_l1, idx_l1,
+                         keys_a1, idx_a1, segcnt, hist, 0, (unsigned long long*)ctx->dbg_stamps);
+    else
+      hipLaunchKernelGGL(nms_candidates_kernel<0>, grid, dim3(NT), lds, st, d_scores, H, W, r, keys_l1, idx_l1,
+                         keys_a1, idx_a1, segcnt, hist, 0, nullptr);
   }
   VO_TRY(vo_check_launch(ctx, "nms_candidates_kernel"));
   {
     vo_prof_scope ps(ctx, VO_K_NMS_THRESHOLD);
-    hipLaunchKernelGGL(nms_threshold_kernel, dim3(1), dim3(1024), 0, ctx->stream, (unsigned*)ctx->nms_hist.p,
-                       ctl, N);
+    hipLaunchKernelGGL(nms_threshold_kernel, dim3(1), dim3(1024), 0, st, hist, ctl, N);
   }
   VO_TRY(vo_check_launch(ctx, "nms_threshold_kernel"));
   ctx->nms_alive_dirty = true;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_COMPACT);
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(512), dim3(NT), 0, ctx->stream,
-                       (const unsigned long long*)ctx->nms_keys_l1.p, (const unsigned*)ctx->nms_idx_l1.p,
-                       (const unsigned long long*)ctx->nms_keys_a1.p, (const unsigned*)ctx->nms_idx_a1.p, keys_c,
-                       idx_c, cand, alive, ctl, cap_c, cap);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(nblk), dim3(NT), 0, st, keys_l1, idx_l1, keys_a1, idx_a1, segcnt,
+                       cand, keys_c, idx_c, alive, ctl, cap_c);
   }
   VO_TRY(vo_check_launch(ctx, "nms_compact_kernel"));
+  const size_t round_lds = ((size_t)(CX + 2 * r) * (CY + 2 * r) + (size_t)(CY + 2 * r) * CX + (size_t)CY * CX) * 4;
   for (int round = 0; round < NMS_ROUNDS; ++round) {
     vo_prof_scope ps(ctx, VO_K_NMS_ROUND);
-    hipLaunchKernelGGL(nms_round_kernel, dim3(512), dim3(NT), 0, ctx->stream, d_scores, alive, cand, keys_c, idx_c,
-                       ctl, cap_c, cap, H, W, r);
+    if (r == 5)
+      hipLaunchKernelGGL(nms_round_kernel<5>, dim3(nblk), dim3(NT), round_lds, st, d_scores, alive, segcnt, cand,
+                         keys_c, idx_c, ctl, cap_c, H, W, r, (int)grid.x, round == 0 ? (unsigned long long*)ctx->dbg_stamps : nullptr);
+    else
+      hipLaunchKernelGGL(nms_round_kernel<0>, dim3(nblk), dim3(NT), round_lds, st, d_scores, alive, segcnt, cand,
+                         keys_c, idx_c, ctl, cap_c, H, W, r, (int)grid.x, round == 0 ? (unsigned long long*)ctx->dbg_stamps : nullptr);
   }
   VO_TRY(vo_check_launch(ctx, "nms_round_kernel"));
   {
     vo_prof_scope ps(ctx, VO_K_NMS_COLLECT);
-    hipLaunchKernelGGL(nms_collect_kernel, dim3(512), dim3(NT), 0, ctx->stream, d_scores, alive, cand, keys_c, idx_c,
-                       ctl, cap_c, cap);
+    hipLaunchKernelGGL(nms_collect_kernel, dim3(nblk), dim3(NT), 0, st, d_scores, alive, segcnt, cand, keys_c, idx_c,
+                       ctl, cap_c);
   }
   VO_TRY(vo_check_launch(ctx, "nms_collect_kernel"));
   ctx->nms_alive_dirty = false;
   {
+    // usual case: nothing undecided and a short list -> rank by counting, emit
+    vo_prof_scope ps(ctx, VO_K_NMS_RANK);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3(RK_BLOCKS), dim3(NT), 0, st, keys_c, idx_c, ctl,
+                       rank);
+  }
+  VO_TRY(vo_check_launch(ctx, "nms_rank_kernel"));
+  {
+    vo_prof_scope ps(ctx, VO_K_NMS_EMIT);
+    hipLaunchKernelGGL(nms_emit_kernel, dim3(1), dim3(SEL_T), 0, st, idx_c, ctl, rank, W, N, r,
+                       (unsigned*)ctx->nms_sel.p, d_kp_xy);
+  }
+  VO_TRY(vo_check_launch(ctx, "nms_emit_kernel"));
+  {
+    // general case (exits at once when the rank path applied): sort + sequential walk
     vo_prof_scope ps(ctx, VO_K_NMS_SELECT);
-    hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_T), 0, ctx->stream, keys_c, idx_c, ctl, cap_c, W, N, r,
+    hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_T), 0, st, keys_c, idx_c, ctl, cap_c, W, N, r,
                        (unsigned*)ctx->nms_sel.p, d_kp_xy);
   }
   return vo_check_launch(ctx, "nms_select_kernel");

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,8 +40,9 @@ struct vo_ctx {
   vo_buf img, img2, scores, kp, desc;
   vo_buf nms_keys_l1, nms_idx_l1, nms_keys_a1, nms_idx_a1;   // candidate lists
   vo_buf nms_keys_c, nms_idx_c;                              // compacted candidates
-  vo_buf nms_hist, nms_ctl, nms_sel, nms_cand, nms_alive;
+  vo_buf nms_hist, nms_ctl, nms_sel, nms_cand, nms_alive, nms_segcnt, nms_rank;
   bool nms_alive_dirty = false;
+  void* dbg_stamps = nullptr;   // optional device buffer for in-kernel phase stamps (diagnostic builds)
   vo_buf scratch[16];
   // pinned host staging
   void* h_pin = nullptr;
