@@ -158,11 +158,11 @@ def main():
     # untimed: warmup, and one all-kernel event profile to find the dominant kernel
     run(args.warmup)
     ctx.prof_enable(-1)
-    ctx.prof_reset()
+    pipe.prof_reset()
     run(8)
     per_kernel = {}
     for kid in range(_native.K_COUNT):
-        ms, n = ctx.prof_read(kid)
+        ms, n = pipe.prof_read(kid)
         if n:
             per_kernel[ctx.kernel_name(kid)] = (ms, n)
     ctx.prof_disable()
@@ -170,14 +170,14 @@ def main():
     dom_id = [k for k in range(_native.K_COUNT) if ctx.kernel_name(k) == dom_name][0]
 
     # timed region: exactly K steps, events only around the dominant kernel
-    ctx.prof_reset()
+    pipe.prof_reset()
     ctx.prof_enable(dom_id)
     fence()
     t0 = time.perf_counter()
     run(args.steps, record=False)
     fence()
     dt = time.perf_counter() - t0
-    dom_ms, dom_n = ctx.prof_read(dom_id)
+    dom_ms, dom_n = pipe.prof_read(dom_id)
     ctx.prof_disable()
 
     # untimed: accuracy against the analytic ground truth of the stream

@@ -242,6 +242,10 @@ int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img, const flo
 int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng);
 int vo_pipeline_prime(vo_pipeline* p, int idx);
 int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out);
+/* vo_prof_read / vo_prof_reset over both of the pipeline's streams (detection runs on a
+ * second stream beside tracking).                                                   */
+int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64_t* launches);
+int vo_pipeline_prof_reset(vo_pipeline* p);
 /* Writes this rank's shared-map record for the last step into DEVICE memory (async):
  * [T_cw 4x4 row-major (16) | n (1) | n triangulated landmarks x 3, n <= cap], all f64,
  * 17 + 3*cap doubles.  The caller all-gathers the records over RCCL (bench.py).     */

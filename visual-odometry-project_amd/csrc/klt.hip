@@ -55,10 +55,24 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict
   dst[(size_t)y * Wd + x] = (uint8_t)((sum + 128) >> 8);
 }
 
-__device__ __forceinline__ long long wave_sum(long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+// Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic), result in
+// every lane.  Steps: within quads, within half rows, within rows of 16, then the two
+// row broadcasts that gfx9 provides for wave64.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// exact 64-bit sum of per-lane 32-bit partials: two 16-bit limbs, each summed in 32 bits
+__device__ __forceinline__ long long wave_sum(int v) {
+  const int lo = wave_sum_i32(v & 0xffff);
+  const int hi = wave_sum_i32(v >> 16);
+  return (long long)hi * 65536LL + (long long)lo;
 }
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -70,28 +84,65 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int
   w11 = (1 << W_BITS) - w00 - w01 - w10;
 }
 
-// stage the (n x n) block of image pixels whose top-left is (x0, y0) into LDS, reflect-101
+// stage the (n x n) block of image pixels whose top-left is (x0, y0) into LDS, reflect-101.
+// Loads go out in batches of 8 per lane before any is written to LDS (one memory round
+// trip per batch instead of one per byte).
 __device__ __forceinline__ void stage_region(const uint8_t* __restrict__ img, int H, int W, int x0, int y0, int n,
                                              uint8_t* s, int lane) {
-  for (int i = lane; i < n * n; i += 64) {
-    const int ly = i / n, lx = i - ly * n;
-    s[i] = img[(size_t)reflect101(y0 + ly, H) * W + reflect101(x0 + lx, W)];
+  const bool inside = x0 >= 0 && y0 >= 0 && x0 + n <= W && y0 + n <= H;
+  const int total = n * n;
+  for (int b0 = 0; b0 < total; b0 += 8 * 64) {
+    uint8_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = b0 + k * 64 + lane;
+      const int ii = i < total ? i : total - 1;
+      const int ly = ii / n, lx = ii - ly * n;
+      const int gy = inside ? y0 + ly : reflect101(y0 + ly, H);
+      const int gx = inside ? x0 + lx : reflect101(x0 + lx, W);
+      v[k] = img[(size_t)gy * W + gx];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = b0 + k * 64 + lane;
+      if (i < total) s[i] = v[k];
+    }
   }
 }
 
-__global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, int win,
+constexpr int KLT_MARGIN = 4;   // pixels of slack staged around the search window
+constexpr int KLT_WAVES = 4;    // keypoints (waves) per workgroup
+
+// Orders LDS traffic between the lanes of ONE wave (each wave owns a private LDS slice, and
+// waves of a workgroup run different trip counts, so a workgroup barrier must not be used).
+// The LDS executes a wave's instructions in order; only the compiler has to be held back.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// WIN_T > 0: window side known at compile time (index arithmetic folds, loops unroll)
+template <int WIN_T>
+__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, int win_arg,
                                                        int max_iter, double eps2, float min_eig_thr,
                                                        float* __restrict__ next_xy, uint8_t* __restrict__ status,
-                                                       float* __restrict__ err) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int i = blockIdx.x;
-  const int lane = threadIdx.x;
+                                                       float* __restrict__ err, unsigned long long* stamps,
+                                                       int lds_per_wave) {
+  extern __shared__ __align__(16) unsigned char smem_all[];
+  const int i = blockIdx.x * KLT_WAVES + (threadIdx.x >> 6);
+  if (i >= N) return;                                  // whole wave leaves together
+  unsigned char* smem = smem_all + (size_t)(threadIdx.x >> 6) * lds_per_wave;
+  const int lane = threadIdx.x & 63;
+  const int win = WIN_T > 0 ? WIN_T : win_arg;
+  unsigned long long st_t[4] = {0, 0, 0, 0}, st_i[4] = {0, 0, 0, 0}, st_n[4] = {0, 0, 0, 0};
+  const unsigned long long st_begin = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   const int ww = win * win;
   const int n1 = win + 1, n3 = win + 3;
-  // LDS: region bytes (n3*n3) | derivatives int (n1*n1, dx | dy << 16) | template shorts (3 * ww)
+  const int RS = n1 + 2 * KLT_MARGIN;             // side of the staged search region
+  // LDS: region bytes (max(n3*n3, RS*RS)) | derivatives int (n1*n1, dx | dy << 16) | template shorts (3 * ww)
   uint8_t* s_reg = smem;
-  int* s_der = reinterpret_cast<int*>(smem + ((n3 * n3 + 15) & ~15));
-  short* s_tpl = reinterpret_cast<short*>(s_der + n1 * n1);
+  int* s_der = reinterpret_cast<int*>(smem + ((max(n3 * n3, RS * RS) + 15) & ~15));
+  short4* s_tpl = reinterpret_cast<short4*>(s_der + n1 * n1 + ((n1 * n1) & 1));   // 8-byte aligned
 
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -128,11 +179,12 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __r
     }
     int w00, w01, w10, w11;
     bilinear_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
+    const unsigned long long st_a = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- template: image block, Scharr derivatives, interpolated patch ----
-    __syncthreads();
+    wave_sync();
     stage_region(I, H, W, ipx - 1, ipy - 1, n3, s_reg, lane);
-    __syncthreads();
+    wave_sync();
     for (int k = lane; k < n1 * n1; k += 64) {
       const int ly = k / n1, lx = k - ly * n1;
       const int gy = ipy + ly, gx = ipx + lx;
@@ -149,9 +201,8 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __r
       }
       s_der[k] = (dx & 0xffff) | (dy << 16);
     }
-    __syncthreads();
-    int a11 = 0, a12 = 0, a22 = 0;
-    long long A11l = 0, A12l = 0, A22l = 0;
+    wave_sync();
+    int a11 = 0, a12 = 0, a22 = 0;   // per-lane partial sums stay below 2^31 for win <= 31
     for (int k = lane; k < ww; k += 64) {
       const int y = k / win, x = k - y * win;
       const uint8_t* r = s_reg + (y + 1) * n3 + (x + 1);
@@ -162,17 +213,14 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __r
                                  (int)(short)(v10 & 0xffff) * w10 + (int)(short)(v11 & 0xffff) * w11,
                              W_BITS);
       const int iy = descale((v00 >> 16) * w00 + (v01 >> 16) * w01 + (v10 >> 16) * w10 + (v11 >> 16) * w11, W_BITS);
-      s_tpl[3 * k] = (short)ival;
-      s_tpl[3 * k + 1] = (short)ix;
-      s_tpl[3 * k + 2] = (short)iy;
-      A11l += (long long)ix * ix;
-      A12l += (long long)ix * iy;
-      A22l += (long long)iy * iy;
+      s_tpl[k] = make_short4((short)ival, (short)ix, (short)iy, 0);
+      a11 += ix * ix;
+      a12 += ix * iy;
+      a22 += iy * iy;
     }
-    (void)a11; (void)a12; (void)a22;
-    const float A11 = (float)wave_sum(A11l) * FLT_SCALE;
-    const float A12 = (float)wave_sum(A12l) * FLT_SCALE;
-    const float A22 = (float)wave_sum(A22l) * FLT_SCALE;
+    const float A11 = (float)wave_sum(a11) * FLT_SCALE;
+    const float A12 = (float)wave_sum(a12) * FLT_SCALE;
+    const float A22 = (float)wave_sum(a22) * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww);
     if (minEig < min_eig_thr || D < 1.1920929e-07f) {
@@ -182,7 +230,13 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __r
     D = 1.f / D;
     qx -= half;
     qy -= half;
+    const unsigned long long st_b = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (stamps && level < 4) st_t[level] = st_b - st_a;
     float pdx = 0.f, pdy = 0.f;
+    // search region of `next`: staged once with KLT_MARGIN pixels of slack, re-staged
+    // only when the window walks out of it
+    int rx0 = 0, ry0 = 0;
+    bool staged = false;
     for (int j = 0; j < max_iter; ++j) {
       const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
       if (iqx < -win || iqx >= W || iqy < -win || iqy >= H) {
@@ -190,22 +244,30 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __r
         break;
       }
       bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
-      __syncthreads();
-      stage_region(J, H, W, iqx, iqy, n1, s_reg, lane);
-      __syncthreads();
-      long long b1l = 0, b2l = 0;
+      if (!staged || iqx < rx0 || iqy < ry0 || iqx + n1 > rx0 + RS || iqy + n1 > ry0 + RS) {
+        rx0 = iqx - KLT_MARGIN;
+        ry0 = iqy - KLT_MARGIN;
+        wave_sync();
+        stage_region(J, H, W, rx0, ry0, RS, s_reg, lane);
+        wave_sync();
+        staged = true;
+      }
+      const uint8_t* base = s_reg + (iqy - ry0) * RS + (iqx - rx0);
+      int b1 = 0, b2 = 0;
+#pragma unroll
       for (int k = lane; k < ww; k += 64) {
         const int y = k / win, x = k - y * win;
-        const uint8_t* r = s_reg + y * n1 + x;
-        const int jv = descale(r[0] * w00 + r[1] * w01 + r[n1] * w10 + r[n1 + 1] * w11, W_BITS - 5);
-        const int diff = jv - s_tpl[3 * k];
-        b1l += (long long)diff * s_tpl[3 * k + 1];
-        b2l += (long long)diff * s_tpl[3 * k + 2];
+        const uint8_t* r = base + y * RS + x;
+        const int jv = descale(r[0] * w00 + r[1] * w01 + r[RS] * w10 + r[RS + 1] * w11, W_BITS - 5);
+        const short4 t = s_tpl[k];
+        const int diff = jv - t.x;
+        b1 += diff * t.y;
+        b2 += diff * t.z;
       }
-      const float b1 = (float)wave_sum(b1l) * FLT_SCALE;
-      const float b2 = (float)wave_sum(b2l) * FLT_SCALE;
-      const float ddx = (A12 * b2 - A22 * b1) * D;
-      const float ddy = (A12 * b1 - A11 * b2) * D;
+      const float fb1 = (float)wave_sum(b1) * FLT_SCALE;
+      const float fb2 = (float)wave_sum(b2) * FLT_SCALE;
+      const float ddx = (A12 * fb2 - A22 * fb1) * D;
+      const float ddy = (A12 * fb1 - A11 * fb2) * D;
       qx += ddx;
       qy += ddy;
       nx = qx + half;
@@ -218,7 +280,9 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __r
       }
       pdx = ddx;
       pdy = ddy;
+      if (stamps && level < 4) st_n[level] += 1;
     }
+    if (stamps && level < 4) st_i[level] = __builtin_amdgcn_s_memtime() - st_b;
     if (ok && level == 0) {
       const float ex = nx - half, ey = ny - half;
       const int iex = (int)floorf(ex), iey = (int)floorf(ey);
@@ -227,18 +291,24 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __r
         continue;
       }
       bilinear_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);
-      __syncthreads();
-      stage_region(J, H, W, iex, iey, n1, s_reg, lane);
-      __syncthreads();
-      long long sl = 0;
+      if (!staged || iex < rx0 || iey < ry0 || iex + n1 > rx0 + RS || iey + n1 > ry0 + RS) {
+        rx0 = iex - KLT_MARGIN;
+        ry0 = iey - KLT_MARGIN;
+        wave_sync();
+        stage_region(J, H, W, rx0, ry0, RS, s_reg, lane);
+        wave_sync();
+        staged = true;
+      }
+      const uint8_t* base = s_reg + (iey - ry0) * RS + (iex - rx0);
+      int sabs = 0;
       for (int k = lane; k < ww; k += 64) {
         const int y = k / win, x = k - y * win;
-        const uint8_t* r = s_reg + y * n1 + x;
-        const int jv = descale(r[0] * w00 + r[1] * w01 + r[n1] * w10 + r[n1 + 1] * w11, W_BITS - 5);
-        const int diff = jv - s_tpl[3 * k];
-        sl += diff < 0 ? -diff : diff;
+        const uint8_t* r = base + y * RS + x;
+        const int jv = descale(r[0] * w00 + r[1] * w01 + r[RS] * w10 + r[RS + 1] * w11, W_BITS - 5);
+        const int diff = jv - s_tpl[k].x;
+        sabs += diff < 0 ? -diff : diff;
       }
-      e_out = (float)wave_sum(sl) / (float)(32 * ww);
+      e_out = (float)wave_sum(sabs) / (float)(32 * ww);
     }
   }
   if (lane == 0) {
@@ -246,12 +316,22 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_t P, const float* __r
     next_xy[2 * i + 1] = ny;
     status[i] = ok ? 1 : 0;
     err[i] = e_out;
+    if (stamps) {
+      unsigned long long* o = stamps + (size_t)i * 16;
+      o[0] = __builtin_amdgcn_s_memtime() - st_begin;
+      for (int l = 0; l < 4; ++l) {
+        o[1 + l] = st_t[l];
+        o[5 + l] = st_i[l];
+        o[9 + l] = st_n[l];
+      }
+    }
   }
 }
 
 size_t klt_lds_bytes(int win) {
-  const int n1 = win + 1, n3 = win + 3;
-  return (size_t)((n3 * n3 + 15) & ~15) + (size_t)n1 * n1 * 4 + (size_t)3 * win * win * 2;
+  const int n1 = win + 1, n3 = win + 3, RS = n1 + 2 * KLT_MARGIN;
+  const int reg = n3 * n3 > RS * RS ? n3 * n3 : RS * RS;
+  return (size_t)((reg + 15) & ~15) + (size_t)(n1 * n1 + 1) * 4 + (size_t)win * win * 8;
 }
 
 }  // namespace
@@ -339,8 +419,28 @@ int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_p
   if (eps > 10) eps = 10;
   {
     vo_prof_scope ps(ctx, VO_K_KLT_TRACK);
-    hipLaunchKernelGGL(klt_track_kernel, dim3(N), dim3(64), klt_lds_bytes(win), ctx->stream, P, d_prev_xy, N, win,
-                       max_iter, eps * eps, (float)min_eig, d_next_xy, d_status, d_err);
+    const int lds_wave = (int)((klt_lds_bytes(win) + 15) & ~size_t(15));
+    const size_t lds = (size_t)lds_wave * KLT_WAVES;
+    hipStream_t st = ctx->stream;
+    const float me = (float)min_eig;
+    const dim3 kgrid(vo_cdiv(N, KLT_WAVES)), kblock(64 * KLT_WAVES);
+    switch (win) {
+      case 15:
+        hipLaunchKernelGGL(klt_track_kernel<15>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
+                           me, d_next_xy, d_status, d_err, (unsigned long long*)ctx->dbg_stamps, lds_wave);
+        break;
+      case 17:
+        hipLaunchKernelGGL(klt_track_kernel<17>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
+                           me, d_next_xy, d_status, d_err, (unsigned long long*)ctx->dbg_stamps, lds_wave);
+        break;
+      case 21:
+        hipLaunchKernelGGL(klt_track_kernel<21>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
+                           me, d_next_xy, d_status, d_err, (unsigned long long*)ctx->dbg_stamps, lds_wave);
+        break;
+      default:
+        hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
+                           me, d_next_xy, d_status, d_err, (unsigned long long*)ctx->dbg_stamps, lds_wave);
+    }
   }
   return vo_check_launch(ctx, "klt_track_kernel");
 }

@@ -13,6 +13,8 @@
 
 struct vo_pipeline {
   vo_ctx* ctx = nullptr;
+  vo_ctx* det = nullptr;            // second context (own stream + NMS workspace): detection runs beside tracking
+  hipEvent_t evDetStart = nullptr, evDetDone = nullptr;
   vo_pipeline_config cfg;
   int n_levels = 1;
   size_t pyr_bytes = 0;
@@ -176,6 +178,10 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   if (!p) return VO_ENOMEM;
   p->ctx = ctx;
   p->cfg = *cfg;
+  if (vo_create(ctx->device, nullptr, &p->det) != VO_OK) {
+    delete p;
+    return vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the detection stream");
+  }
   const int N = cfg->n_keypoints, Hyp = cfg->hyp;
   const size_t px = (size_t)cfg->H * cfg->W;
   p->n_levels = vo_klt_num_levels(cfg->H, cfg->W, cfg->klt_win, cfg->klt_max_level);
@@ -219,7 +225,9 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(pin_alloc(ctx, &p->h_C, 24));
 #undef PA
   if (rc == VO_OK && (hipEventCreateWithFlags(&p->evA, hipEventDisableTiming) != hipSuccess ||
-                      hipEventCreateWithFlags(&p->evB, hipEventDisableTiming) != hipSuccess))
+                      hipEventCreateWithFlags(&p->evB, hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evDetStart, hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evDetDone, hipEventDisableTiming) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   if (rc != VO_OK) {
     vo_pipeline_destroy(p);
@@ -253,6 +261,9 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (q) (void)hipHostFree(q);
   if (p->evA) (void)hipEventDestroy(p->evA);
   if (p->evB) (void)hipEventDestroy(p->evB);
+  if (p->evDetStart) (void)hipEventDestroy(p->evDetStart);
+  if (p->evDetDone) (void)hipEventDestroy(p->evDetDone);
+  if (p->det) vo_destroy(p->det);
   delete p;
 }
 
@@ -276,10 +287,26 @@ int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
   return VO_OK;
 }
 
+// Harris response + NMS of `frame` on the detection stream.  It starts once everything
+// queued on the main stream so far has finished (the keypoint buffer it overwrites may
+// still be read there) and is joined back into the main stream by detect_join().
 static int detect(vo_pipeline* p, int frame, double* d_kp) {
   const vo_pipeline_config& c = p->cfg;
-  VO_TRY(vo_harris_response_dev(p->ctx, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores));
-  return vo_nms_keypoints_dev(p->ctx, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, d_kp);
+  vo_ctx* ctx = p->ctx;
+  p->det->prof_on = ctx->prof_on;
+  p->det->prof_kernel = ctx->prof_kernel;
+  VO_HIP_TRY(ctx, hipEventRecord(p->evDetStart, ctx->stream));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(p->det->stream, p->evDetStart, 0));
+  int rc = vo_harris_response_dev(p->det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
+  if (rc == VO_OK) rc = vo_nms_keypoints_dev(p->det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, d_kp);
+  if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->det));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, p->det->stream));
+  return VO_OK;
+}
+
+static int detect_join(vo_pipeline* p) {
+  VO_HIP_TRY(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->evDetDone, 0));
+  return VO_OK;
 }
 
 int vo_pipeline_prime(vo_pipeline* p, int idx) {
@@ -291,6 +318,7 @@ int vo_pipeline_prime(vo_pipeline* p, int idx) {
   p->cur = 0;
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[idx], p->cfg.H, p->cfg.W, p->n_levels, p->d_pyr[0]));
   VO_TRY(detect(p, idx, p->d_kp[0]));
+  VO_TRY(detect_join(p));
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   p->prev_frame = idx;
   return VO_OK;
@@ -310,6 +338,9 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   memset(out, 0, sizeof(*out));
   out->best_index = -1;
 
+  // ---- detection on the new frame (feeds the next step) runs on its own stream ----
+  VO_TRY(detect(p, next_idx, p->d_kp[b]));
+
   // ---- tracking ----
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
   hipLaunchKernelGGL(kp_to_f32_kernel, dim3(vo_cdiv(2 * N, 256)), dim3(256), 0, st, p->d_kp[a], N, p->d_prev_f32);
@@ -328,9 +359,6 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   }
   VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
   VO_HIP_TRY(ctx, hipEventRecord(p->evA, st));
-
-  // ---- detection on the new frame (feeds the next step); overlaps the host-side sampling ----
-  VO_TRY(detect(p, next_idx, p->d_kp[b]));
 
   VO_HIP_TRY(ctx, hipEventSynchronize(p->evA));
   const int n = *p->h_ntracked;
@@ -402,6 +430,7 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
       VO_TRY(vo_triangulate_dlt_dev(ctx, p->d_prev_c, p->d_next_c, n, p->d_C, 0, p->d_C + 12, p->d_tri));
     }
   }
+  VO_TRY(detect_join(p));   // the next step (and any fetch) sees the new keypoints
   p->cur = b;
   p->prev_frame = next_idx;
   return VO_OK;
@@ -424,6 +453,25 @@ int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int ca
   hipLaunchKernelGGL(export_state_kernel, dim3(vo_cdiv(threads, 256)), dim3(256), 0, ctx->stream, h, p->d_tri, n, cap,
                      d_record);
   return vo_check_launch(ctx, "export_state_kernel");
+}
+
+// per-kernel event times accumulated on the detection stream (vo_prof_read covers the main one)
+int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64_t* launches) {
+  if (!p) return VO_EINVAL;
+  double a = 0, b = 0;
+  int64_t na = 0, nb = 0;
+  VO_TRY(vo_prof_read(p->ctx, kernel_id, &a, &na));
+  int rc = vo_prof_read(p->det, kernel_id, &b, &nb);
+  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->det));
+  if (total_ms) *total_ms = a + b;
+  if (launches) *launches = na + nb;
+  return VO_OK;
+}
+
+int vo_pipeline_prof_reset(vo_pipeline* p) {
+  if (!p) return VO_EINVAL;
+  VO_TRY(vo_prof_reset(p->ctx));
+  return vo_prof_reset(p->det);
 }
 
 int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* next_xy, double* landmarks,

@@ -120,6 +120,8 @@ _SIGS = {
     "vo_pipeline_step": (_i, [_vp, _i, _i, _vp]),
     "vo_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vo_pipeline_export_state_dev": (_i, [_vp, _vp, _i, _vp]),
+    "vo_pipeline_prof_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_int64)]),
+    "vo_pipeline_prof_reset": (_i, [_vp]),
 }
 
 
@@ -436,6 +438,14 @@ class Pipeline:
         r = StepResult()
         self.ctx._chk(self.ctx._lib.vo_pipeline_step(self._h, int(prev_idx), int(next_idx), C.byref(r)))
         return r
+
+    def prof_read(self, kernel_id):
+        ms, n = C.c_double(), C.c_int64()
+        self.ctx._chk(self.ctx._lib.vo_pipeline_prof_read(self._h, int(kernel_id), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def prof_reset(self):
+        self.ctx._chk(self.ctx._lib.vo_pipeline_prof_reset(self._h))
 
     def export_state_dev(self, result, cap, d_record):
         self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_dev(self._h, C.byref(result), int(cap), C.c_void_p(d_record)))
