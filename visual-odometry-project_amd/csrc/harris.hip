@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
                                                             unsigned long long* __restrict__ seg_keys_a1,
                                                             unsigned* __restrict__ seg_idx_a1,
                                                             uint4* __restrict__ seg_cnt,
-                                                            unsigned* __restrict__ hist, int dbg, unsigned long long* stamps) {
+                                                            unsigned* __restrict__ hist) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int r = R_T > 0 ? R_T : r_arg;
   const int RW = CX + 4 * r, RH = CY + 4 * r;   // score region (2r halo)
@@ -189,8 +189,6 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
   const int x0 = blockIdx.x * CX, y0 = blockIdx.y * CY;
   const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
   if (tid < 2) s_cnt[tid] = 0;
-#define STAMP(k) do { if (stamps && tid == 0) stamps[(size_t)blk * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-  STAMP(0);
 
   for (int i = tid; i < RW * RH; i += NT) {
     const int ly = i / RW, lx = i - ly * RW;
@@ -201,10 +199,8 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
   }
   for (int i = tid; i < LH * 4; i += NT) s_mask[i] = 0;
   __syncthreads();
-  STAMP(1);
 
   // separable window maximum: rows, then columns (no data-dependent branches)
-  if (!(dbg & 1))
   for (int i = tid; i < RH * LW; i += NT) {
     const int ly = i / LW, lx = i - ly * LW;
     const double* row = s_sc + ly * RW + lx;
@@ -216,8 +212,6 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
     s_rm[i] = m;
   }
   __syncthreads();
-  STAMP(2);
-  if (!(dbg & 2))
   for (int i = tid; i < LW * LH; i += NT) {
     const int ly = i / LW, lx = i - ly * LW;
     const double* col = s_rm + ly * LW + lx;
@@ -256,7 +250,6 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
     if (is) atomicOr(&s_mask[ly * 4 + (lx >> 5)], 1u << (lx & 31));
   }
   __syncthreads();
-  STAMP(3);
 
   // L1 flags are bit rows (4 words per L row); a tile row's cover mask is the OR of 2r+1 of them
   for (int i = tid; i < CY * 4; i += NT) {
@@ -266,12 +259,10 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
     s_comb[i] = m;
   }
   __syncthreads();
-  STAMP(4);
 
   // classify the tile's own pixels and append them to the tile's segments
   const int lx = tid & (CX - 1);
   const size_t seg0 = (size_t)blk * SEG;
-  if (!(dbg & 8))
 #pragma unroll
   for (int k = 0; k < SEG / NT; ++k) {
     const int ly = tid / CX + k * (NT / CX);
@@ -307,7 +298,6 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
     }
   }
   __syncthreads();
-  STAMP(5);
   if (tid == 0) seg_cnt[blk] = make_uint4(s_cnt[0], s_cnt[1], 0u, 0u);
 }
 
@@ -442,8 +432,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
                                                        const unsigned* __restrict__ seg_cand,
                                                        unsigned long long* __restrict__ keys_c,
                                                        unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c,
-                                                       int H, int W, int r_arg, int tiles_x,
-                                                       unsigned long long* stamps) {
+                                                       int H, int W, int r_arg, int tiles_x) {
   extern __shared__ __align__(16) unsigned s_dyn[];
   const int r = R_T > 0 ? R_T : r_arg;
   const int WN = 2 * r + 1;
@@ -458,7 +447,6 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   const unsigned blk = blockIdx.x;
   const unsigned n = seg_cnt[blk].z;
   const int tid = threadIdx.x;
-  if (stamps && tid == 0) { for (int k = 0; k < 24; ++k) stamps[(size_t)blk * 24 + k] = 0; stamps[(size_t)blk * 24] = __builtin_amdgcn_s_memtime(); stamps[(size_t)blk*24+23] = n; }
   if (n == 0 || seg_cnt[blk].w == 0) return;
   const int x0 = (int)(blk % (unsigned)tiles_x) * CX, y0 = (int)(blk / (unsigned)tiles_x) * CY;
   const size_t seg0 = (size_t)blk * SEG;
@@ -497,7 +485,6 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   }
   if (tid == 0) s_nsel = 0;
   __syncthreads();
-  if (stamps && tid == 0) stamps[(size_t)blk * 24 + 1] = __builtin_amdgcn_s_memtime();
   for (int iter = 0; iter < ROUND_ITERS; ++iter) {
     // ---- window maximum of the state words, rows then columns ----
     for (int it = tid; it < LH * (CX / 8); it += NT) {
@@ -602,7 +589,6 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     }
     const bool progress = npass != 0;
     const int any = __syncthreads_or(progress ? 1 : 0);
-    if (stamps && tid == 0) stamps[(size_t)blk * 24 + 2 + iter] = __builtin_amdgcn_s_memtime();
     if (!any) break;
   }
   // append this launch's selections to the global list: one atomic per tile
@@ -1098,10 +1084,10 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
     const size_t lds = candidates_lds_bytes(r);
     if (r == 5)
       hipLaunchKernelGGL(nms_candidates_kernel<5>, grid, dim3(NT), lds, st, d_scores, H, W, r, keys_l1, idx_l1,
-                         keys_a1, idx_a1, segcnt, hist, 0, (unsigned long long*)ctx->dbg_stamps);
+                         keys_a1, idx_a1, segcnt, hist);
     else
       hipLaunchKernelGGL(nms_candidates_kernel<0>, grid, dim3(NT), lds, st, d_scores, H, W, r, keys_l1, idx_l1,
-                         keys_a1, idx_a1, segcnt, hist, 0, nullptr);
+                         keys_a1, idx_a1, segcnt, hist);
   }
   VO_TRY(vo_check_launch(ctx, "nms_candidates_kernel"));
   {
@@ -1121,10 +1107,10 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
     vo_prof_scope ps(ctx, VO_K_NMS_ROUND);
     if (r == 5)
       hipLaunchKernelGGL(nms_round_kernel<5>, dim3(nblk), dim3(NT), round_lds, st, d_scores, alive, segcnt, cand,
-                         keys_c, idx_c, ctl, cap_c, H, W, r, (int)grid.x, round == 0 ? (unsigned long long*)ctx->dbg_stamps : nullptr);
+                         keys_c, idx_c, ctl, cap_c, H, W, r, (int)grid.x);
     else
       hipLaunchKernelGGL(nms_round_kernel<0>, dim3(nblk), dim3(NT), round_lds, st, d_scores, alive, segcnt, cand,
-                         keys_c, idx_c, ctl, cap_c, H, W, r, (int)grid.x, round == 0 ? (unsigned long long*)ctx->dbg_stamps : nullptr);
+                         keys_c, idx_c, ctl, cap_c, H, W, r, (int)grid.x);
   }
   VO_TRY(vo_check_launch(ctx, "nms_round_kernel"));
   {

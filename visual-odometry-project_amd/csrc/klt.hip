@@ -126,16 +126,13 @@ template <int WIN_T>
 __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, int win_arg,
                                                        int max_iter, double eps2, float min_eig_thr,
                                                        float* __restrict__ next_xy, uint8_t* __restrict__ status,
-                                                       float* __restrict__ err, unsigned long long* stamps,
-                                                       int lds_per_wave) {
+                                                       float* __restrict__ err, int lds_per_wave) {
   extern __shared__ __align__(16) unsigned char smem_all[];
   const int i = blockIdx.x * KLT_WAVES + (threadIdx.x >> 6);
   if (i >= N) return;                                  // whole wave leaves together
   unsigned char* smem = smem_all + (size_t)(threadIdx.x >> 6) * lds_per_wave;
   const int lane = threadIdx.x & 63;
   const int win = WIN_T > 0 ? WIN_T : win_arg;
-  unsigned long long st_t[4] = {0, 0, 0, 0}, st_i[4] = {0, 0, 0, 0}, st_n[4] = {0, 0, 0, 0};
-  const unsigned long long st_begin = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   const int ww = win * win;
   const int n1 = win + 1, n3 = win + 3;
   const int RS = n1 + 2 * KLT_MARGIN;             // side of the staged search region
@@ -179,7 +176,6 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
     }
     int w00, w01, w10, w11;
     bilinear_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
-    const unsigned long long st_a = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- template: image block, Scharr derivatives, interpolated patch ----
     wave_sync();
@@ -230,8 +226,6 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
     D = 1.f / D;
     qx -= half;
     qy -= half;
-    const unsigned long long st_b = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    if (stamps && level < 4) st_t[level] = st_b - st_a;
     float pdx = 0.f, pdy = 0.f;
     // search region of `next`: staged once with KLT_MARGIN pixels of slack, re-staged
     // only when the window walks out of it
@@ -280,9 +274,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
       }
       pdx = ddx;
       pdy = ddy;
-      if (stamps && level < 4) st_n[level] += 1;
     }
-    if (stamps && level < 4) st_i[level] = __builtin_amdgcn_s_memtime() - st_b;
     if (ok && level == 0) {
       const float ex = nx - half, ey = ny - half;
       const int iex = (int)floorf(ex), iey = (int)floorf(ey);
@@ -316,15 +308,6 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
     next_xy[2 * i + 1] = ny;
     status[i] = ok ? 1 : 0;
     err[i] = e_out;
-    if (stamps) {
-      unsigned long long* o = stamps + (size_t)i * 16;
-      o[0] = __builtin_amdgcn_s_memtime() - st_begin;
-      for (int l = 0; l < 4; ++l) {
-        o[1 + l] = st_t[l];
-        o[5 + l] = st_i[l];
-        o[9 + l] = st_n[l];
-      }
-    }
   }
 }
 
@@ -427,19 +410,19 @@ int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_p
     switch (win) {
       case 15:
         hipLaunchKernelGGL(klt_track_kernel<15>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
-                           me, d_next_xy, d_status, d_err, (unsigned long long*)ctx->dbg_stamps, lds_wave);
+                           me, d_next_xy, d_status, d_err, lds_wave);
         break;
       case 17:
         hipLaunchKernelGGL(klt_track_kernel<17>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
-                           me, d_next_xy, d_status, d_err, (unsigned long long*)ctx->dbg_stamps, lds_wave);
+                           me, d_next_xy, d_status, d_err, lds_wave);
         break;
       case 21:
         hipLaunchKernelGGL(klt_track_kernel<21>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
-                           me, d_next_xy, d_status, d_err, (unsigned long long*)ctx->dbg_stamps, lds_wave);
+                           me, d_next_xy, d_status, d_err, lds_wave);
         break;
       default:
         hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
-                           me, d_next_xy, d_status, d_err, (unsigned long long*)ctx->dbg_stamps, lds_wave);
+                           me, d_next_xy, d_status, d_err, lds_wave);
     }
   }
   return vo_check_launch(ctx, "klt_track_kernel");

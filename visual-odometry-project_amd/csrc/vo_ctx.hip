@@ -101,12 +101,6 @@ void vo_destroy(vo_ctx* c) {
 
 const char* vo_last_error(const vo_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
-int vo_debug_set_stamps(vo_ctx* ctx, void* dev_buffer) {
-  if (!ctx) return VO_EINVAL;
-  ctx->dbg_stamps = dev_buffer;
-  return VO_OK;
-}
-
 int vo_sync(vo_ctx* ctx) {
   if (!ctx) return VO_EINVAL;
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -42,7 +42,6 @@ struct vo_ctx {
   vo_buf nms_keys_c, nms_idx_c;                              // compacted candidates
   vo_buf nms_hist, nms_ctl, nms_sel, nms_cand, nms_alive, nms_segcnt, nms_rank;
   bool nms_alive_dirty = false;
-  void* dbg_stamps = nullptr;   // optional device buffer for in-kernel phase stamps (diagnostic builds)
   vo_buf scratch[16];
   // pinned host staging
   void* h_pin = nullptr;
