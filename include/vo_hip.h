@@ -176,6 +176,25 @@ int vo_reproj_inliers_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int
                           const double* K, const double* d_Rt, double thr_sq,
                           uint8_t* d_mask, double* d_err);
 
+/* ---- descriptor matching ---------------------------------------------------------
+ * [ref: src/vo/features/harris.py:246-262, src/vo/features/sift.py:38-54]
+ * cv2.BFMatcher().knnMatch(q, t, k=2) + ratio test + first-come uniqueness on the train
+ * index, queries in order.  q: nq*D, t: nt*D float32; pairs: up to nq (query, train)
+ * rows; n_pairs: rows written.  Distances are exact for integer-valued descriptors.   */
+int vo_match_knn2_ratio(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int D,
+                        double ratio, int32_t* pairs, int32_t* n_pairs);
+int vo_knn2_dev(vo_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt, int D,
+                int32_t* d_best, double* d_d2);
+
+/* ---- Shi-Tomasi corners -----------------------------------------------------------
+ * [ref: src/vo/features/klt.py:98]  cv2.goodFeaturesToTrack(img, mask, maxCorners,
+ * qualityLevel, minDistance, blockSize).  xy: max_corners*2 float32 (or H*W/4*2 when
+ * max_corners <= 0); n: corners found.  vo_min_eigen_map exposes the H*W float32 map. */
+int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_t* mask,
+                     int max_corners, double quality, double min_dist, int block, float* xy,
+                     int32_t* n);
+int vo_min_eigen_map(vo_ctx* ctx, const uint8_t* img, int H, int W, int block, float* eig);
+
 /* ---- RANSAC control (host-side, bit-compatible with the reference) --------------
  * [ref: src/vo/algorithms/ransac.py:52, 92-94]  the sample stream of
  *   np.random.default_rng(2023).choice(np.arange(pop), replace=False, size=s)

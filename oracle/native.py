@@ -97,3 +97,38 @@ def klt_track(prev, nxt, prev_xy, win=17, max_level=2, max_iter=10, eps=0.03, mi
                            C.c_int(max_level), C.c_int(max_iter), C.c_double(eps), C.c_double(min_eig),
                            _p(out), _p(status), _p(err))
     return out, status, err
+
+
+def match_knn2_ratio(q, t, ratio):
+    q = np.ascontiguousarray(np.asarray(q).reshape(len(q), -1), np.float32)
+    t = np.ascontiguousarray(np.asarray(t).reshape(len(t), -1), np.float32)
+    nq, nt, D = q.shape[0], t.shape[0], q.shape[1]
+    pairs = np.zeros((max(nq, 1), 2), np.int32)
+    best = np.zeros((max(nq, 1), 2), np.int32)
+    d2 = np.zeros((max(nq, 1), 2), np.float64)
+    used = np.zeros(max(nt, 1), np.uint8)
+    f = lib().oracle_match_knn2_ratio
+    f.restype = C.c_int
+    n = f(_p(q), C.c_int(nq), _p(t), C.c_int(nt), C.c_int(D), C.c_double(ratio), _p(pairs), _p(best), _p(d2), _p(used))
+    return pairs[:n].astype(np.int64), best, d2
+
+
+def min_eigen_map(img, block=7):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.zeros((H, W), np.float32)
+    lib().oracle_min_eigen_map(_p(img), C.c_int(H), C.c_int(W), C.c_int(block), _p(out))
+    return out
+
+
+def good_features(img, mask=None, max_corners=500, quality=0.01, min_distance=8, block=7):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    cap = max_corners if max_corners > 0 else H * W
+    xy = np.zeros((cap, 2), np.float32)
+    f = lib().oracle_good_features
+    f.restype = C.c_int
+    n = f(_p(img), C.c_int(H), C.c_int(W), _p(m) if m is not None else None, C.c_int(max_corners),
+          C.c_double(quality), C.c_double(min_distance), C.c_int(block), _p(xy))
+    return xy[:n].copy()

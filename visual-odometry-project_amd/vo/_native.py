@@ -109,6 +109,10 @@ _SIGS = {
     "vo_p3p_hypotheses_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "vo_reproj_inliers": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),
     "vo_reproj_inliers_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
+    "vo_match_knn2_ratio": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _vp, _vp]),
+    "vo_knn2_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "vo_good_features": (_i, [_vp, _vp, _i, _i, _vp, _i, _d, _d, _i, _vp, _vp]),
+    "vo_min_eigen_map": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vo_rng_choice": (_i, [_vp, _i, _i, _i, _vp]),
     "vo_ransac_num_iterations": (C.c_int64, [_d, _d, _i]),
     "vo_ransac_replay": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -265,6 +269,38 @@ class Context:
         d = (2 * r + 1) ** 2
         out = np.empty((n, d), np.float64)
         self._chk(self._lib.vo_patch_descriptors(self._h, _ptr(img), H, W, _ptr(kp), n, int(r), _ptr(out)))
+        return out
+
+    # ---- matching / corners ----
+    def match_knn2_ratio(self, q, t, ratio):
+        q, t = np.asarray(q), np.asarray(t)
+        if len(q) == 0 or len(t) == 0:
+            return np.empty((0, 2), np.int64)
+        q = _c(q.reshape(len(q), -1), np.float32)
+        t = _c(t.reshape(len(t), -1), np.float32)
+        assert q.shape[1] == t.shape[1]
+        pairs = np.empty((max(q.shape[0], 1), 2), np.int32)
+        n = C.c_int32(0)
+        self._chk(self._lib.vo_match_knn2_ratio(self._h, _ptr(q), q.shape[0], _ptr(t), t.shape[0],
+                                                max(q.shape[1], 1), float(ratio), _ptr(pairs), C.byref(n)))
+        return pairs[: n.value].astype(np.int64)
+
+    def good_features(self, img, mask=None, max_corners=500, quality=0.01, min_distance=8, block_size=7):
+        img = _c(img, np.uint8)
+        H, W = img.shape
+        m = None if mask is None else _c(mask, np.uint8)
+        cap = max_corners if max_corners > 0 else (H * W) // 4 + 64
+        xy = np.empty((cap, 2), np.float32)
+        n = C.c_int32(0)
+        self._chk(self._lib.vo_good_features(self._h, _ptr(img), H, W, _ptr(m), int(max_corners), float(quality),
+                                             float(min_distance), int(block_size), _ptr(xy), C.byref(n)))
+        return xy[: n.value].copy()
+
+    def min_eigen_map(self, img, block_size=7):
+        img = _c(img, np.uint8)
+        H, W = img.shape
+        out = np.empty((H, W), np.float32)
+        self._chk(self._lib.vo_min_eigen_map(self._h, _ptr(img), H, W, int(block_size), _ptr(out)))
         return out
 
     # ---- KLT ----
