@@ -38,10 +38,14 @@ def algorithmic_bytes(kernel_name, n_tracked):
     table = {
         "harris_response": px * 1 + px * 8,                   # image read once, fp64 map written once
         "nms_candidates": px * 8,                             # fp64 map read once
-        "nms_threshold": 65536 * 4 * 2,
-        "nms_compact": 0,                                     # list traffic is not compulsory
+        "nms_threshold": 65536 * 4 * 2,                       # histogram read + cleared
+        "nms_compact": N_KP * 12,                             # the N selected strict maxima
+        "nms_round": N_KP * 4 * 2,                            # state words of the picks (list traffic is not compulsory)
+        "nms_collect": 0,
+        "nms_rank": N_KP * 12,
+        "nms_emit": N_KP * 16,                                # keypoints written
         "nms_select": N_KP * 16,
-        "pyr_down": None,                                     # per level, filled below
+        "pyr_down": (px + px // 4) // 2,                      # per launch (2 launches): read level l, write level l+1
         "klt_track": N_KP * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + N_KP * (8 + 8 + 1 + 4),
         "track_gather": N_KP * (8 + 1 + 4 + 16) + n_tracked * (16 + 16 + 24 + 4),
         "p3p_solve": HYP * (16 + 4 * 40 + 96 + 1),
@@ -101,7 +105,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    from vo import _native, synthetic
+    from vo import _native, sharding, synthetic
     comp = torch.cuda.Stream()
     comm = torch.cuda.Stream()
     ctx = _native.Context(local, stream=comp.cuda_stream)
@@ -112,7 +116,7 @@ def main():
         pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
 
     cap = N_KP
-    rec_len = 17 + 3 * cap
+    rec_len = sharding.record_length(cap)
     recs = [torch.zeros(rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
     gathered = [torch.zeros(world * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
     comm_done = [None, None]
@@ -137,7 +141,7 @@ def main():
                 ev.record(comp)
                 comm.wait_event(ev)
                 with torch.cuda.stream(comm):
-                    dist.all_gather_into_tensor(gathered[s], recs[s])
+                    sharding.allgather_records(recs[s], gathered[s])
                     comm_done[s] = torch.cuda.Event()
                     comm_done[s].record(comm)
             if record:
