@@ -82,6 +82,9 @@ enum {
   VO_K_NMS_COLLECT = 15,
   VO_K_NMS_RANK = 16,
   VO_K_NMS_EMIT = 17,
+  VO_K_SIFT_SCALESPACE = 18,
+  VO_K_SIFT_DETECT = 19,
+  VO_K_SIFT_DESCRIBE = 20,
   VO_K_COUNT = 32
 };
 int vo_prof_enable(vo_ctx* ctx, int kernel_id);
@@ -194,6 +197,16 @@ int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_
                      int max_corners, double quality, double min_dist, int block, float* xy,
                      int32_t* n);
 int vo_min_eigen_map(vo_ctx* ctx, const uint8_t* img, int H, int W, int block, float* eig);
+
+/* ---- SIFT ---------------------------------------------------------------------------
+ * [ref: src/vo/features/sift.py:10,17]  cv2.SIFT_create().detectAndCompute(image, None)
+ * with OpenCV's defaults (3 layers/octave, contrast 0.04, edge 10, sigma 1.6, image
+ * doubled first).  kp: cap*6 float32 (x, y, size, angle, response, octave) in image
+ * coordinates, ordered as KeyPointsFilter::removeDuplicatedSorted leaves them; desc:
+ * cap*128 float32 (integer-valued 0..255).  If more than `cap` keypoints are found the
+ * `cap` strongest by response are kept (the reference itself sets no cap).             */
+int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp, float* desc,
+            int32_t* n);
 
 /* ---- RANSAC control (host-side, bit-compatible with the reference) --------------
  * [ref: src/vo/algorithms/ransac.py:52, 92-94]  the sample stream of

@@ -132,3 +132,14 @@ def good_features(img, mask=None, max_corners=500, quality=0.01, min_distance=8,
     n = f(_p(img), C.c_int(H), C.c_int(W), _p(m) if m is not None else None, C.c_int(max_corners),
           C.c_double(quality), C.c_double(min_distance), C.c_int(block), _p(xy))
     return xy[:n].copy()
+
+
+def sift(img, cap=20000):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    kp = np.zeros((cap, 6), np.float32)
+    desc = np.zeros((cap, 128), np.float32)
+    f = lib().oracle_sift
+    f.restype = C.c_int
+    n = f(_p(img), C.c_int(H), C.c_int(W), C.c_int(cap), _p(kp), _p(desc))
+    return kp[:n].copy(), desc[:n].copy()

@@ -223,3 +223,37 @@ def test_headless_driver_runs_the_reference_call_sequence(ctx):
     err = driver.trajectory_error(out, seq)
     # forward motion 0.8 m/frame; monocular scale fitted once
     assert err["rms"] < 0.05 * err["path_length"], err
+
+
+# ---------------- SIFT ----------------
+@pytest.mark.parametrize("kind,shape,seed", [("smooth", (240, 320), 21), ("blocks", (200, 260), 5), ("smooth", (97, 131), 8)])
+def test_sift_matches_oracle(ctx, kind, shape, seed):
+    if kind == "smooth":
+        img, _ = shift_image(shape[0], shape[1], seed, 0.0, 0.0)
+    else:
+        img = synthetic_image(shape[0], shape[1], seed, block=14, noise=3.0)
+    kr, dr = native.sift(img)
+    kg, dg = ctx.sift(img)
+    assert len(kr) > 20
+    assert kg.shape == kr.shape and np.array_equal(kg, kr), "SIFT keypoints not bit-identical to the oracle"
+    assert np.array_equal(dg, dr), "SIFT descriptors not bit-identical to the oracle"
+    assert np.all(np.diff(kg[:, 0]) >= 0) and np.all(dg == np.round(dg)) and dg.max() <= 255
+    capped_r, _ = native.sift(img, cap=25)
+    capped_g, dcg = ctx.sift(img, cap=25)
+    assert np.array_equal(capped_g, capped_r) and len(capped_g) == min(25, len(kr))
+
+
+def test_sift_tracker_mode(ctx):
+    from vo.features import SIFTDetector, Tracker
+    from vo.primitives import Frame, Matches
+    a, b = shift_image(240, 320, 21, 4.0, -3.0)
+    fa, fb = Frame(a), Frame(b)
+    det = SIFTDetector(fa)
+    assert fa.features.keypoints.shape[1:] == (2, 1) and fa.features.descriptors.shape[1] == 128
+    m = det.get_sift_matches(fa, fb)
+    assert isinstance(m, Matches)
+    n = int((m.frame2.features.state >= 1).sum())
+    flow = (m.frame2.features.keypoints[:n] - m.frame1.features.keypoints[:n])[:, :, 0]
+    assert n > 60 and np.mean(np.abs(flow - [4, -3]).max(axis=1) < 1.0) > 0.85
+    t = Tracker(Frame(a), mode="sift")
+    assert isinstance(t.trackFeatures(t._init_frame, Frame(b)), Matches)

@@ -86,7 +86,7 @@ void vo_destroy(vo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   vo_buf* all[] = {&c->img, &c->img2, &c->scores, &c->kp, &c->desc, &c->nms_keys_l1, &c->nms_idx_l1,
                    &c->nms_keys_a1, &c->nms_idx_a1, &c->nms_keys_c, &c->nms_idx_c, &c->nms_hist,
-                   &c->nms_ctl, &c->nms_sel, &c->nms_cand, &c->nms_alive, &c->nms_segcnt, &c->nms_rank};
+                   &c->nms_ctl, &c->nms_sel, &c->nms_cand, &c->nms_alive, &c->nms_segcnt, &c->nms_rank, &c->sift_arena};
   for (vo_buf* b : all) free_buf(*b);
   for (vo_buf& b : c->scratch) free_buf(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -147,7 +147,7 @@ int vo_dev_download(vo_ctx* ctx, void* dst, const void* src, size_t bytes) {
 static const char* const k_names[VO_K_COUNT] = {
     "harris_response", "nms_candidates", "nms_threshold", "nms_compact", "nms_select",
     "patch_descriptors", "pyr_down", "klt_track", "dlt_triangulate", "p3p_solve",
-    "p3p_score", "reproj_inliers", "match_knn2", "track_gather", "nms_round", "nms_collect", "nms_rank", "nms_emit"};
+    "p3p_score", "reproj_inliers", "match_knn2", "track_gather", "nms_round", "nms_collect", "nms_rank", "nms_emit", "sift_scale_space", "sift_detect", "sift_describe"};
 
 const char* vo_kernel_name(int k) {
   if (k < 0 || k >= VO_K_COUNT || !k_names[k]) return "";

@@ -43,6 +43,7 @@ struct vo_ctx {
   vo_buf nms_hist, nms_ctl, nms_sel, nms_cand, nms_alive, nms_segcnt, nms_rank;
   bool nms_alive_dirty = false;
   vo_buf scratch[16];
+  vo_buf sift_arena;
   // pinned host staging
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
