@@ -15,6 +15,9 @@ struct vo_pipeline {
   vo_ctx* ctx = nullptr;
   vo_ctx* det = nullptr;            // second context (own stream + NMS workspace): detection runs beside tracking
   hipEvent_t evDetStart = nullptr, evDetDone = nullptr;
+  uint8_t* d_det_img = nullptr;     // detection input (the frame is copied here so the captured graph is frame-independent)
+  hipGraphExec_t det_graph[2] = {nullptr, nullptr};   // Harris + NMS into d_kp[0] / d_kp[1], captured once
+  bool det_warm = false;
   vo_pipeline_config cfg;
   int n_levels = 1;
   size_t pyr_bytes = 0;
@@ -44,6 +47,9 @@ struct vo_pipeline {
   uint8_t* h_valid = nullptr;
   int32_t* h_counts = nullptr;
   double* h_pose = nullptr;          // 12
+  double *h_R = nullptr, *h_t = nullptr;     // all hypotheses' poses, written by the GPU into mapped host memory
+  volatile unsigned* h_seq = nullptr;         // [0] tracking done, [1] hypotheses mirrored: sequence numbers the host spins on
+  unsigned seq = 0;
   double* h_C = nullptr;             // 24 (C1, C2)
   hipEvent_t evA = nullptr, evB = nullptr;
   // RANSAC object state (persists across frames like the reference's estimator)
@@ -73,7 +79,8 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
                                                              const double* __restrict__ T_wc,
                                                              double* __restrict__ prev_c, double* __restrict__ next_c,
                                                              double* __restrict__ land_c, int32_t* __restrict__ n_out,
-                                                             int32_t* __restrict__ n_out_host) {
+                                                             int32_t* __restrict__ n_out_host,
+                                                             unsigned* __restrict__ seq_host, unsigned seq) {
   __shared__ int s_w[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -114,6 +121,38 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
   if (tid == 0) {
     *n_out = s_base;
     *n_out_host = s_base;   // mapped pinned host memory
+    __threadfence_system();
+    *seq_host = seq;        // the host spins on this word instead of waiting on an event
+  }
+}
+
+// Copies the hypotheses' (valid, count, R, t) into mapped host memory and then publishes a
+// sequence number: the host polls that word, which costs far less than an event wait.
+__global__ __launch_bounds__(256) void mirror_hypotheses_kernel(const uint8_t* __restrict__ valid,
+                                                                const int32_t* __restrict__ counts,
+                                                                const double* __restrict__ R,
+                                                                const double* __restrict__ t, int hyp,
+                                                                uint8_t* __restrict__ h_valid, int32_t* __restrict__ h_counts,
+                                                                double* __restrict__ h_R, double* __restrict__ h_t,
+                                                                unsigned* __restrict__ seq_host, unsigned seq,
+                                                                unsigned* __restrict__ done) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = gridDim.x * blockDim.x;
+  for (int k = i; k < hyp; k += stride) {
+    h_valid[k] = valid[k];
+    h_counts[k] = counts[k];
+  }
+  for (int k = i; k < hyp * 9; k += stride) h_R[k] = R[k];
+  for (int k = i; k < hyp * 3; k += stride) h_t[k] = t[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(done, 1u);
+    if (prev == gridDim.x - 1) {       // last workgroup: everything above is visible to the host
+      *done = 0;
+      __threadfence_system();
+      *seq_host = seq;
+    }
   }
 }
 
@@ -142,6 +181,17 @@ int pin_alloc(vo_ctx* ctx, T** p, size_t count) {
   hipError_t e = hipHostMalloc((void**)p, count * sizeof(T), hipHostMallocMapped);
   if (e != hipSuccess) return vo_set_error(ctx, VO_ENOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
   return VO_OK;
+}
+
+// Polls a word the GPU writes into mapped host memory; falls back to a stream wait if the
+// value has not appeared after ~2 s (a fault would otherwise spin forever).
+int spin_until(vo_ctx* ctx, volatile unsigned* word, unsigned value) {
+  for (long it = 0; it < 400000000L; ++it) {
+    if (*word == value) return VO_OK;
+    __builtin_ia32_pause();
+  }
+  VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return *word == value ? VO_OK : vo_set_error(ctx, VO_EHIP, "pipeline: the GPU never published sequence %u", value);
 }
 
 void rigid_inverse(const double* T, double* Ti) {
@@ -201,6 +251,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     PA(dev_alloc(ctx, &p->d_kp[k], (size_t)N * 2));
   }
   PA(dev_alloc(ctx, &p->d_scores, px));
+  PA(dev_alloc(ctx, &p->d_det_img, px));
   PA(dev_alloc(ctx, &p->d_prev_f32, (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_next_f32, (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_err, (size_t)N));
@@ -209,7 +260,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_next_c, (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_land_c, (size_t)N * 3));
   PA(dev_alloc(ctx, &p->d_tri, (size_t)N * 3));
-  PA(dev_alloc(ctx, &p->d_ntracked, 1));
+  PA(dev_alloc(ctx, &p->d_ntracked, 4));
   PA(dev_alloc(ctx, &p->d_samples, (size_t)Hyp * 4));
   PA(dev_alloc(ctx, &p->d_R, (size_t)Hyp * 9));
   PA(dev_alloc(ctx, &p->d_t, (size_t)Hyp * 3));
@@ -222,6 +273,14 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(pin_alloc(ctx, &p->h_valid, (size_t)Hyp));
   PA(pin_alloc(ctx, &p->h_counts, (size_t)Hyp));
   PA(pin_alloc(ctx, &p->h_pose, 12));
+  PA(pin_alloc(ctx, &p->h_R, (size_t)Hyp * 9));
+  PA(pin_alloc(ctx, &p->h_t, (size_t)Hyp * 3));
+  {
+    unsigned* q = nullptr;
+    PA(pin_alloc(ctx, &q, 16));
+    if (q) memset(q, 0, 64);
+    p->h_seq = q;
+  }
   PA(pin_alloc(ctx, &p->h_C, 24));
 #undef PA
   if (rc == VO_OK && (hipEventCreateWithFlags(&p->evA, hipEventDisableTiming) != hipSuccess ||
@@ -232,6 +291,10 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   if (rc != VO_OK) {
     vo_pipeline_destroy(p);
     return rc;
+  }
+  if (hipMemset(p->d_ntracked, 0, 16) != hipSuccess) {
+    vo_pipeline_destroy(p);
+    return vo_set_error(ctx, VO_EHIP, "pipeline: hipMemset failed");
   }
   p->rs.outlier_ratio = cfg->ransac_outlier_ratio;
   p->rs.confidence = cfg->ransac_confidence;
@@ -251,12 +314,14 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   (void)hipStreamSynchronize(p->ctx->stream);
   for (auto q : p->d_img) (void)hipFree(q);
   for (auto q : p->d_depth) (void)hipFree(q);
-  void* dev[] = {p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_prev_f32,
+  for (int k = 0; k < 2; ++k)
+    if (p->det_graph[k]) (void)hipGraphExecDestroy(p->det_graph[k]);
+  void* dev[] = {p->d_det_img, p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_prev_f32,
                  p->d_next_f32, p->d_err, p->d_status, p->d_prev_c, p->d_next_c, p->d_land_c, p->d_tri,
                  p->d_ntracked, p->d_samples, p->d_R, p->d_t, p->d_C, p->d_valid, p->d_counts, p->d_masks};
   for (void* q : dev)
     if (q) (void)hipFree(q);
-  void* pin[] = {p->h_ntracked, p->h_samples, p->h_valid, p->h_counts, p->h_pose, p->h_C};
+  void* pin[] = {p->h_ntracked, p->h_samples, p->h_valid, p->h_counts, p->h_pose, p->h_C, p->h_R, p->h_t, (void*)p->h_seq};
   for (void* q : pin)
     if (q) (void)hipHostFree(q);
   if (p->evA) (void)hipEventDestroy(p->evA);
@@ -287,20 +352,51 @@ int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
   return VO_OK;
 }
 
-// Harris response + NMS of `frame` on the detection stream.  It starts once everything
-// queued on the main stream so far has finished (the keypoint buffer it overwrites may
-// still be read there) and is joined back into the main stream by detect_join().
-static int detect(vo_pipeline* p, int frame, double* d_kp) {
+// Harris response + NMS of `frame` on the detection stream, joined back into the main stream
+// by detect_join().  The ~15 launches are replayed from a hipGraph captured once per output
+// buffer (the host-side launch cost, not the kernels, was the bottleneck of the step); the
+// plain launch path is kept for the first call (allocations) and for per-kernel profiling.
+static int detect_launches(vo_pipeline* p, double* d_kp) {
   const vo_pipeline_config& c = p->cfg;
+  int rc = vo_harris_response_dev(p->det, p->d_det_img, c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
+  if (rc == VO_OK) rc = vo_nms_keypoints_dev(p->det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, d_kp);
+  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->det));
+  return VO_OK;
+}
+
+static int detect(vo_pipeline* p, int frame, double* d_kp, bool after_main) {
   vo_ctx* ctx = p->ctx;
+  hipStream_t ds = p->det->stream;
   p->det->prof_on = ctx->prof_on;
   p->det->prof_kernel = ctx->prof_kernel;
-  VO_HIP_TRY(ctx, hipEventRecord(p->evDetStart, ctx->stream));
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(p->det->stream, p->evDetStart, 0));
-  int rc = vo_harris_response_dev(p->det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
-  if (rc == VO_OK) rc = vo_nms_keypoints_dev(p->det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, d_kp);
-  if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->det));
-  VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, p->det->stream));
+  if (after_main) {
+    VO_HIP_TRY(ctx, hipEventRecord(p->evDetStart, ctx->stream));
+    VO_HIP_TRY(ctx, hipStreamWaitEvent(ds, p->evDetStart, 0));
+  }
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_det_img, p->d_img[frame], (size_t)p->cfg.H * p->cfg.W, hipMemcpyDeviceToDevice, ds));
+  const int slot = d_kp == p->d_kp[0] ? 0 : 1;
+  static const bool no_graph = getenv("VO_NO_GRAPH") != nullptr;
+  if (!p->det_warm || ctx->prof_on || no_graph) {
+    VO_TRY(detect_launches(p, d_kp));
+    p->det_warm = true;
+  } else {
+    if (!p->det_graph[slot]) {
+      hipGraph_t g = nullptr;
+      VO_HIP_TRY(ctx, hipStreamBeginCapture(ds, hipStreamCaptureModeThreadLocal));
+      const int rc = detect_launches(p, d_kp);
+      const hipError_t e = hipStreamEndCapture(ds, &g);
+      if (rc != VO_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+      }
+      VO_HIP_TRY(ctx, e);
+      const hipError_t ei = hipGraphInstantiate(&p->det_graph[slot], g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      VO_HIP_TRY(ctx, ei);
+    }
+    VO_HIP_TRY(ctx, hipGraphLaunch(p->det_graph[slot], ds));
+  }
+  VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, ds));
   return VO_OK;
 }
 
@@ -317,7 +413,7 @@ int vo_pipeline_prime(vo_pipeline* p, int idx) {
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   p->cur = 0;
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[idx], p->cfg.H, p->cfg.W, p->n_levels, p->d_pyr[0]));
-  VO_TRY(detect(p, idx, p->d_kp[0]));
+  VO_TRY(detect(p, idx, p->d_kp[0], true));
   VO_TRY(detect_join(p));
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   p->prev_frame = idx;
@@ -338,9 +434,6 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   memset(out, 0, sizeof(*out));
   out->best_index = -1;
 
-  // ---- detection on the new frame (feeds the next step) runs on its own stream ----
-  VO_TRY(detect(p, next_idx, p->d_kp[b]));
-
   // ---- tracking ----
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
   hipLaunchKernelGGL(kp_to_f32_kernel, dim3(vo_cdiv(2 * N, 256)), dim3(256), 0, st, p->d_kp[a], N, p->d_prev_f32);
@@ -348,20 +441,35 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
                           p->n_levels, p->d_prev_f32, N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
+  // device-side aliases of the mapped host buffers the kernels publish into
+  int32_t* m_ntracked = nullptr;
+  unsigned* m_seq = nullptr;
+  uint8_t* m_valid = nullptr;
+  int32_t* m_counts = nullptr;
+  double *m_R = nullptr, *m_t = nullptr;
+  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_ntracked, p->h_ntracked, 0));
+  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_seq, (void*)p->h_seq, 0));
+  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_valid, p->h_valid, 0));
+  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_counts, p->h_counts, 0));
+  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_R, p->h_R, 0));
+  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_t, p->h_t, 0));
+  const unsigned seq_a = ++p->seq;
   {
-    int32_t* n_host_dev = nullptr;
-    VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&n_host_dev, p->h_ntracked, 0));
     vo_prof_scope ps(ctx, VO_K_GATHER);
     hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, st, p->d_kp[a], p->d_next_f32, p->d_status,
                        p->d_err, N, (float)c.klt_err_threshold, p->d_depth[prev_idx], c.H, c.W, fx, fy, cx, cy,
                        p->d_T_wc + (size_t)prev_idx * 16, p->d_prev_c, p->d_next_c, p->d_land_c, p->d_ntracked,
-                       n_host_dev);
+                       m_ntracked, m_seq, seq_a);
   }
   VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
-  VO_HIP_TRY(ctx, hipEventRecord(p->evA, st));
 
-  VO_HIP_TRY(ctx, hipEventSynchronize(p->evA));
-  const int n = *p->h_ntracked;
+  // ---- detection on the new frame (feeds the next step) runs beside it on its own stream.
+  // The keypoint buffer it overwrites was last read by the previous step's tracking, which
+  // the host has already waited for, so it needs no dependency on the main stream. ----
+  VO_TRY(detect(p, next_idx, p->d_kp[b], false));
+
+  VO_TRY(spin_until(ctx, p->h_seq, seq_a));
+  const int n = *(volatile int32_t*)p->h_ntracked;
   out->n_tracked = n;
   p->last_ntracked = n;
   p->last_best = -1;
@@ -378,10 +486,11 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
       VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_samples, p->h_samples, (size_t)c.hyp * 16, hipMemcpyHostToDevice, st));
       VO_TRY(vo_p3p_hypotheses_dev(ctx, p->d_land_c, p->d_next_c, n, c.K, p->d_samples, c.hyp, c.p3p_thr_sq, p->d_R,
                                    p->d_t, p->d_valid, p->d_counts, p->d_masks));
-      VO_HIP_TRY(ctx, hipMemcpyAsync(p->h_valid, p->d_valid, (size_t)c.hyp, hipMemcpyDeviceToHost, st));
-      VO_HIP_TRY(ctx, hipMemcpyAsync(p->h_counts, p->d_counts, (size_t)c.hyp * 4, hipMemcpyDeviceToHost, st));
-      VO_HIP_TRY(ctx, hipEventRecord(p->evB, st));
-      VO_HIP_TRY(ctx, hipEventSynchronize(p->evB));
+      const unsigned seq_b = ++p->seq;
+      hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, st, p->d_valid, p->d_counts, p->d_R, p->d_t,
+                         c.hyp, m_valid, m_counts, m_R, m_t, m_seq + 1, seq_b, (unsigned*)p->d_ntracked + 1);
+      VO_TRY(vo_check_launch(ctx, "mirror_hypotheses_kernel"));
+      VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
       int consumed = 0;
       const int32_t before = best_idx;
       VO_TRY(vo_ransac_replay(&p->rs, p->h_valid, p->h_counts, c.hyp, n, &n_done, &best_count, &best_idx,
@@ -391,11 +500,8 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
       if (best_idx != before) {
         // the winner so far lives in this batch: fetch its pose before the buffers are reused
         const int local = best_idx - batches * c.hyp;
-        VO_HIP_TRY(ctx, hipMemcpyAsync(p->h_pose, p->d_R + (size_t)local * 9, 72, hipMemcpyDeviceToHost, st));
-        VO_HIP_TRY(ctx, hipMemcpyAsync(p->h_pose + 9, p->d_t + (size_t)local * 3, 24, hipMemcpyDeviceToHost, st));
-        VO_HIP_TRY(ctx, hipStreamSynchronize(st));
-        memcpy(out->R, p->h_pose, 72);
-        memcpy(out->t, p->h_pose + 9, 24);
+        memcpy(out->R, p->h_R + (size_t)local * 9, 72);
+        memcpy(out->t, p->h_t + (size_t)local * 3, 24);
         p->last_best = local;
       } else if (batches > 0) {
         p->last_best = -1;   // winner's mask row was overwritten by a later batch
