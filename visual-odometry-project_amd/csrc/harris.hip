@@ -415,16 +415,28 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
   }
 }
 
-// Parallel rounds of the greedy rule, one workgroup per tile.  The tile's part of the
-// state map (tile + r halo) is staged in LDS and the tile iterates locally:
+// Parallel rounds of the greedy rule, one workgroup per tile.  Each iteration the tile
+//   0. re-reads its part of the global state map (tile + r halo) into LDS -- the map is only
+//      ever written with agent-scope stores, so selections and kills made by neighbouring
+//      tiles during this same launch become visible here without another launch;
 //   1. M = (2r+1)^2 window maximum of the state words (separable, dense over the tile);
-//   2. a live candidate whose word equals M has no live neighbour with a larger 32-bit
-//      view of the score; it scans its window once for equal words (settled by the full
-//      score and the index) and, if it still stands, is selected: own word := 1, every
-//      other word of its window := 0, in LDS and in the global map.
-// Halo words are a snapshot taken at kernel start; state only moves live -> selected |
-// dead, so a stale word can only postpone a decision to the next launch.
-constexpr int ROUND_ITERS = 12;
+//   2. a live candidate whose word equals M has no live neighbour with a larger 32-bit view
+//      of the score; one wave scans its window: a selected word in it means the candidate was
+//      killed (its cell is cleared); equal words are settled by the full score and the index;
+//      if it still stands it is selected: own word := 1, live words of its window := 0, in
+//      LDS and (agent scope) in the global map.
+// State only moves live -> selected | dead, so a word that is stale for an iteration only
+// postpones a decision.  A tile leaves when none of its candidates is live; tiles blocked on
+// a neighbour poll for a bounded number of iterations, what is left goes to the next launch
+// and finally to the sorted walk of nms_select_kernel.
+constexpr int ROUND_ITERS = 24;
+
+__device__ __forceinline__ unsigned load_state(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_state(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int R_T>
 __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict__ sc, unsigned* alive,
@@ -450,10 +462,17 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   if (n == 0 || seg_cnt[blk].w == 0) return;
   const int x0 = (int)(blk % (unsigned)tiles_x) * CX, y0 = (int)(blk / (unsigned)tiles_x) * CY;
   const size_t seg0 = (size_t)blk * SEG;
-  {
-    // all loads of the snapshot are issued before the first is stored
-    constexpr int PER = R_T > 0 ? ((CX + 2 * R_T) * (CY + 2 * R_T) + NT - 1) / NT : 1;
+  for (unsigned i = tid; i < n; i += NT) {
+    const unsigned idx = seg_cand[seg0 + i];
+    const int py = (int)(idx / (unsigned)W), px = (int)(idx - (unsigned)py * (unsigned)W);
+    s_cell[i] = (unsigned short)((py - y0 + r) * LW + (px - x0 + r));
+  }
+  if (tid == 0) s_nsel = 0;
+  __syncthreads();
+  for (int iter = 0; iter < ROUND_ITERS; ++iter) {
+    // ---- fresh copy of the tile's part of the state map ----
     if (R_T > 0) {
+      constexpr int PER = ((CX + 2 * R_T) * (CY + 2 * R_T) + NT - 1) / NT;
       unsigned v[PER];
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
         const int ly = i / LW, lx = i - ly * LW;
         const int gy = y0 - r + ly, gx = x0 - r + lx;
         const bool in = i < LW * LH && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        v[k] = in ? alive[(size_t)(in ? gy : 0) * W + (in ? gx : 0)] : 0u;
+        v[k] = in ? load_state(alive + (size_t)(in ? gy : 0) * W + (in ? gx : 0)) : 0u;
       }
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
@@ -473,19 +492,11 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
         const int ly = i / LW, lx = i - ly * LW;
         const int gy = y0 - r + ly, gx = x0 - r + lx;
         unsigned v = 0u;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = alive[(size_t)gy * W + gx];
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = load_state(alive + (size_t)gy * W + gx);
         s_state[i] = v;
       }
     }
-  }
-  for (unsigned i = tid; i < n; i += NT) {
-    const unsigned idx = seg_cand[seg0 + i];
-    const int py = (int)(idx / (unsigned)W), px = (int)(idx - (unsigned)py * (unsigned)W);
-    s_cell[i] = (unsigned short)((py - y0 + r) * LW + (px - x0 + r));
-  }
-  if (tid == 0) s_nsel = 0;
-  __syncthreads();
-  for (int iter = 0; iter < ROUND_ITERS; ++iter) {
+    __syncthreads();
     // ---- window maximum of the state words, rows then columns ----
     for (int it = tid; it < LH * (CX / 8); it += NT) {
       const int ly = it / (CX / 8), xs = (it - ly * (CX / 8)) * 8;
@@ -536,15 +547,18 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     // ---- candidates whose word tops their window ----
     if (tid == 0) s_npass = 0;
     __syncthreads();
+    unsigned live = 0;
     for (unsigned i = tid; i < n; i += NT) {
       const int cell = s_cell[i];
       const unsigned cp = s_state[cell];
       if (cp < 3u) continue;                                   // selected or dead
+      ++live;
       const int ly = cell / LW, lx = cell - ly * LW;
       if (s_m[(ly - r) * CX + (lx - r)] != cp) continue;       // a live neighbour has a larger word
       s_pass[atomicAdd(&s_npass, 1u)] = (unsigned short)cell;
     }
-    __syncthreads();
+    const int any_live = __syncthreads_or(live ? 1 : 0);
+    if (!any_live) break;                                      // nothing left to decide in this tile
     const unsigned npass = s_npass;
     // ---- one wave per passing candidate: lanes share the window ----
     // Equal words are settled by the full score, then the flat index (a total order, so of
@@ -558,18 +572,25 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
       if (cp < 3u) continue;                                   // killed by a tied winner meanwhile
       const int ly = cell / LW, lx = cell - ly * LW;
       const int py = y0 - r + ly, px = x0 - r + lx;
-      bool blocked = false;
+      bool blocked = false, killed = false;
       for (int t = lane; t < WN * WN; t += 64) {
         const int j = t / WN - r, d = t - (t / WN) * WN - r;
         if (j == 0 && d == 0) continue;
         const unsigned v = c[j * LW + d];
-        if (v == 1u) blocked = true;                           // a tied neighbour was selected first
+        if (v == 1u) killed = true;                            // a selected pixel owns this window
         if (v == cp) {
           const double s = sc[(size_t)py * W + px];
           const double q = sc[(size_t)(py + j) * W + (px + d)];
           const bool before = (j < 0) || (j == 0 && d < 0);
           if (before ? (q >= s) : (q > s)) blocked = true;
         }
+      }
+      if (__ballot(killed) != 0ull) {
+        if (lane == 0) {
+          *c = 0u;
+          store_state(alive + (size_t)py * W + px, 0u);
+        }
+        continue;
       }
       if (__ballot(blocked) != 0ull) continue;
       for (int t = lane; t < WN * WN; t += 64) {
@@ -578,18 +599,16 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
         unsigned* q = c + j * LW + d;
         if (*q >= 3u) {                                        // live words only (always inside the image)
           *q = 0u;
-          alive[(size_t)(py + j) * W + (px + d)] = 0u;
+          store_state(alive + (size_t)(py + j) * W + (px + d), 0u);
         }
       }
       if (lane == 0) {
         *c = 1u;
-        alive[(size_t)py * W + px] = 1u;
+        store_state(alive + (size_t)py * W + px, 1u);
         s_sel[atomicAdd(&s_nsel, 1u)] = (unsigned short)cell;   // flushed to the global list at the end
       }
     }
-    const bool progress = npass != 0;
-    const int any = __syncthreads_or(progress ? 1 : 0);
-    if (!any) break;
+    __syncthreads();   // LDS and global updates of this iteration are complete before the reload
   }
   // append this launch's selections to the global list: one atomic per tile
   __syncthreads();
@@ -694,7 +713,7 @@ __global__ __launch_bounds__(NT) void nms_rank_kernel(const unsigned long long* 
 constexpr int SEL_T = 1024;       // threads of the single-workgroup kernels
 constexpr int CHUNK = 8192;       // entries sorted in LDS at a time
 constexpr int MAX_N = 16384;      // keypoints
-constexpr int NMS_ROUNDS = 4;     // launches of the tile-local greedy rounds before the final stage
+constexpr int NMS_ROUNDS = 2;     // launches of the tile-local greedy rounds before the final stage
 
 __device__ __forceinline__ void write_keypoints(const unsigned* sel, unsigned nsel, unsigned edge, int W, int N,
                                                 double* __restrict__ kp_xy) {
