@@ -36,68 +36,131 @@
 
 namespace {
 
-constexpr int TX = 64;   // tile width  (outputs per workgroup row)
-constexpr int TY = 16;   // tile height
 constexpr int NT = 256;  // threads per workgroup
+constexpr int RX = 64;   // response tile width  (one lane per column)
+constexpr int RY = 32;   // response tile height (four strips of eight rows)
 
 // ---------------------------------------------------------------------------------
 // Harris response
 // ---------------------------------------------------------------------------------
+// One workgroup per 64x32 tile.  All sums are integers (exact in any order):
+//   A  image tile + halo -> LDS bytes          (all global loads issued before the first use)
+//   B  Sobel pair, four pixels per work item   (word reads, one 16-byte store)
+//   C  horizontal box sums of Ix^2, Iy^2, IxIy (one lane per column)
+//   D  vertical box sums as running sums down a strip of eight rows, then the fp64 formula
+// P_T > 0: patch size known at compile time; P_T == 0: runtime patch size, plain loops.
+struct resp_geom {
+  int pr, GW, GWp, GH, IWp, IH;
+};
+__host__ __device__ inline resp_geom response_geometry(int p) {
+  resp_geom g;
+  g.pr = p >> 1;
+  g.GW = RX + 2 * g.pr;
+  g.GWp = (g.GW + 3) & ~3;      // gradient row pitch: whole groups of four
+  g.GH = RY + 2 * g.pr;
+  g.IWp = g.GWp + 4;            // image bytes per row (GWp + 2 used), word multiple
+  g.IH = g.GH + 2;
+  return g;
+}
+
+template <int P_T>
 __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __restrict__ img, int H, int W,
-                                                             int p, double kappa,
+                                                             int p_arg, double kappa,
                                                              double* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int pr = p >> 1;
-  const int GW = TX + 2 * pr, GH = TY + 2 * pr;   // gradient region
-  const int IW = GW + 2, IH = GH + 2;             // image region
-  const int IWp = (IW + 3) & ~3;
+  const int p = P_T > 0 ? P_T : p_arg;
+  const resp_geom g = response_geometry(p);
+  const int pr = g.pr, GWp = g.GWp, GH = g.GH, IWp = g.IWp, IH = g.IH;
   uint8_t* s_img = smem;
-  int* s_g = reinterpret_cast<int*>(smem + ((IWp * IH + 15) & ~15));   // packed (Ix | Iy << 16)
-  int* s_hxx = s_g + GW * GH;
-  int* s_hyy = s_hxx + GH * TX;
-  int* s_hxy = s_hyy + GH * TX;
+  int* s_g = reinterpret_cast<int*>(smem + ((IWp * IH + 15) & ~15));   // packed (Ix | Iy << 16), GH x GWp
+  int* s_hxx = s_g + GWp * GH;                                         // GH x RX each
+  int* s_hyy = s_hxx + GH * RX;
+  int* s_hxy = s_hyy + GH * RX;
 
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int x0 = blockIdx.x * RX, y0 = blockIdx.y * RY;
   const int ix0 = x0 - pr - 1, iy0 = y0 - pr - 1;   // image coords of s_img[0][0]
 
   // A: image tile + halo (zeros outside the image; such pixels only feed outputs
   //    that the border rule forces to 0)
-  for (int i = tid; i < IWp * IH; i += NT) {
-    int ly = i / IWp, lx = i - ly * IWp;
-    int gy = iy0 + ly, gx = ix0 + lx;
-    uint8_t v = 0;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[(size_t)gy * W + gx];
-    s_img[i] = v;
+  if (P_T > 0) {
+    constexpr int PG = ((RX + 2 * (P_T >> 1) + 3) & ~3) + 4;
+    constexpr int PER = (PG * (RY + 2 * (P_T >> 1) + 2) + NT - 1) / NT;
+    uint8_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT;
+      const int ly = i / IWp, lx = i - ly * IWp;
+      const int gy = iy0 + ly, gx = ix0 + lx;
+      const bool in = i < IWp * IH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      v[k] = in ? img[(size_t)gy * W + gx] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT;
+      if (i < IWp * IH) s_img[i] = v[k];
+    }
+  } else {
+    for (int i = tid; i < IWp * IH; i += NT) {
+      const int ly = i / IWp, lx = i - ly * IWp;
+      const int gy = iy0 + ly, gx = ix0 + lx;
+      uint8_t v = 0;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[(size_t)gy * W + gx];
+      s_img[i] = v;
+    }
   }
   __syncthreads();
 
   // B: Sobel as a TRUE convolution (kernel flipped): left minus right, top minus bottom
-  for (int i = tid; i < GW * GH; i += NT) {
-    int ly = i / GW, lx = i - ly * GW;
-    const uint8_t* r0 = s_img + ly * IWp + lx;      // row above centre
-    const uint8_t* r1 = r0 + IWp;
-    const uint8_t* r2 = r1 + IWp;
-    int a00 = r0[0], a01 = r0[1], a02 = r0[2];
-    int a10 = r1[0], a12 = r1[2];
-    int a20 = r2[0], a21 = r2[1], a22 = r2[2];
-    int gx = (a00 - a02) + 2 * (a10 - a12) + (a20 - a22);
-    int gy = (a00 - a20) + 2 * (a01 - a21) + (a02 - a22);
-    s_g[i] = (gx & 0xffff) | (gy << 16);
+  const int groups = GWp >> 2;
+  for (int i = tid; i < GH * groups; i += NT) {
+    const int ly = i / groups, j = i - ly * groups;
+    const unsigned* r0 = reinterpret_cast<const unsigned*>(s_img + ly * IWp + 4 * j);   // row above centre
+    const unsigned* r1 = r0 + (IWp >> 2);
+    const unsigned* r2 = r1 + (IWp >> 2);
+    const unsigned long long a0 = r0[0] | ((unsigned long long)r0[1] << 32);
+    const unsigned long long a1 = r1[0] | ((unsigned long long)r1[1] << 32);
+    const unsigned long long a2 = r2[0] | ((unsigned long long)r2[1] << 32);
+    int o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int a00 = (int)((a0 >> (8 * k)) & 255), a01 = (int)((a0 >> (8 * k + 8)) & 255),
+                a02 = (int)((a0 >> (8 * k + 16)) & 255);
+      const int a10 = (int)((a1 >> (8 * k)) & 255), a12 = (int)((a1 >> (8 * k + 16)) & 255);
+      const int a20 = (int)((a2 >> (8 * k)) & 255), a21 = (int)((a2 >> (8 * k + 8)) & 255),
+                a22 = (int)((a2 >> (8 * k + 16)) & 255);
+      const int gx = (a00 - a02) + 2 * (a10 - a12) + (a20 - a22);
+      const int gy = (a00 - a20) + 2 * (a01 - a21) + (a02 - a22);
+      o[k] = (gx & 0xffff) | (gy << 16);
+    }
+    *reinterpret_cast<int4*>(s_g + ly * GWp + 4 * j) = make_int4(o[0], o[1], o[2], o[3]);
   }
   __syncthreads();
 
   // C: horizontal box sums of the three products
-  for (int i = tid; i < GH * TX; i += NT) {
-    int ly = i / TX, lx = i - ly * TX;
-    const int* g = s_g + ly * GW + lx;
+  for (int i = tid; i < GH * RX; i += NT) {
+    const int ly = i / RX, lx = i - ly * RX;
+    const int* gp = s_g + ly * GWp + lx;
     int sxx = 0, syy = 0, sxy = 0;
-    for (int k = 0; k < p; ++k) {
-      int v = g[k];
-      int gx = (int)(short)(v & 0xffff), gy = v >> 16;
-      sxx += gx * gx;
-      syy += gy * gy;
-      sxy += gx * gy;
+    if (P_T > 0) {
+      int v[P_T > 0 ? P_T : 1];
+#pragma unroll
+      for (int k = 0; k < P_T; ++k) v[k] = gp[k];
+#pragma unroll
+      for (int k = 0; k < P_T; ++k) {
+        const int gx = (int)(short)(v[k] & 0xffff), gy = v[k] >> 16;
+        sxx += gx * gx;
+        syy += gy * gy;
+        sxy += gx * gy;
+      }
+    } else {
+      for (int k = 0; k < p; ++k) {
+        const int v = gp[k];
+        const int gx = (int)(short)(v & 0xffff), gy = v >> 16;
+        sxx += gx * gx;
+        syy += gy * gy;
+        sxy += gx * gy;
+      }
     }
     s_hxx[i] = sxx;
     s_hyy[i] = syy;
@@ -106,27 +169,67 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
   __syncthreads();
 
   // D: vertical sums + response
-  const int lx = tid & (TX - 1);
+  const int lx = tid & (RX - 1);
   const int border = pr + 1;
-  for (int ly = tid / TX; ly < TY; ly += NT / TX) {
-    int gy = y0 + ly, gx = x0 + lx;
-    if (gy >= H || gx >= W) continue;
-    double r = 0.0;
-    if (gy >= border && gy < H - border && gx >= border && gx < W - border) {
-      int sxx = 0, syy = 0, sxy = 0;
-      for (int k = 0; k < p; ++k) {
-        int j = (ly + k) * TX + lx;
-        sxx += s_hxx[j];
-        syy += s_hyy[j];
-        sxy += s_hxy[j];
-      }
-      double dxx = (double)sxx, dyy = (double)syy, dxy = (double)sxy;
-      double trace = dxx + dyy;
-      double det = dxx * dyy - dxy * dxy;
-      r = det - kappa * (trace * trace);
-      if (r < 0) r = 0;
+  const int gx = x0 + lx;
+  if (P_T > 0) {
+    const int ys = (tid / RX) * 8;                 // strip of eight output rows
+    int vxx[8 + P_T - 1], vyy[8 + P_T - 1], vxy[8 + P_T - 1];
+#pragma unroll
+    for (int k = 0; k < 8 + P_T - 1; ++k) {
+      const int j = (ys + k) * RX + lx;
+      vxx[k] = s_hxx[j];
+      vyy[k] = s_hyy[j];
+      vxy[k] = s_hxy[j];
     }
-    out[(size_t)gy * W + gx] = r;
+    int sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+    for (int k = 0; k < P_T; ++k) {
+      sxx += vxx[k];
+      syy += vyy[k];
+      sxy += vxy[k];
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int gy = y0 + ys + o;
+      if (gy < H && gx < W) {
+        double r = 0.0;
+        if (gy >= border && gy < H - border && gx >= border && gx < W - border) {
+          const double dxx = (double)sxx, dyy = (double)syy, dxy = (double)sxy;
+          const double trace = dxx + dyy;
+          const double det = dxx * dyy - dxy * dxy;
+          r = det - kappa * (trace * trace);
+          if (r < 0) r = 0;
+        }
+        out[(size_t)gy * W + gx] = r;
+      }
+      if (o < 7) {
+        sxx += vxx[o + P_T] - vxx[o];
+        syy += vyy[o + P_T] - vyy[o];
+        sxy += vxy[o + P_T] - vxy[o];
+      }
+    }
+  } else {
+    for (int ly = tid / RX; ly < RY; ly += NT / RX) {
+      const int gy = y0 + ly;
+      if (gy >= H || gx >= W) continue;
+      double r = 0.0;
+      if (gy >= border && gy < H - border && gx >= border && gx < W - border) {
+        int sxx = 0, syy = 0, sxy = 0;
+        for (int k = 0; k < p; ++k) {
+          const int j = (ly + k) * RX + lx;
+          sxx += s_hxx[j];
+          syy += s_hyy[j];
+          sxy += s_hxy[j];
+        }
+        const double dxx = (double)sxx, dyy = (double)syy, dxy = (double)sxy;
+        const double trace = dxx + dyy;
+        const double det = dxx * dyy - dxy * dxy;
+        r = det - kappa * (trace * trace);
+        if (r < 0) r = 0;
+      }
+      out[(size_t)gy * W + gx] = r;
+    }
   }
 }
 
@@ -165,6 +268,21 @@ __device__ __forceinline__ unsigned wave_slot(bool take, unsigned* counter) {
   return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// 32-bit view of a score for the window maxima: 0 for scores that are not positive, else the
+// top half of the double (monotone; equal words are settled on the full values).
+__device__ __forceinline__ unsigned score_word(double v) {
+  const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(v) >> 32);
+  return v > 0.0 ? (hi ? hi : 1u) : 0u;
+}
+
+// One workgroup per 64x32 tile; L1 flags are needed on the tile + r halo, hence scores on
+// the tile + 2r halo.
+//   A  score words of the region -> LDS          (all global loads issued before the first use)
+//   B  column maxima, running down strips of eight rows (one lane per column)
+//   C  row maxima of those = window maxima; a pixel whose word equals it is a "qualifier"
+//   D  one wave per qualifier: neighbours with the same word are compared on the full score
+//      and, for equal scores, on flat order -> L1 bit rows
+//   E  tile pixels: L1 -> segment 0 (+ histogram); positive and not within r of any L1 -> segment 1
 // R_T > 0: radius known at compile time (window loops unroll); R_T == 0: runtime radius.
 template <int R_T>
 __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __restrict__ sc, int H, int W, int r_arg,
@@ -179,75 +297,129 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
   const int RW = CX + 4 * r, RH = CY + 4 * r;   // score region (2r halo)
   const int LW = CX + 2 * r, LH = CY + 2 * r;   // region where L1 flags are needed
   const int WN = 2 * r + 1;
-  double* s_sc = reinterpret_cast<double*>(smem);
-  double* s_rm = s_sc + RW * RH;                // row maxima, RH x LW
-  unsigned* s_mask = reinterpret_cast<unsigned*>(s_rm + RH * LW);   // LH rows x 4 words (LW <= 128 bits)
-  unsigned* s_comb = s_mask + LH * 4;                               // CY rows x 4 words
-  __shared__ unsigned s_cnt[2];
+  unsigned* s_w = reinterpret_cast<unsigned*>(smem);   // RH x RW score words
+  unsigned* s_cm = s_w + RW * RH;                      // LH x RW column maxima
+  unsigned* s_mask = s_cm + RW * LH;                   // LH rows x 4 words (LW <= 128 bits)
+  unsigned* s_comb = s_mask + LH * 4;                  // CY rows x 4 words
+  unsigned short* s_list = reinterpret_cast<unsigned short*>(s_comb + CY * 4);   // qualifiers (L cells)
+  __shared__ unsigned s_cnt[3];
 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * CX, y0 = blockIdx.y * CY;
   const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
-  if (tid < 2) s_cnt[tid] = 0;
+  if (tid < 3) s_cnt[tid] = 0;
 
-  for (int i = tid; i < RW * RH; i += NT) {
-    const int ly = i / RW, lx = i - ly * RW;
-    const int gy = y0 - 2 * r + ly, gx = x0 - 2 * r + lx;
-    double v = 0.0;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = sc[(size_t)gy * W + gx];
-    s_sc[i] = v;
+  // the tile's own scores stay in registers for step E
+  const int lx = tid & (CX - 1);
+  double own[SEG / NT];
+#pragma unroll
+  for (int k = 0; k < SEG / NT; ++k) {
+    const int gy = y0 + tid / CX + k * (NT / CX), gx = x0 + lx;
+    const bool in = gy < H && gx < W;
+    own[k] = in ? sc[(size_t)(in ? gy : 0) * W + (in ? gx : 0)] : 0.0;
+  }
+  // A
+  if (R_T > 0) {
+    constexpr int PER = ((CX + 4 * R_T) * (CY + 4 * R_T) + NT - 1) / NT;
+    double v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT;
+      const int ly = i / RW, lxx = i - ly * RW;
+      const int gy = y0 - 2 * r + ly, gx = x0 - 2 * r + lxx;
+      const bool in = i < RW * RH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      v[k] = in ? sc[(size_t)(in ? gy : 0) * W + (in ? gx : 0)] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT;
+      if (i < RW * RH) s_w[i] = score_word(v[k]);
+    }
+  } else {
+    for (int i = tid; i < RW * RH; i += NT) {
+      const int ly = i / RW, lxx = i - ly * RW;
+      const int gy = y0 - 2 * r + ly, gx = x0 - 2 * r + lxx;
+      double v = 0.0;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = sc[(size_t)gy * W + gx];
+      s_w[i] = score_word(v);
+    }
   }
   for (int i = tid; i < LH * 4; i += NT) s_mask[i] = 0;
   __syncthreads();
 
-  // separable window maximum: rows, then columns (no data-dependent branches)
-  for (int i = tid; i < RH * LW; i += NT) {
-    const int ly = i / LW, lx = i - ly * LW;
-    const double* row = s_sc + ly * RW + lx;
-    double m = row[0];
+  // B: s_cm[ly][x] = max of s_w[ly .. ly + 2r][x]
+  if (R_T > 0) {
+    const int strips = (LH + 7) / 8;
+    for (int it = tid; it < RW * strips; it += NT) {
+      const int st = it / RW, x = it - st * RW;
+      const int ys = st * 8;
+      unsigned v[8 + 2 * R_T];
 #pragma unroll
-    for (int d = 1; d < (R_T > 0 ? 2 * R_T + 1 : 1); ++d) m = fmax(m, row[d]);
-    if (R_T == 0)
-      for (int d = 1; d < WN; ++d) m = fmax(m, row[d]);
-    s_rm[i] = m;
-  }
-  __syncthreads();
-  for (int i = tid; i < LW * LH; i += NT) {
-    const int ly = i / LW, lx = i - ly * LW;
-    const double* col = s_rm + ly * LW + lx;
-    double m = col[0];
+      for (int k = 0; k < 8 + 2 * R_T; ++k) v[k] = ys + k < RH ? s_w[(ys + k) * RW + x] : 0u;
 #pragma unroll
-    for (int d = 1; d < (R_T > 0 ? 2 * R_T + 1 : 1); ++d) m = fmax(m, col[d * LW]);
-    if (R_T == 0)
-      for (int d = 1; d < WN; ++d) m = fmax(m, col[d * LW]);
-    const double* c = s_sc + (ly + r) * RW + (lx + r);
-    const double sv = *c;
-    bool is = sv > 0.0 && sv == m;
-    if (is) {
-      // window maximum by value: it loses only to an equal score earlier in flat order.
-      // All window loads are issued before any is tested (no dependent-load chain).
-      if (R_T > 0) {
-        bool tie = false;
+      for (int o = 0; o < 8; ++o) {
+        unsigned m = v[o];
 #pragma unroll
-        for (int dy = -R_T; dy <= 0; ++dy) {
-#pragma unroll
-          for (int dx = -R_T; dx <= R_T; ++dx)
-            if (dy < 0 || dx < 0) tie |= (c[dy * RW + dx] == sv);
-        }
-        is = !tie;
-      } else {
-        for (int dy = -r; dy <= 0 && is; ++dy) {
-          const double* rowp = c + dy * RW;
-          const int dx_end = dy < 0 ? r : -1;
-          for (int dx = -r; dx <= dx_end; ++dx)
-            if (rowp[dx] == sv) {
-              is = false;
-              break;
-            }
-        }
+        for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
+        if (ys + o < LH) s_cm[(ys + o) * RW + x] = m;
       }
     }
-    if (is) atomicOr(&s_mask[ly * 4 + (lx >> 5)], 1u << (lx & 31));
+  } else {
+    for (int i = tid; i < RW * LH; i += NT) {
+      const int ly = i / RW, x = i - ly * RW;
+      const unsigned* col = s_w + ly * RW + x;
+      unsigned m = col[0];
+      for (int d = 1; d < WN; ++d) m = max(m, col[d * RW]);
+      s_cm[i] = m;
+    }
+  }
+  __syncthreads();
+
+  // C: window maximum = max of s_cm[ly][lx .. lx + 2r]
+  for (int b0 = 0; b0 < LW * LH; b0 += NT) {
+    const int i = b0 + tid;
+    bool q = false;
+    if (i < LW * LH) {
+      const int ly = i / LW, lxx = i - ly * LW;
+      const unsigned* row = s_cm + ly * RW + lxx;
+      unsigned m = row[0];
+      if (R_T > 0) {
+#pragma unroll
+        for (int d = 1; d <= 2 * R_T; ++d) m = max(m, row[d]);
+      } else {
+        for (int d = 1; d < WN; ++d) m = max(m, row[d]);
+      }
+      const unsigned cw = s_w[(ly + r) * RW + (lxx + r)];
+      q = cw != 0u && cw == m;
+    }
+    const unsigned slot = wave_slot(q, &s_cnt[2]);
+    if (q) s_list[slot] = (unsigned short)i;
+  }
+  __syncthreads();
+
+  // D: one wave per qualifier
+  {
+    const unsigned nq = s_cnt[2];
+    const int lane = tid & 63;
+    for (unsigned k = tid >> 6; k < nq; k += NT / 64) {
+      const int cell = s_list[k];
+      const int ly = cell / LW, lxx = cell - ly * LW;
+      const unsigned* c = s_w + (ly + r) * RW + (lxx + r);
+      const unsigned cw = *c;
+      const int py = y0 - r + ly, px = x0 - r + lxx;     // inside the image: its word is not 0
+      bool beaten = false;
+      for (int t = lane; t < WN * WN; t += 64) {
+        const int j = t / WN - r, d = t - (t / WN) * WN - r;
+        if (j == 0 && d == 0) continue;
+        if (c[j * RW + d] == cw) {
+          const double s = sc[(size_t)py * W + px];
+          const double q = sc[(size_t)(py + j) * W + (px + d)];
+          const bool before = (j < 0) || (j == 0 && d < 0);
+          if (before ? (q >= s) : (q > s)) beaten = true;
+        }
+      }
+      if (__ballot(beaten) == 0ull && lane == 0) atomicOr(&s_mask[ly * 4 + (lxx >> 5)], 1u << (lxx & 31));
+    }
   }
   __syncthreads();
 
@@ -260,29 +432,25 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
   }
   __syncthreads();
 
-  // classify the tile's own pixels and append them to the tile's segments
-  const int lx = tid & (CX - 1);
+  // E: classify the tile's own pixels and append them to the tile's segments
   const size_t seg0 = (size_t)blk * SEG;
 #pragma unroll
   for (int k = 0; k < SEG / NT; ++k) {
     const int ly = tid / CX + k * (NT / CX);
     const int gy = y0 + ly, gx = x0 + lx;
     int kind = -1;
-    double sv = 0.0;
-    if (gy < H && gx < W) {
-      sv = s_sc[(ly + 2 * r) * RW + (lx + 2 * r)];
-      if (sv > 0.0) {
-        const int bx = lx + r;                                   // own bit in the L row
-        const bool own = (s_mask[(ly + r) * 4 + (bx >> 5)] >> (bx & 31)) & 1u;
-        // any L1 bit in columns lx .. lx + 2r of the combined row?
-        const unsigned* cw = s_comb + ly * 4;
-        const unsigned long long lo = cw[0] | ((unsigned long long)cw[1] << 32);
-        const unsigned long long hi = cw[2] | ((unsigned long long)cw[3] << 32);
-        const unsigned long long win = lx == 0 ? lo : ((lo >> lx) | (hi << (64 - lx)));
-        const bool covered = (win & ((1ull << WN) - 1ull)) != 0ull;
-        if (own) kind = 0;
-        else if (!covered) kind = 1;
-      }
+    const double sv = own[k];
+    if (gy < H && gx < W && sv > 0.0) {
+      const int bx = lx + r;                                   // own bit in the L row
+      const bool is_l1 = (s_mask[(ly + r) * 4 + (bx >> 5)] >> (bx & 31)) & 1u;
+      // any L1 bit in columns lx .. lx + 2r of the combined row?
+      const unsigned* cw = s_comb + ly * 4;
+      const unsigned long long lo = cw[0] | ((unsigned long long)cw[1] << 32);
+      const unsigned long long hi = cw[2] | ((unsigned long long)cw[3] << 32);
+      const unsigned long long win = lx == 0 ? lo : ((lo >> lx) | (hi << (64 - lx)));
+      const bool covered = (win & ((1ull << WN) - 1ull)) != 0ull;
+      if (is_l1) kind = 0;
+      else if (!covered) kind = 1;
     }
     const unsigned long long key = (unsigned long long)__double_as_longlong(sv);
     const unsigned idx = (unsigned)gy * (unsigned)W + (unsigned)gx;
@@ -999,17 +1167,14 @@ __global__ __launch_bounds__(NT) void patch_desc_kernel(const uint8_t* __restric
 }
 
 size_t response_lds_bytes(int p) {
-  int pr = p >> 1;
-  int GW = TX + 2 * pr, GH = TY + 2 * pr;
-  int IW = GW + 2, IH = GH + 2;
-  int IWp = (IW + 3) & ~3;
-  return (size_t)((IWp * IH + 15) & ~15) + (size_t)GW * GH * 4 + (size_t)3 * GH * TX * 4;
+  const resp_geom g = response_geometry(p);
+  return (size_t)((g.IWp * g.IH + 15) & ~15) + (size_t)g.GWp * g.GH * 4 + (size_t)3 * g.GH * RX * 4;
 }
 
 size_t candidates_lds_bytes(int r) {
   const int RW = CX + 4 * r, RH = CY + 4 * r;
   const int LW = CX + 2 * r, LH = CY + 2 * r;
-  return (size_t)RW * RH * 8 + (size_t)RH * LW * 8 + (size_t)LH * 16 + (size_t)CY * 16;
+  return (size_t)RW * RH * 4 + (size_t)RW * LH * 4 + (size_t)LH * 16 + (size_t)CY * 16 + (size_t)LW * LH * 2;
 }
 
 unsigned next_pow2(unsigned v) {
@@ -1029,12 +1194,22 @@ int vo_harris_response_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int 
   VO_REQUIRE(ctx, H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "harris_response: bad image size %dx%d", W, H);
   VO_REQUIRE(ctx, patch >= 3 && patch <= 31 && (patch & 1), "harris_response: patch must be odd in 3..31");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dim3 grid(vo_cdiv(W, TX), vo_cdiv(H, TY));
+  dim3 grid(vo_cdiv(W, RX), vo_cdiv(H, RY));
   size_t lds = response_lds_bytes(patch);
   {
+    static bool lds_opt_in = false;   // dynamic LDS above 64 KiB must be requested per kernel
+    if (!lds_opt_in) {
+      VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&harris_response_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+      lds_opt_in = true;
+    }
     vo_prof_scope ps(ctx, VO_K_HARRIS_RESPONSE);
-    hipLaunchKernelGGL(harris_response_kernel, grid, dim3(NT), lds, ctx->stream, d_img, H, W, patch, kappa,
-                       d_scores);
+    if (patch == 9)
+      hipLaunchKernelGGL(harris_response_kernel<9>, grid, dim3(NT), lds, ctx->stream, d_img, H, W, patch, kappa,
+                         d_scores);
+    else
+      hipLaunchKernelGGL(harris_response_kernel<0>, grid, dim3(NT), lds, ctx->stream, d_img, H, W, patch, kappa,
+                         d_scores);
   }
   return vo_check_launch(ctx, "harris_response_kernel");
 }
