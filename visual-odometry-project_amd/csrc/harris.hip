@@ -884,7 +884,7 @@ constexpr int MAX_N = 16384;      // keypoints
 constexpr int NMS_ROUNDS = 2;     // launches of the tile-local greedy rounds before the final stage
 
 __device__ __forceinline__ void write_keypoints(const unsigned* sel, unsigned nsel, unsigned edge, int W, int N,
-                                                double* __restrict__ kp_xy) {
+                                                double* __restrict__ kp_xy, float* __restrict__ kp_f32) {
   // reference slicing corner cases: a pick with y < r or x < r suppresses nothing and is
   // returned for every later slot; once the scores are exhausted the picks are (0, 0)
   for (unsigned i = threadIdx.x; i < (unsigned)N; i += SEL_T) {
@@ -899,12 +899,17 @@ __device__ __forceinline__ void write_keypoints(const unsigned* sel, unsigned ns
     }
     kp_xy[2 * i] = x;
     kp_xy[2 * i + 1] = y;
+    if (kp_f32) {   // the same points as float pairs, the form the KLT tracker takes
+      kp_f32[2 * i] = (float)x;
+      kp_f32[2 * i + 1] = (float)y;
+    }
   }
 }
 
 __global__ __launch_bounds__(SEL_T) void nms_emit_kernel(const unsigned* __restrict__ idx_c, nms_ctl* ctl,
                                                          unsigned* __restrict__ rank, int W, int N, int r,
-                                                         unsigned* sel, double* __restrict__ kp_xy) {
+                                                         unsigned* sel, double* __restrict__ kp_xy,
+                                                         float* __restrict__ kp_f32) {
   __shared__ unsigned s_edge;
   const unsigned M = ctl->n_c;
   if (ctl->n_rem != 0 || M > (unsigned)RANK_MAX) return;
@@ -923,7 +928,7 @@ __global__ __launch_bounds__(SEL_T) void nms_emit_kernel(const unsigned* __restr
   __threadfence_block();
   __syncthreads();
   const unsigned nsel = min(M, (unsigned)N);
-  write_keypoints(sel, nsel, s_edge, W, N, kp_xy);
+  write_keypoints(sel, nsel, s_edge, W, N, kp_xy, kp_f32);
   if (threadIdx.x == 0) ctl->n_sel = nsel;
 }
 
@@ -956,7 +961,8 @@ __global__ __launch_bounds__(SEL_T) void nms_select_kernel(unsigned long long* _
                                                            unsigned* __restrict__ idx_c, nms_ctl* ctl,
                                                            unsigned cap_pow2, int W, int N, int r,
                                                            unsigned* __restrict__ sel,
-                                                           double* __restrict__ kp_xy) {
+                                                           double* __restrict__ kp_xy,
+                                                           float* __restrict__ kp_f32) {
   __shared__ __align__(16) unsigned long long s_keys[CHUNK];   // 64 KiB
   __shared__ __align__(16) unsigned s_idx[CHUNK];              // 32 KiB
   __shared__ unsigned s_wsum[SEL_T / 64];
@@ -1143,7 +1149,7 @@ __global__ __launch_bounds__(SEL_T) void nms_select_kernel(unsigned long long* _
   __syncthreads();
 
   const unsigned nsel = min(s_nsel, (unsigned)N);
-  write_keypoints(sel, nsel, s_edge, W, N, kp_xy);
+  write_keypoints(sel, nsel, s_edge, W, N, kp_xy, kp_f32);
   if (tid == 0) ctl->n_sel = nsel;
 }
 
@@ -1324,14 +1330,14 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   {
     vo_prof_scope ps(ctx, VO_K_NMS_EMIT);
     hipLaunchKernelGGL(nms_emit_kernel, dim3(1), dim3(SEL_T), 0, st, idx_c, ctl, rank, W, N, r,
-                       (unsigned*)ctx->nms_sel.p, d_kp_xy);
+                       (unsigned*)ctx->nms_sel.p, d_kp_xy, ctx->nms_kp_f32);
   }
   VO_TRY(vo_check_launch(ctx, "nms_emit_kernel"));
   {
     // general case (exits at once when the rank path applied): sort + sequential walk
     vo_prof_scope ps(ctx, VO_K_NMS_SELECT);
     hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_T), 0, st, keys_c, idx_c, ctl, cap_c, W, N, r,
-                       (unsigned*)ctx->nms_sel.p, d_kp_xy);
+                       (unsigned*)ctx->nms_sel.p, d_kp_xy, ctx->nms_kp_f32);
   }
   return vo_check_launch(ctx, "nms_select_kernel");
 }

@@ -32,12 +32,11 @@ struct vo_pipeline {
   int cur = 0;                       // buffer index holding `prev`'s pyramid / keypoints
   int prev_frame = -1;
   double* d_scores = nullptr;
-  float *d_prev_f32 = nullptr, *d_next_f32 = nullptr, *d_err = nullptr;
+  float *d_kp_f32[2] = {nullptr, nullptr}, *d_next_f32 = nullptr, *d_err = nullptr;   // d_kp as float pairs
   uint8_t* d_status = nullptr;
   double *d_prev_c = nullptr, *d_next_c = nullptr, *d_land_c = nullptr, *d_tri = nullptr;
   int32_t* d_ntracked = nullptr;
-  int32_t* d_samples = nullptr;
-  double *d_R = nullptr, *d_t = nullptr, *d_C = nullptr;
+  double *d_R = nullptr, *d_t = nullptr;
   uint8_t* d_valid = nullptr;
   int32_t* d_counts = nullptr;
   uint64_t* d_masks = nullptr;
@@ -61,11 +60,6 @@ struct vo_pipeline {
 };
 
 namespace {
-
-__global__ __launch_bounds__(256) void kp_to_f32_kernel(const double* __restrict__ kp, int n, float* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * n) out[i] = (float)kp[i];
-}
 
 // Keeps tracks with status != 0 and err < thr in their original order (the boolean
 // mask of klt.py:244-269), converts to float64 and looks the landmark of each
@@ -252,7 +246,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   }
   PA(dev_alloc(ctx, &p->d_scores, px));
   PA(dev_alloc(ctx, &p->d_det_img, px));
-  PA(dev_alloc(ctx, &p->d_prev_f32, (size_t)N * 2));
+  PA(dev_alloc(ctx, &p->d_kp_f32[0], (size_t)N * 2));
+  PA(dev_alloc(ctx, &p->d_kp_f32[1], (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_next_f32, (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_err, (size_t)N));
   PA(dev_alloc(ctx, &p->d_status, (size_t)N));
@@ -261,10 +256,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_land_c, (size_t)N * 3));
   PA(dev_alloc(ctx, &p->d_tri, (size_t)N * 3));
   PA(dev_alloc(ctx, &p->d_ntracked, 4));
-  PA(dev_alloc(ctx, &p->d_samples, (size_t)Hyp * 4));
   PA(dev_alloc(ctx, &p->d_R, (size_t)Hyp * 9));
   PA(dev_alloc(ctx, &p->d_t, (size_t)Hyp * 3));
-  PA(dev_alloc(ctx, &p->d_C, 24));
   PA(dev_alloc(ctx, &p->d_valid, (size_t)Hyp));
   PA(dev_alloc(ctx, &p->d_counts, (size_t)Hyp));
   PA(dev_alloc(ctx, &p->d_masks, (size_t)Hyp * vo_cdiv(N, 64)));
@@ -316,9 +309,9 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   for (auto q : p->d_depth) (void)hipFree(q);
   for (int k = 0; k < 2; ++k)
     if (p->det_graph[k]) (void)hipGraphExecDestroy(p->det_graph[k]);
-  void* dev[] = {p->d_det_img, p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_prev_f32,
+  void* dev[] = {p->d_det_img, p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_kp_f32[0], p->d_kp_f32[1],
                  p->d_next_f32, p->d_err, p->d_status, p->d_prev_c, p->d_next_c, p->d_land_c, p->d_tri,
-                 p->d_ntracked, p->d_samples, p->d_R, p->d_t, p->d_C, p->d_valid, p->d_counts, p->d_masks};
+                 p->d_ntracked, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks};
   for (void* q : dev)
     if (q) (void)hipFree(q);
   void* pin[] = {p->h_ntracked, p->h_samples, p->h_valid, p->h_counts, p->h_pose, p->h_C, p->h_R, p->h_t, (void*)p->h_seq};
@@ -358,6 +351,7 @@ int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
 // plain launch path is kept for the first call (allocations) and for per-kernel profiling.
 static int detect_launches(vo_pipeline* p, double* d_kp) {
   const vo_pipeline_config& c = p->cfg;
+  p->det->nms_kp_f32 = p->d_kp_f32[d_kp == p->d_kp[0] ? 0 : 1];   // the tracker's float copy of the keypoints
   int rc = vo_harris_response_dev(p->det, p->d_det_img, c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
   if (rc == VO_OK) rc = vo_nms_keypoints_dev(p->det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, d_kp);
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->det));
@@ -436,23 +430,24 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
 
   // ---- tracking ----
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
-  hipLaunchKernelGGL(kp_to_f32_kernel, dim3(vo_cdiv(2 * N, 256)), dim3(256), 0, st, p->d_kp[a], N, p->d_prev_f32);
-  VO_TRY(vo_check_launch(ctx, "kp_to_f32_kernel"));
   VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
-                          p->n_levels, p->d_prev_f32, N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
+                          p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
   // device-side aliases of the mapped host buffers the kernels publish into
   int32_t* m_ntracked = nullptr;
   unsigned* m_seq = nullptr;
   uint8_t* m_valid = nullptr;
   int32_t* m_counts = nullptr;
-  double *m_R = nullptr, *m_t = nullptr;
+  double *m_R = nullptr, *m_t = nullptr, *m_C = nullptr;
+  int32_t* m_samples = nullptr;
   VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_ntracked, p->h_ntracked, 0));
   VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_seq, (void*)p->h_seq, 0));
   VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_valid, p->h_valid, 0));
   VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_counts, p->h_counts, 0));
   VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_R, p->h_R, 0));
   VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_t, p->h_t, 0));
+  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_C, p->h_C, 0));
+  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_samples, p->h_samples, 0));
   const unsigned seq_a = ++p->seq;
   {
     vo_prof_scope ps(ctx, VO_K_GATHER);
@@ -482,9 +477,9 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     int32_t best_count = -1, best_idx = -1;
     int total_consumed = 0, finished = 0, batches = 0, hyp_valid = 0;
     while (!finished) {
+      // the sample indices are read by the solve kernel straight from mapped host memory
       VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, p->h_samples));
-      VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_samples, p->h_samples, (size_t)c.hyp * 16, hipMemcpyHostToDevice, st));
-      VO_TRY(vo_p3p_hypotheses_dev(ctx, p->d_land_c, p->d_next_c, n, c.K, p->d_samples, c.hyp, c.p3p_thr_sq, p->d_R,
+      VO_TRY(vo_p3p_hypotheses_dev(ctx, p->d_land_c, p->d_next_c, n, c.K, m_samples, c.hyp, c.p3p_thr_sq, p->d_R,
                                    p->d_t, p->d_valid, p->d_counts, p->d_masks));
       const unsigned seq_b = ++p->seq;
       hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, st, p->d_valid, p->d_counts, p->d_R, p->d_t,
@@ -532,11 +527,17 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
         Rt[4 * r + 3] = out->t[r];
       }
       k_times_rt(c.K, Rt, p->h_C + 12);
-      VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_C, p->h_C, 192, hipMemcpyHostToDevice, st));
-      VO_TRY(vo_triangulate_dlt_dev(ctx, p->d_prev_c, p->d_next_c, n, p->d_C, 0, p->d_C + 12, p->d_tri));
+      // Off the tracking stream: the inputs are complete (the host has seen the gather's
+      // sequence word), the result is only read after detect_join(), and the cameras are read
+      // from mapped host memory, rewritten no earlier than the next step's RANSAC.
+      p->det->prof_on = ctx->prof_on;
+      p->det->prof_kernel = ctx->prof_kernel;
+      const int rc = vo_triangulate_dlt_dev(p->det, p->d_prev_c, p->d_next_c, n, m_C, 0, m_C + 12, p->d_tri);
+      if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->det));
+      VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, p->det->stream));
     }
   }
-  VO_TRY(detect_join(p));   // the next step (and any fetch) sees the new keypoints
+  VO_TRY(detect_join(p));   // the next step (and any fetch) sees the new keypoints and landmarks
   p->cur = b;
   p->prev_frame = next_idx;
   return VO_OK;

@@ -113,6 +113,31 @@ void choice_floyd(pcg& g, int64_t pop, int s, int64_t* out, uint64_t* hash, uint
   }
 }
 
+// The same draws for small s: the hash set only answers "was this value drawn before", which
+// for a handful of values is a few compares; the output is identical.
+template <int S>
+inline void choice_small(pcg& g, uint32_t pop, int32_t* out) {
+  int32_t v[S];
+#pragma unroll
+  for (int k = 0; k < S; ++k) {
+    const uint32_t j = pop - S + k;
+    const uint32_t val = (uint32_t)g.bounded(j);
+    bool seen = false;
+#pragma unroll
+    for (int q = 0; q < k; ++q) seen |= (v[q] == (int32_t)val);
+    v[k] = seen ? (int32_t)j : (int32_t)val;
+  }
+#pragma unroll
+  for (int i = S - 1; i >= 1; --i) {
+    const int j = (int)g.bounded((uint64_t)i);
+    const int32_t tmp = v[j];
+    v[j] = v[i];
+    v[i] = tmp;
+  }
+#pragma unroll
+  for (int k = 0; k < S; ++k) out[k] = v[k];
+}
+
 int64_t n_iterations_for(double confidence, double outlier_ratio, int s) {
   // ransac.py:64-67: int(np.ceil(np.log(1 - conf) / np.log(1 - (1 - outlier_ratio) ** s)))
   const double k = std::ceil(std::log(1.0 - confidence) / std::log(1.0 - std::pow(1.0 - outlier_ratio, (double)s)));
@@ -138,6 +163,11 @@ int vo_rng_choice(vo_pcg64* rng, int pop, int s, int count, int32_t* out) {
   uint64_t hash[128];
   int64_t idx[64];
   pcg g = load(rng);
+  if (s == 4 && pop >= 8) {
+    for (int c = 0; c < count; ++c) choice_small<4>(g, (uint32_t)pop, out + (size_t)c * 4);
+    store(g, rng);
+    return VO_OK;
+  }
   for (int c = 0; c < count; ++c) {
     choice_floyd(g, pop, s, idx, hash, mask);
     for (int k = 0; k < s; ++k) out[(size_t)c * s + k] = (int32_t)idx[k];
