@@ -41,9 +41,17 @@ def oracle_step(stream, prev, nxt, kp_prev, rs, cfg):
                 draws=len(rs.trace) - n0, iters=rs.iterations_done)
 
 
+@pytest.mark.parametrize("sampler", ["device", "sequential"])
 @pytest.mark.parametrize("H,W,N,hyp", [(240, 320, 300, 256), (480, 640, 500, 1000)])
-def test_pipeline_matches_oracle_composition(ctx, H, W, N, hyp):
+def test_pipeline_matches_oracle_composition(ctx, H, W, N, hyp, sampler, monkeypatch):
+    """sampler = "device": sample indices derived in the solve kernel from raw generator outputs;
+    "sequential": the host sampler the pipeline falls back to when a draw may have been rejected
+    (VO_SEQ_SAMPLER forces it).  Both must reproduce the reference's sample stream."""
     from vo import _native, synthetic
+    if sampler == "sequential":
+        monkeypatch.setenv("VO_SEQ_SAMPLER", "1")
+    else:
+        monkeypatch.delenv("VO_SEQ_SAMPLER", raising=False)
     F = 4
     stream = synthetic.Stream(F, H, W)
     cfg = dict(win=15, lvl=2, N=N)

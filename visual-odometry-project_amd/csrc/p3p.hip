@@ -147,15 +147,77 @@ __device__ __forceinline__ double reproj_sq(const double* R, const double* t, do
   return nrm * nrm;
 }
 
+// NumPy's bounded draw on one 32-bit output of the generator (Lemire, ransac_host.hip):
+// `risky` is raised when the draw could have been rejected, i.e. when the sequential
+// generator might have consumed one more output than this position-based view assumes.
+__device__ __forceinline__ unsigned bounded_from_raw(unsigned raw, unsigned rng, bool& risky) {
+  const unsigned rex = rng + 1u;
+  const unsigned long long m = (unsigned long long)raw * rex;
+  if ((unsigned)m < rex) risky = true;
+  return (unsigned)(m >> 32);
+}
+
+// RAW == false: sample indices are given.
+// RAW == true : hypothesis h derives its sample from generator outputs raws[7h .. 7h+6] and the
+//   population size *d_n, both of which may still be in flight when the kernel is enqueued:
+//   Generator.choice(n, 4, replace=False) is four bounded draws (Floyd) and three for the
+//   shuffle, so without rejections sample h sits at a fixed offset of the stream.  Any possible
+//   rejection (or n < 8, where the draw count changes) sets *flag and the host redoes the batch
+//   with the sequential sampler.
+template <bool RAW>
 __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
-                                                       const int* __restrict__ samples, int Hyp, double fx,
+                                                       const int* __restrict__ samples,
+                                                       const unsigned* __restrict__ raws,
+                                                       const int* __restrict__ d_n, unsigned* __restrict__ flag,
+                                                       int Hyp, double fx,
                                                        double fy, double cx, double cy, double* __restrict__ Rout,
                                                        double* __restrict__ tout, uint8_t* __restrict__ valid) {
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= Hyp) return;
+  int sidx[4];
+  if (RAW) {
+    const int n = *d_n;
+    if (n < 8) {
+      if (h == 0) atomicOr(flag, 1u);
+      for (int k = 0; k < 9; ++k) Rout[9 * h + k] = 0.0;
+      for (int k = 0; k < 3; ++k) tout[3 * h + k] = 0.0;
+      valid[h] = 0;
+      return;
+    }
+    unsigned rw[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) rw[k] = raws[7 * h + k];
+    bool risky = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned j = (unsigned)(n - 4 + k);
+      const int val = (int)bounded_from_raw(rw[k], j, risky);
+      bool seen = false;
+#pragma unroll
+      for (int q = 0; q < k; ++q) seen |= (sidx[q] == val);
+      sidx[k] = seen ? (int)j : val;
+    }
+#pragma unroll
+    for (int i = 3; i >= 1; --i) {
+      const int j = (int)bounded_from_raw(rw[4 + (3 - i)], (unsigned)i, risky);
+      int vj = sidx[0];
+#pragma unroll
+      for (int q = 1; q <= i; ++q) vj = (j == q) ? sidx[q] : vj;
+      const int vi = sidx[i];
+#pragma unroll
+      for (int q = 0; q <= i; ++q)
+        if (q == j) sidx[q] = vi;
+      sidx[i] = vj;
+    }
+    if (risky) atomicOr(flag, 1u);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sidx[k] = samples[4 * h + k];
+  }
   double P[4][3], px[4][2];
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int idx = samples[4 * h + k];
+    const int idx = sidx[k];
     P[k][0] = Xw[3 * idx];
     P[k][1] = Xw[3 * idx + 1];
     P[k][2] = Xw[3 * idx + 2];
@@ -241,13 +303,16 @@ constexpr int SC_T = 256;
 
 // one workgroup per hypothesis; mask row h holds ceil(N/64) 64-bit words
 __global__ __launch_bounds__(SC_T) void p3p_score_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
-                                                         int N, const double* __restrict__ Rall,
+                                                         int N_arg, const int* __restrict__ d_n,
+                                                         const double* __restrict__ Rall,
                                                          const double* __restrict__ tall,
                                                          const uint8_t* __restrict__ valid, double fx, double fy,
                                                          double cx, double cy, double thr, int* __restrict__ counts,
                                                          unsigned long long* __restrict__ masks, int words) {
   const int h = blockIdx.x;
   const int tid = threadIdx.x;
+  const int N = d_n ? *d_n : N_arg;         // population size known only on the device (pipeline) or given
+  const int words_n = (N + 63) >> 6;        // words in use; `words` is the row stride
   __shared__ int s_cnt[SC_T / 64];
   double R[9], t[3];
 #pragma unroll
@@ -256,7 +321,7 @@ __global__ __launch_bounds__(SC_T) void p3p_score_kernel(const double* __restric
   for (int k = 0; k < 3; ++k) t[k] = tall[3 * h + k];
   const bool ok = valid[h] != 0;
   int cnt = 0;
-  for (int base = 0; base < words * 64; base += SC_T) {
+  for (int base = 0; base < words_n * 64; base += SC_T) {
     const int i = base + tid;
     bool in = false;
     if (ok && i < N) {
@@ -265,7 +330,7 @@ __global__ __launch_bounds__(SC_T) void p3p_score_kernel(const double* __restric
     }
     const unsigned long long m = __ballot(in);
     const int w = i >> 6;
-    if ((tid & 63) == 0 && w < words) {
+    if ((tid & 63) == 0 && w < words_n) {
       if (masks) masks[(size_t)h * words + w] = m;
       cnt += __popcll(m);
     }
@@ -297,6 +362,31 @@ __global__ __launch_bounds__(256) void reproj_kernel(const double* __restrict__ 
 
 }  // namespace
 
+// Pipeline-internal form of vo_p3p_hypotheses_dev: population size and generator outputs are
+// device-readable and need not be final when this is enqueued (see p3p_solve_kernel<true>).
+int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
+                              const double* K, const uint32_t* d_raws, int Hyp, double thr_sq, double* d_R,
+                              double* d_t, uint8_t* d_valid, int32_t* d_counts, uint64_t* d_masks, uint32_t* d_flag) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, d_X && d_x && d_n && K && d_raws && d_R && d_t && d_valid && d_counts && d_flag,
+             "p3p_hypotheses_raw: null pointer");
+  VO_REQUIRE(ctx, n_cap >= 4 && Hyp >= 1, "p3p_hypotheses_raw: need n_cap >= 4 and Hyp >= 1");
+  VO_REQUIRE(ctx, K[0] != 0.0 && K[4] != 0.0, "p3p_hypotheses_raw: singular intrinsics");
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  {
+    vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
+    hipLaunchKernelGGL(p3p_solve_kernel<true>, dim3(vo_cdiv(Hyp, 64)), dim3(64), 0, ctx->stream, d_X, d_x,
+                       (const int*)nullptr, d_raws, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid);
+  }
+  VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
+  {
+    vo_prof_scope ps(ctx, VO_K_P3P_SCORE);
+    hipLaunchKernelGGL(p3p_score_kernel, dim3(Hyp), dim3(SC_T), 0, ctx->stream, d_X, d_x, 0, d_n, d_R, d_t, d_valid,
+                       fx, fy, cx, cy, thr_sq, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64));
+  }
+  return vo_check_launch(ctx, "p3p_score_kernel");
+}
+
 extern "C" {
 
 int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const double* K,
@@ -310,15 +400,16 @@ int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int
   const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
-    hipLaunchKernelGGL(p3p_solve_kernel, dim3(vo_cdiv(Hyp, 64)), dim3(64), 0, ctx->stream, d_X, d_x, d_samples, Hyp,
-                       fx, fy, cx, cy, d_R, d_t, d_valid);
+    hipLaunchKernelGGL(p3p_solve_kernel<false>, dim3(vo_cdiv(Hyp, 64)), dim3(64), 0, ctx->stream, d_X, d_x,
+                       d_samples, (const unsigned*)nullptr, (const int*)nullptr, (unsigned*)nullptr, Hyp, fx, fy, cx,
+                       cy, d_R, d_t, d_valid);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   const int words = vo_cdiv(N, 64);
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SCORE);
-    hipLaunchKernelGGL(p3p_score_kernel, dim3(Hyp), dim3(SC_T), 0, ctx->stream, d_X, d_x, N, d_R, d_t, d_valid, fx,
-                       fy, cx, cy, thr_sq, d_counts, (unsigned long long*)d_masks, words);
+    hipLaunchKernelGGL(p3p_score_kernel, dim3(Hyp), dim3(SC_T), 0, ctx->stream, d_X, d_x, N, (const int*)nullptr, d_R,
+                       d_t, d_valid, fx, fy, cx, cy, thr_sq, d_counts, (unsigned long long*)d_masks, words);
   }
   return vo_check_launch(ctx, "p3p_score_kernel");
 }

@@ -2,11 +2,15 @@
 // reference driver's steady-state loop (src/main.py:248-286) with every array kept in
 // HBM between stages.  See include/vo_hip.h for the stage list.
 //
-// Stream plan for one step (single HIP stream, two host waits):
-//   pyramid(next) -> KLT -> gather/compact  --event A-->  host reads n_tracked
-//   Harris response + NMS on next            (runs while the host draws the samples)
-//   H2D samples -> P3P solve -> P3P score -> D2H (valid, counts)  --event B-->  host
-//   replays the sequential RANSAC rule, fetches the winning pose, queues the DLT.
+// Stream plan for one step (two HIP streams, one host wait):
+//   main:  pyramid(next) -> KLT -> gather/compact -> P3P solve -> P3P score -> mirror
+//          all enqueued back to back: the solve kernel derives its samples on the device from
+//          raw PCG64 outputs the host wrote to mapped memory while the KLT kernel ran, and
+//          reads the tracked count the gather left in HBM, so nothing waits for the host.
+//   det:   [DLT of the previous step] -> Harris response + NMS on next (a captured hipGraph)
+//   host:  spins on a sequence word the mirror kernel publishes in mapped memory, replays the
+//          sequential RANSAC rule over (valid, count), takes the winning pose; the DLT of this
+//          step is queued at the start of the next one (or by fetch/export, whichever is first).
 #include "vo_internal.h"
 
 #pragma clang fp contract(off)
@@ -34,7 +38,12 @@ struct vo_pipeline {
   double* d_scores = nullptr;
   float *d_kp_f32[2] = {nullptr, nullptr}, *d_next_f32 = nullptr, *d_err = nullptr;   // d_kp as float pairs
   uint8_t* d_status = nullptr;
-  double *d_prev_c = nullptr, *d_next_c = nullptr, *d_land_c = nullptr, *d_tri = nullptr;
+  // compacted tracks, two sets: the deferred DLT of step k reads set k&1 while step k+1 fills the other
+  double *d_prev_c[2] = {nullptr, nullptr}, *d_next_c[2] = {nullptr, nullptr}, *d_land_c[2] = {nullptr, nullptr};
+  double* d_tri = nullptr;
+  int cset = 0;                      // set written by the last step
+  bool dlt_pending = false;          // the last step's DLT has not been enqueued yet
+  int dlt_n = 0, dlt_set = 0;
   int32_t* d_ntracked = nullptr;
   double *d_R = nullptr, *d_t = nullptr;
   uint8_t* d_valid = nullptr;
@@ -43,13 +52,20 @@ struct vo_pipeline {
   // pinned host
   int32_t* h_ntracked = nullptr;
   int32_t* h_samples = nullptr;
+  uint32_t* h_raw = nullptr;         // 7 * hyp generator outputs for the device-side sampler
   uint8_t* h_valid = nullptr;
   int32_t* h_counts = nullptr;
   double* h_pose = nullptr;          // 12
   double *h_R = nullptr, *h_t = nullptr;     // all hypotheses' poses, written by the GPU into mapped host memory
   volatile unsigned* h_seq = nullptr;         // [0] tracking done, [1] hypotheses mirrored: sequence numbers the host spins on
   unsigned seq = 0;
-  double* h_C = nullptr;             // 24 (C1, C2)
+  double* h_C = nullptr;             // 2 x 24 (C1, C2), alternating with the track sets
+  // device aliases of the mapped host buffers
+  int32_t *m_ntracked = nullptr, *m_samples = nullptr, *m_counts = nullptr;
+  uint32_t* m_raw = nullptr;
+  unsigned* m_seq = nullptr;
+  uint8_t* m_valid = nullptr;
+  double *m_R = nullptr, *m_t = nullptr, *m_C = nullptr;
   hipEvent_t evA = nullptr, evB = nullptr;
   // RANSAC object state (persists across frames like the reference's estimator)
   vo_pcg64 rng;
@@ -113,10 +129,11 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
     __syncthreads();
   }
   if (tid == 0) {
-    *n_out = s_base;
+    n_out[0] = s_base;
+    n_out[2] = 0;           // "sampler needs the sequential path" flag of the solve kernel that follows
     *n_out_host = s_base;   // mapped pinned host memory
     __threadfence_system();
-    *seq_host = seq;        // the host spins on this word instead of waiting on an event
+    *seq_host = seq;
   }
 }
 
@@ -129,8 +146,14 @@ __global__ __launch_bounds__(256) void mirror_hypotheses_kernel(const uint8_t* _
                                                                 uint8_t* __restrict__ h_valid, int32_t* __restrict__ h_counts,
                                                                 double* __restrict__ h_R, double* __restrict__ h_t,
                                                                 unsigned* __restrict__ seq_host, unsigned seq,
-                                                                unsigned* __restrict__ done) {
+                                                                unsigned* __restrict__ done,
+                                                                const int32_t* __restrict__ n_flag,
+                                                                int32_t* __restrict__ h_n_flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && n_flag) {
+    h_n_flag[0] = n_flag[0];   // tracked count
+    h_n_flag[2] = n_flag[2];   // sampler flag
+  }
   const int stride = gridDim.x * blockDim.x;
   for (int k = i; k < hyp; k += stride) {
     h_valid[k] = valid[k];
@@ -251,9 +274,11 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_next_f32, (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_err, (size_t)N));
   PA(dev_alloc(ctx, &p->d_status, (size_t)N));
-  PA(dev_alloc(ctx, &p->d_prev_c, (size_t)N * 2));
-  PA(dev_alloc(ctx, &p->d_next_c, (size_t)N * 2));
-  PA(dev_alloc(ctx, &p->d_land_c, (size_t)N * 3));
+  for (int k = 0; k < 2; ++k) {
+    PA(dev_alloc(ctx, &p->d_prev_c[k], (size_t)N * 2));
+    PA(dev_alloc(ctx, &p->d_next_c[k], (size_t)N * 2));
+    PA(dev_alloc(ctx, &p->d_land_c[k], (size_t)N * 3));
+  }
   PA(dev_alloc(ctx, &p->d_tri, (size_t)N * 3));
   PA(dev_alloc(ctx, &p->d_ntracked, 4));
   PA(dev_alloc(ctx, &p->d_R, (size_t)Hyp * 9));
@@ -263,6 +288,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_masks, (size_t)Hyp * vo_cdiv(N, 64)));
   PA(pin_alloc(ctx, &p->h_ntracked, 4));
   PA(pin_alloc(ctx, &p->h_samples, (size_t)Hyp * 4));
+  PA(pin_alloc(ctx, &p->h_raw, (size_t)Hyp * 7));
   PA(pin_alloc(ctx, &p->h_valid, (size_t)Hyp));
   PA(pin_alloc(ctx, &p->h_counts, (size_t)Hyp));
   PA(pin_alloc(ctx, &p->h_pose, 12));
@@ -274,7 +300,19 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     if (q) memset(q, 0, 64);
     p->h_seq = q;
   }
-  PA(pin_alloc(ctx, &p->h_C, 24));
+  PA(pin_alloc(ctx, &p->h_C, 48));
+#define MAP(dst, src) do { if (rc == VO_OK && hipHostGetDevicePointer((void**)&(dst), (void*)(src), 0) != hipSuccess) \
+    rc = vo_set_error(ctx, VO_EHIP, "hipHostGetDevicePointer failed"); } while (0)
+  MAP(p->m_ntracked, p->h_ntracked);
+  MAP(p->m_samples, p->h_samples);
+  MAP(p->m_raw, p->h_raw);
+  MAP(p->m_seq, p->h_seq);
+  MAP(p->m_valid, p->h_valid);
+  MAP(p->m_counts, p->h_counts);
+  MAP(p->m_R, p->h_R);
+  MAP(p->m_t, p->h_t);
+  MAP(p->m_C, p->h_C);
+#undef MAP
 #undef PA
   if (rc == VO_OK && (hipEventCreateWithFlags(&p->evA, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evB, hipEventDisableTiming) != hipSuccess ||
@@ -310,11 +348,12 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   for (int k = 0; k < 2; ++k)
     if (p->det_graph[k]) (void)hipGraphExecDestroy(p->det_graph[k]);
   void* dev[] = {p->d_det_img, p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_kp_f32[0], p->d_kp_f32[1],
-                 p->d_next_f32, p->d_err, p->d_status, p->d_prev_c, p->d_next_c, p->d_land_c, p->d_tri,
+                 p->d_next_f32, p->d_err, p->d_status, p->d_prev_c[0], p->d_next_c[0], p->d_land_c[0], p->d_prev_c[1],
+                 p->d_next_c[1], p->d_land_c[1], p->d_tri,
                  p->d_ntracked, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks};
   for (void* q : dev)
     if (q) (void)hipFree(q);
-  void* pin[] = {p->h_ntracked, p->h_samples, p->h_valid, p->h_counts, p->h_pose, p->h_C, p->h_R, p->h_t, (void*)p->h_seq};
+  void* pin[] = {p->h_ntracked, p->h_samples, p->h_raw, p->h_valid, p->h_counts, p->h_pose, p->h_C, p->h_R, p->h_t, (void*)p->h_seq};
   for (void* q : pin)
     if (q) (void)hipHostFree(q);
   if (p->evA) (void)hipEventDestroy(p->evA);
@@ -406,12 +445,39 @@ int vo_pipeline_prime(vo_pipeline* p, int idx) {
   VO_REQUIRE(ctx, p->seeded, "pipeline_prime: call vo_pipeline_seed first");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   p->cur = 0;
+  p->dlt_pending = false;
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[idx], p->cfg.H, p->cfg.W, p->n_levels, p->d_pyr[0]));
   VO_TRY(detect(p, idx, p->d_kp[0], true));
   VO_TRY(detect_join(p));
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   p->prev_frame = idx;
   return VO_OK;
+}
+
+// The DLT of the last step is enqueued lazily on the detection stream: it is not on the path
+// to the next pose, only fetch / export / the shared-map exchange read it.
+static int flush_dlt(vo_pipeline* p) {
+  if (!p->dlt_pending) return VO_OK;
+  vo_ctx* ctx = p->ctx;
+  p->dlt_pending = false;
+  p->det->prof_on = ctx->prof_on;
+  p->det->prof_kernel = ctx->prof_kernel;
+  const int s = p->dlt_set;
+  // cameras are read from mapped host memory (set s is rewritten two steps later at the earliest)
+  const int rc = vo_triangulate_dlt_dev(p->det, p->d_prev_c[s], p->d_next_c[s], p->dlt_n, p->m_C + 24 * s, 0,
+                                        p->m_C + 24 * s + 12, p->d_tri);
+  if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->det));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, p->det->stream));
+  return VO_OK;
+}
+
+static int launch_mirror(vo_pipeline* p, unsigned seq, bool with_count) {
+  const vo_pipeline_config& c = p->cfg;
+  hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, p->ctx->stream, p->d_valid, p->d_counts, p->d_R,
+                     p->d_t, c.hyp, p->m_valid, p->m_counts, p->m_R, p->m_t, p->m_seq + 1, seq,
+                     (unsigned*)p->d_ntracked + 1, with_count ? (const int32_t*)p->d_ntracked : (const int32_t*)nullptr,
+                     p->m_ntracked);
+  return vo_check_launch(p->ctx, "mirror_hypotheses_kernel");
 }
 
 int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out) {
@@ -424,68 +490,71 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int N = c.n_keypoints, a = p->cur, b = 1 - p->cur;
+  const int cs = 1 - p->cset;                       // track set this step fills
   const double fx = c.K[0], fy = c.K[4], cx = c.K[2], cy = c.K[5];
+  const bool seq_sampler = getenv("VO_SEQ_SAMPLER") != nullptr;   // test hook: always take the sequential path
   memset(out, 0, sizeof(*out));
   out->best_index = -1;
 
-  // ---- tracking ----
+  // ---- tracking + hypotheses, enqueued back to back ----
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
+  VO_TRY(detect_join(p));   // keypoints of `prev` (detected during the previous step)
   VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
                           p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
-  // device-side aliases of the mapped host buffers the kernels publish into
-  int32_t* m_ntracked = nullptr;
-  unsigned* m_seq = nullptr;
-  uint8_t* m_valid = nullptr;
-  int32_t* m_counts = nullptr;
-  double *m_R = nullptr, *m_t = nullptr, *m_C = nullptr;
-  int32_t* m_samples = nullptr;
-  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_ntracked, p->h_ntracked, 0));
-  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_seq, (void*)p->h_seq, 0));
-  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_valid, p->h_valid, 0));
-  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_counts, p->h_counts, 0));
-  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_R, p->h_R, 0));
-  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_t, p->h_t, 0));
-  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_C, p->h_C, 0));
-  VO_HIP_TRY(ctx, hipHostGetDevicePointer((void**)&m_samples, p->h_samples, 0));
   const unsigned seq_a = ++p->seq;
   {
     vo_prof_scope ps(ctx, VO_K_GATHER);
     hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, st, p->d_kp[a], p->d_next_f32, p->d_status,
                        p->d_err, N, (float)c.klt_err_threshold, p->d_depth[prev_idx], c.H, c.W, fx, fy, cx, cy,
-                       p->d_T_wc + (size_t)prev_idx * 16, p->d_prev_c, p->d_next_c, p->d_land_c, p->d_ntracked,
-                       m_ntracked, m_seq, seq_a);
+                       p->d_T_wc + (size_t)prev_idx * 16, p->d_prev_c[cs], p->d_next_c[cs], p->d_land_c[cs],
+                       p->d_ntracked, p->m_ntracked, p->m_seq, seq_a);
   }
   VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
+  // Generator outputs for the device-side sampler: drawn from a copy, the real generator
+  // advances by what the sequential rule consumes (below).  The KLT kernel is running meanwhile.
+  vo_pcg64 g = p->rng;
+  vo_rng_raw32(&g, 7 * c.hyp, p->h_raw);
+  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], p->d_ntracked, N, c.K, p->m_raw, c.hyp,
+                                   c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks,
+                                   (uint32_t*)p->d_ntracked + 2));
+  unsigned seq_b = ++p->seq;
+  VO_TRY(launch_mirror(p, seq_b, true));
 
-  // ---- detection on the new frame (feeds the next step) runs beside it on its own stream.
-  // The keypoint buffer it overwrites was last read by the previous step's tracking, which
-  // the host has already waited for, so it needs no dependency on the main stream. ----
+  // ---- the other stream: last step's DLT, then detection on the new frame (feeds the next step).
+  // The keypoint buffer it overwrites was last read by the previous step's tracking, which the
+  // host has already waited for. ----
+  VO_TRY(flush_dlt(p));
   VO_TRY(detect(p, next_idx, p->d_kp[b], false));
 
-  VO_TRY(spin_until(ctx, p->h_seq, seq_a));
-  const int n = *(volatile int32_t*)p->h_ntracked;
+  VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
+  const int n = ((volatile int32_t*)p->h_ntracked)[0];
+  const bool redo = ((volatile int32_t*)p->h_ntracked)[2] != 0 || seq_sampler;
   out->n_tracked = n;
   p->last_ntracked = n;
   p->last_best = -1;
-  p->last_words = vo_cdiv(n > 0 ? n : 1, 64);
+  p->last_words = vo_cdiv(N, 64);
+  p->cset = cs;
 
   if (n >= 4) {
-    // ---- P3P-RANSAC: bulk hypotheses on the GPU, sequential rule replayed on the host ----
-    vo_pcg64 g = p->rng;                 // speculative copy; the real generator advances by what is consumed
+    // ---- sequential RANSAC rule replayed on the host over the bulk (valid, count) ----
     int64_t n_done = 0;
     int32_t best_count = -1, best_idx = -1;
     int total_consumed = 0, finished = 0, batches = 0, hyp_valid = 0;
+    bool have_batch = !redo;
+    int words = vo_cdiv(N, 64);
+    if (redo) g = p->rng;   // a draw may have been rejected (or n < 8): the batch is redone from sequential samples
     while (!finished) {
-      // the sample indices are read by the solve kernel straight from mapped host memory
-      VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, p->h_samples));
-      VO_TRY(vo_p3p_hypotheses_dev(ctx, p->d_land_c, p->d_next_c, n, c.K, m_samples, c.hyp, c.p3p_thr_sq, p->d_R,
-                                   p->d_t, p->d_valid, p->d_counts, p->d_masks));
-      const unsigned seq_b = ++p->seq;
-      hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, st, p->d_valid, p->d_counts, p->d_R, p->d_t,
-                         c.hyp, m_valid, m_counts, m_R, m_t, m_seq + 1, seq_b, (unsigned*)p->d_ntracked + 1);
-      VO_TRY(vo_check_launch(ctx, "mirror_hypotheses_kernel"));
-      VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
+      if (!have_batch) {
+        VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, p->h_samples));
+        VO_TRY(vo_p3p_hypotheses_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], n, c.K, p->m_samples, c.hyp, c.p3p_thr_sq,
+                                     p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks));
+        seq_b = ++p->seq;
+        VO_TRY(launch_mirror(p, seq_b, false));
+        VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
+        words = vo_cdiv(n, 64);
+      }
+      have_batch = false;
       int consumed = 0;
       const int32_t before = best_idx;
       VO_TRY(vo_ransac_replay(&p->rs, p->h_valid, p->h_counts, c.hyp, n, &n_done, &best_count, &best_idx,
@@ -493,11 +562,12 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
       for (int i = 0; i < c.hyp; ++i) hyp_valid += p->h_valid[i] ? 1 : 0;
       total_consumed += consumed;
       if (best_idx != before) {
-        // the winner so far lives in this batch: fetch its pose before the buffers are reused
+        // the winner so far lives in this batch: take its pose before the buffers are reused
         const int local = best_idx - batches * c.hyp;
         memcpy(out->R, p->h_R + (size_t)local * 9, 72);
         memcpy(out->t, p->h_t + (size_t)local * 3, 24);
         p->last_best = local;
+        p->last_words = words;
       } else if (batches > 0) {
         p->last_best = -1;   // winner's mask row was overwritten by a later batch
       }
@@ -518,26 +588,21 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     // ---- DLT triangulation of the tracked pairs: C1 = K T_cw(prev) (stream pose), C2 = K [R | t] ----
     if (best_idx >= 0) {
       double Tcw[16], Rt[12];
+      double* hC = p->h_C + 24 * cs;
       rigid_inverse(&p->T_wc[(size_t)prev_idx * 16], Tcw);
-      k_times_rt(c.K, Tcw, p->h_C);
+      k_times_rt(c.K, Tcw, hC);
       for (int r = 0; r < 3; ++r) {
         Rt[4 * r] = out->R[3 * r];
         Rt[4 * r + 1] = out->R[3 * r + 1];
         Rt[4 * r + 2] = out->R[3 * r + 2];
         Rt[4 * r + 3] = out->t[r];
       }
-      k_times_rt(c.K, Rt, p->h_C + 12);
-      // Off the tracking stream: the inputs are complete (the host has seen the gather's
-      // sequence word), the result is only read after detect_join(), and the cameras are read
-      // from mapped host memory, rewritten no earlier than the next step's RANSAC.
-      p->det->prof_on = ctx->prof_on;
-      p->det->prof_kernel = ctx->prof_kernel;
-      const int rc = vo_triangulate_dlt_dev(p->det, p->d_prev_c, p->d_next_c, n, m_C, 0, m_C + 12, p->d_tri);
-      if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->det));
-      VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, p->det->stream));
+      k_times_rt(c.K, Rt, hC + 12);
+      p->dlt_pending = true;
+      p->dlt_n = n;
+      p->dlt_set = cs;
     }
   }
-  VO_TRY(detect_join(p));   // the next step (and any fetch) sees the new keypoints and landmarks
   p->cur = b;
   p->prev_frame = next_idx;
   return VO_OK;
@@ -547,6 +612,8 @@ int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int ca
   if (!p || !r || !d_record) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
   VO_REQUIRE(ctx, cap >= 0, "pipeline_export_state: bad capacity");
+  VO_TRY(flush_dlt(p));
+  VO_TRY(detect_join(p));
   pose17 h;
   for (int row = 0; row < 3; ++row) {
     for (int c = 0; c < 3; ++c) h.v[4 * row + c] = r->R[3 * row + c];
@@ -587,12 +654,15 @@ int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* 
   vo_ctx* ctx = p->ctx;
   hipStream_t st = ctx->stream;
   const int n = p->last_ntracked, N = p->cfg.n_keypoints;
+  const int cs = p->cset;
+  VO_TRY(flush_dlt(p));
+  VO_TRY(detect_join(p));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   if (kp_next) VO_HIP_TRY(ctx, hipMemcpy(kp_next, p->d_kp[p->cur], (size_t)N * 16, hipMemcpyDeviceToHost));
   if (n > 0) {
-    if (prev_xy) VO_HIP_TRY(ctx, hipMemcpy(prev_xy, p->d_prev_c, (size_t)n * 16, hipMemcpyDeviceToHost));
-    if (next_xy) VO_HIP_TRY(ctx, hipMemcpy(next_xy, p->d_next_c, (size_t)n * 16, hipMemcpyDeviceToHost));
-    if (landmarks) VO_HIP_TRY(ctx, hipMemcpy(landmarks, p->d_land_c, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (prev_xy) VO_HIP_TRY(ctx, hipMemcpy(prev_xy, p->d_prev_c[cs], (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (next_xy) VO_HIP_TRY(ctx, hipMemcpy(next_xy, p->d_next_c[cs], (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (landmarks) VO_HIP_TRY(ctx, hipMemcpy(landmarks, p->d_land_c[cs], (size_t)n * 24, hipMemcpyDeviceToHost));
     if (triangulated) VO_HIP_TRY(ctx, hipMemcpy(triangulated, p->d_tri, (size_t)n * 24, hipMemcpyDeviceToHost));
     if (inliers) {
       VO_REQUIRE(ctx, p->last_best >= 0, "pipeline_fetch: no inlier mask for the last step");

@@ -146,6 +146,12 @@ int64_t n_iterations_for(double confidence, double outlier_ratio, int s) {
 
 }  // namespace
 
+void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out) {
+  pcg g = load(rng);
+  for (int i = 0; i < count; ++i) out[i] = g.next32();
+  store(g, rng);
+}
+
 extern "C" {
 
 int vo_rng_choice(vo_pcg64* rng, int pop, int s, int count, int32_t* out) {
