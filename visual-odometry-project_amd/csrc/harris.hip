@@ -244,6 +244,7 @@ struct nms_ctl {
 
 constexpr int HIST_SHIFT = 47;           // 65536 bins over non-negative doubles
 constexpr int HIST_BINS = 1 << 16;
+constexpr int HIST_TOTAL = HIST_BINS + 256;   // fine bins, then 256 coarse bins (fine >> 8)
 constexpr int CX = 64, CY = 32;          // candidate tile
 constexpr int SEG = CX * CY;             // capacity of one tile's list segment
 constexpr int RANK_MAX = 32768;          // entries the rank kernel orders (above: sort path)
@@ -303,11 +304,13 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
   unsigned* s_comb = s_mask + LH * 4;                  // CY rows x 4 words
   unsigned short* s_list = reinterpret_cast<unsigned short*>(s_comb + CY * 4);   // qualifiers (L cells)
   __shared__ unsigned s_cnt[3];
+  __shared__ unsigned s_coarse[256];   // the tile's share of the coarse histogram level
 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * CX, y0 = blockIdx.y * CY;
   const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
   if (tid < 3) s_cnt[tid] = 0;
+  s_coarse[tid] = 0;
 
   // the tile's own scores stay in registers for step E
   const int lx = tid & (CX - 1);
@@ -459,7 +462,10 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
     if (kind == 0) {
       seg_keys_l1[seg0 + s0] = key;
       seg_idx_l1[seg0 + s0] = idx;
-      atomicAdd(&hist[key >> HIST_SHIFT], 1u);
+      const unsigned bin = (unsigned)(key >> HIST_SHIFT);
+      atomicAdd(&hist[bin], 1u);
+      atomicAdd(&s_coarse[bin >> 8], 1u);   // coarse level (256 fine bins each): the scores of a frame share
+                                            // a few of these bins, so they are summed per tile first
     } else if (kind == 1) {
       seg_keys_a1[seg0 + s1] = key;
       seg_idx_a1[seg0 + s1] = idx;
@@ -467,72 +473,67 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
   }
   __syncthreads();
   if (tid == 0) seg_cnt[blk] = make_uint4(s_cnt[0], s_cnt[1], 0u, 0u);
+  if (s_coarse[tid]) atomicAdd(&hist[HIST_BINS + tid], s_coarse[tid]);
 }
 
 // ---------------------------------------------------------------------------------
-// NMS stage 2: score bound with >= N L1 entries above it; clears the histogram
+// NMS stage 2: score bound with >= N L1 entries above it (two-level histogram walk)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void nms_threshold_kernel(unsigned* __restrict__ hist, nms_ctl* ctl, int N) {
-  // wave w owns bins [4096 w, 4096 w + 4096) as 64 rows of 64 bins; lane l loads bin 64 j + l of row j
-  __shared__ unsigned s_wave[16];
-  __shared__ unsigned s_t[64 * 65];   // the crossing wave's bins, row stride 65 (conflict-free column walks)
+// suffix sums over the 256 values held one per thread: returns sum of v over threads >= tid
+__device__ __forceinline__ unsigned suffix_sum_256(unsigned v, unsigned* s_w) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  unsigned v[64];
-  unsigned part = 0;
-  unsigned* base = hist + wv * 4096 + lane;
+  unsigned suf = v;
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    v[j] = base[64 * j];
-    base[64 * j] = 0;
-    part += v[j];
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = __shfl_down(suf, off);
+    if (lane + off < 64) suf += o;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-  if (lane == 0) s_wave[wv] = part;
   __syncthreads();
-  unsigned above = 0, total = 0;
-  for (int w = 15; w >= 0; --w) {
-    if (w > wv) above += s_wave[w];
-    total += s_wave[w];
+  if (lane == 0) s_w[wv] = suf;
+  __syncthreads();
+  for (int w = wv + 1; w < 4; ++w) suf += s_w[w];
+  return suf;
+}
+
+__global__ __launch_bounds__(256) void nms_threshold_kernel(const unsigned* __restrict__ hist, nms_ctl* ctl, int N) {
+  __shared__ unsigned s_w[4];
+  __shared__ unsigned s_above;
+  const int tid = threadIdx.x;
+  if (tid == 0) {   // counters of this call (the list is filled by the kernels that follow)
+    ctl->n_c = 0;
+    ctl->n_rem = 0;
+    ctl->overflow = 0;
+    ctl->n_sel = 0;
   }
-  if (tid == 0 && total < (unsigned)N) ctl->t_bits = 1ull;   // fewer than N strict maxima: keep everything
-  if (total >= (unsigned)N && above < (unsigned)N && above + s_wave[wv] >= (unsigned)N) {
-    // exactly one wave gets here.  Transpose through LDS: lane j then owns row j.
-#pragma unroll
-    for (int j = 0; j < 64; ++j) s_t[j * 65 + lane] = v[j];
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave's own LDS writes have landed
-    unsigned row = 0;
-#pragma unroll
-    for (int l = 0; l < 64; ++l) row += s_t[lane * 65 + l];
-    // suffix sums over rows (higher row = higher bins)
-    unsigned suf = row;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned o = __shfl_down(suf, off);
-      if (lane + off < 64) suf += o;
-    }
-    const unsigned long long mr = __ballot(above + suf >= (unsigned)N);
-    const int jr = 63 - __builtin_clzll(mr);                 // crossing row
-    const unsigned suf_next = __shfl(suf, (jr + 1) & 63);
-    const unsigned acc = above + (jr < 63 ? suf_next : 0u);  // count strictly above row jr
-    // inside row jr: lane l holds bin l
-    unsigned sb = s_t[jr * 65 + lane];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned o = __shfl_down(sb, off);
-      if (lane + off < 64) sb += o;
-    }
-    const unsigned long long mb = __ballot(acc + sb >= (unsigned)N);
-    const int bin = wv * 4096 + 64 * jr + (63 - __builtin_clzll(mb));
-    if (lane == 0) {
-      const unsigned long long t = (unsigned long long)bin << HIST_SHIFT;
-      ctl->t_bits = t ? t : 1ull;
-    }
+  // coarse level: thread t holds the count of fine bins [256 t, 256 t + 256)
+  const unsigned v1 = hist[HIST_BINS + tid];
+  const unsigned suf1 = suffix_sum_256(v1, s_w);
+  const int n_ge = __syncthreads_count(suf1 >= (unsigned)N);   // suffix sums do not increase with t
+  if (n_ge == 0) {
+    if (tid == 0) ctl->t_bits = 1ull;   // fewer than N strict maxima: keep everything
+    return;
+  }
+  const int cb = n_ge - 1;              // crossing coarse bin
+  if (tid == cb) s_above = suf1 - v1;   // strict maxima in coarse bins above it
+  __syncthreads();
+  const unsigned above = s_above;
+  const unsigned v2 = hist[cb * 256 + tid];
+  const unsigned suf2 = suffix_sum_256(v2, s_w);
+  const int m_ge = __syncthreads_count(above + suf2 >= (unsigned)N);   // >= 1: bin 0 of cb reaches suf1(cb) >= N
+  if (tid == 0) {
+    const unsigned long long t = (unsigned long long)(cb * 256 + (m_ge - 1)) << HIST_SHIFT;
+    ctl->t_bits = t ? t : 1ull;
   }
 }
 
+// List entry format (idx_c): flat pixel index << 2 | flags.  bit 0: undecided (the sorted walk
+// must still test it); bit 1: came from the candidate segments (a selected one suppresses
+// later undecided entries; strict maxima never do, no candidate lies within r of one).
+constexpr unsigned ENT_UNDECIDED = 1u, ENT_CAND = 2u;
+
 // ---------------------------------------------------------------------------------
-// NMS stage 3 (one workgroup per tile): L1 >= T -> selected list; A1 >= T -> live candidates
+// NMS stage 3 (one workgroup per tile): L1 >= T -> selected list; A1 >= T -> live candidates.
+// Also clears the histogram (its only reader has run) for the next call.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long long* __restrict__ seg_keys_l1,
                                                          const unsigned* __restrict__ seg_idx_l1,
@@ -541,29 +542,36 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
                                                          uint4* __restrict__ seg_cnt, unsigned* __restrict__ seg_cand,
                                                          unsigned long long* __restrict__ keys_c,
                                                          unsigned* __restrict__ idx_c, unsigned* __restrict__ alive,
-                                                         nms_ctl* ctl, unsigned cap_c) {
-  __shared__ unsigned s_n;
+                                                         nms_ctl* ctl, unsigned cap_c, unsigned* __restrict__ hist) {
+  __shared__ unsigned s_n, s_l1n, s_base;
   const unsigned blk = blockIdx.x;
   const size_t seg0 = (size_t)blk * SEG;
   const uint4 cnt = seg_cnt[blk];
   const unsigned long long t = ctl->t_bits;
   const int tid = threadIdx.x;
+  for (unsigned i = blk * NT + tid; i < (unsigned)HIST_TOTAL; i += gridDim.x * NT) hist[i] = 0;
   if (tid == 0) s_n = 0;
   __syncthreads();
   for (unsigned b0 = 0; b0 < cnt.x; b0 += NT) {
     const unsigned i = b0 + tid;
-    if (i < cnt.x) {
-      const unsigned long long key = seg_keys_l1[seg0 + i];
-      if (key >= t) {
-        const unsigned pos = atomicAdd(&ctl->n_c, 1u);
-        if (pos < cap_c) {
-          keys_c[pos] = key;
-          idx_c[pos] = seg_idx_l1[seg0 + i] << 1;
-        } else {
-          ctl->overflow = 1;
-        }
+    const unsigned long long key = i < cnt.x ? seg_keys_l1[seg0 + i] : 0ull;
+    const bool keep = i < cnt.x && key >= t;
+    if (tid == 0) s_l1n = 0;
+    __syncthreads();
+    const unsigned slot = wave_slot(keep, &s_l1n);
+    __syncthreads();
+    if (tid == 0 && s_l1n) s_base = atomicAdd(&ctl->n_c, s_l1n);   // one list reservation per tile and chunk
+    __syncthreads();
+    if (keep) {
+      const unsigned pos = s_base + slot;
+      if (pos < cap_c) {
+        keys_c[pos] = key;
+        idx_c[pos] = seg_idx_l1[seg0 + i] << 2;
+      } else {
+        ctl->overflow = 1;
       }
     }
+    __syncthreads();
   }
   for (unsigned b0 = 0; b0 < cnt.y; b0 += NT) {
     const unsigned i = b0 + tid;
@@ -578,11 +586,14 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
   }
   __syncthreads();
   if (tid == 0) {
-    seg_cnt[blk].z = s_n;
-    seg_cnt[blk].w = s_n;   // live candidates left in this tile
+    seg_cnt[blk].z = s_n;   // candidates of this tile
+    seg_cnt[blk].w = s_n;   // of which still live
   }
 }
 
+// ---------------------------------------------------------------------------------
+// NMS stage 3b: the greedy rule among the candidates
+// ---------------------------------------------------------------------------------
 // Parallel rounds of the greedy rule, one workgroup per tile.  Each iteration the tile
 //   0. re-reads its part of the global state map (tile + r halo) into LDS -- the map is only
 //      ever written with agent-scope stores, so selections and kills made by neighbouring
@@ -594,9 +605,10 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
 //      if it still stands it is selected: own word := 1, live words of its window := 0, in
 //      LDS and (agent scope) in the global map.
 // State only moves live -> selected | dead, so a word that is stale for an iteration only
-// postpones a decision.  A tile leaves when none of its candidates is live; tiles blocked on
-// a neighbour poll for a bounded number of iterations, what is left goes to the next launch
-// and finally to the sorted walk of nms_select_kernel.
+// postpones a decision; so step 0 is skipped while the tile is still deciding things on its
+// own.  A tile leaves when none of its candidates is live; tiles blocked on a neighbour poll
+// for a bounded number of iterations, what is left goes to the second launch, and what that
+// leaves (FINAL) joins the list as undecided entries for the sorted walk.
 constexpr int ROUND_ITERS = 24;
 
 __device__ __forceinline__ unsigned load_state(const unsigned* p) {
@@ -606,7 +618,7 @@ __device__ __forceinline__ void store_state(unsigned* p, unsigned v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int R_T>
+template <int R_T, bool FINAL>
 __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict__ sc, unsigned* alive,
                                                        uint4* __restrict__ seg_cnt,
                                                        const unsigned* __restrict__ seg_cand,
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   __shared__ unsigned short s_cell[SEG];         // LDS cell of candidate i
   __shared__ unsigned short s_pass[SEG];         // candidates that top their window this iteration
   __shared__ unsigned short s_sel[SEG];          // candidates selected in this launch
-  __shared__ unsigned s_npass, s_nsel;
+  __shared__ unsigned s_npass, s_nsel, s_prog;
   const unsigned blk = blockIdx.x;
   const unsigned n = seg_cnt[blk].z;
   const int tid = threadIdx.x;
@@ -635,11 +647,16 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     const int py = (int)(idx / (unsigned)W), px = (int)(idx - (unsigned)py * (unsigned)W);
     s_cell[i] = (unsigned short)((py - y0 + r) * LW + (px - x0 + r));
   }
-  if (tid == 0) s_nsel = 0;
+  if (tid == 0) {
+    s_nsel = 0;
+    s_prog = 0;
+  }
   __syncthreads();
+  bool reload = true;
   for (int iter = 0; iter < ROUND_ITERS; ++iter) {
     // ---- fresh copy of the tile's part of the state map ----
-    if (R_T > 0) {
+    if (!reload) {
+    } else if (R_T > 0) {
       constexpr int PER = ((CX + 2 * R_T) * (CY + 2 * R_T) + NT - 1) / NT;
       unsigned v[PER];
 #pragma unroll
@@ -713,7 +730,10 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     }
     __syncthreads();
     // ---- candidates whose word tops their window ----
-    if (tid == 0) s_npass = 0;
+    if (tid == 0) {
+      s_npass = 0;
+      s_prog = 0;
+    }
     __syncthreads();
     unsigned live = 0;
     for (unsigned i = tid; i < n; i += NT) {
@@ -757,6 +777,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
         if (lane == 0) {
           *c = 0u;
           store_state(alive + (size_t)py * W + px, 0u);
+          s_prog = 1;
         }
         continue;
       }
@@ -774,65 +795,49 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
         *c = 1u;
         store_state(alive + (size_t)py * W + px, 1u);
         s_sel[atomicAdd(&s_nsel, 1u)] = (unsigned short)cell;   // flushed to the global list at the end
+        s_prog = 1;
       }
     }
     __syncthreads();   // LDS and global updates of this iteration are complete before the reload
+    reload = s_prog == 0;   // nothing decided here: look at what the neighbours did
   }
-  // append this launch's selections to the global list: one atomic per tile
+  // append this launch's selections (and, in the last launch, what is still undecided) to the
+  // global list: one reservation per tile
   __syncthreads();
   {
     if (tid == 0) s_npass = 0;
     __syncthreads();
-    unsigned live = 0;
-    for (unsigned i = tid; i < n; i += NT) live += s_state[s_cell[i]] >= 3u ? 1u : 0u;
-    if (live) atomicAdd(&s_npass, live);
+    for (unsigned b0 = 0; b0 < n; b0 += NT) {
+      const unsigned i = b0 + tid;
+      const bool live = i < n && s_state[s_cell[i]] >= 3u;
+      const unsigned slot = wave_slot(live, &s_npass);
+      if (FINAL && live) s_pass[slot] = s_cell[i];
+    }
     __syncthreads();
     if (tid == 0) seg_cnt[blk].w = s_npass;
     __syncthreads();
   }
   const unsigned nsel = s_nsel;
-  if (nsel == 0) return;
-  if (tid == 0) s_npass = atomicAdd(&ctl->n_c, nsel);
+  const unsigned nrem = FINAL ? s_npass : 0u;
+  if (nsel + nrem == 0) return;
+  __syncthreads();
+  if (tid == 0) {
+    s_npass = atomicAdd(&ctl->n_c, nsel + nrem);
+    if (nrem) atomicAdd(&ctl->n_rem, nrem);
+  }
   __syncthreads();
   const unsigned base = s_npass;
-  for (unsigned k = tid; k < nsel; k += NT) {
-    const int cell = s_sel[k];
+  for (unsigned k = tid; k < nsel + nrem; k += NT) {
+    const bool und = k >= nsel;
+    const int cell = und ? s_pass[k - nsel] : s_sel[k];
     const int ly = cell / LW, lx = cell - ly * LW;
     const unsigned idx = (unsigned)(y0 - r + ly) * (unsigned)W + (unsigned)(x0 - r + lx);
     const unsigned pos = base + k;
     if (pos < cap_c) {
       keys_c[pos] = (unsigned long long)__double_as_longlong(sc[idx]);
-      idx_c[pos] = idx << 1;
+      idx_c[pos] = (idx << 2) | ENT_CAND | (und ? ENT_UNDECIDED : 0u);
     } else {
       ctl->overflow = 1;
-    }
-  }
-}
-
-// After the rounds: candidates still live join the list as undecided entries (bit 0 set);
-// every candidate's mark is cleared so the map is all-zero for the next call.
-__global__ __launch_bounds__(NT) void nms_collect_kernel(const double* __restrict__ sc, unsigned* alive,
-                                                         const uint4* __restrict__ seg_cnt,
-                                                         const unsigned* __restrict__ seg_cand,
-                                                         unsigned long long* __restrict__ keys_c,
-                                                         unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c) {
-  const unsigned blk = blockIdx.x;
-  const unsigned n = seg_cnt[blk].z;
-  const size_t seg0 = (size_t)blk * SEG;
-  for (unsigned i = threadIdx.x; i < n; i += NT) {
-    const unsigned idx = seg_cand[seg0 + i];
-    const unsigned a = alive[idx];
-    if (a == 0u) continue;
-    alive[idx] = 0u;
-    if (a >= 3u) {
-      atomicAdd(&ctl->n_rem, 1u);
-      const unsigned pos = atomicAdd(&ctl->n_c, 1u);
-      if (pos < cap_c) {
-        keys_c[pos] = (unsigned long long)__double_as_longlong(sc[idx]);
-        idx_c[pos] = (idx << 1) | 1u;
-      } else {
-        ctl->overflow = 1;
-      }
     }
   }
 }
@@ -846,19 +851,27 @@ constexpr int RK_BLOCKS = 1024;
 
 __device__ __forceinline__ bool prio_before(unsigned long long ka, unsigned ia, unsigned long long kb,
                                             unsigned ib) {
-  // higher score first; equal scores: lower flat index first (bit 0 is a flag, idx is unique)
+  // higher score first; equal scores: lower flat index first (the low bits are flags, idx is unique)
   return ka > kb || (ka == kb && ia < ib);
 }
 
+// Also returns the state map to all-zero for the next call (the candidates' marks are the only
+// words ever set in it).
 __global__ __launch_bounds__(NT) void nms_rank_kernel(const unsigned long long* __restrict__ keys_c,
                                                       const unsigned* __restrict__ idx_c, const nms_ctl* ctl,
-                                                      unsigned* __restrict__ rank) {
+                                                      unsigned* __restrict__ rank, unsigned* __restrict__ alive,
+                                                      const uint4* __restrict__ seg_cnt,
+                                                      const unsigned* __restrict__ seg_cand, unsigned nblk) {
   __shared__ unsigned long long s_k[RK_J];
   __shared__ unsigned s_i[RK_J];
+  const int tid = threadIdx.x;
+  for (unsigned tile = blockIdx.x; tile < nblk; tile += gridDim.x) {
+    const unsigned n = seg_cnt[tile].z;
+    for (unsigned i = tid; i < n; i += NT) alive[seg_cand[(size_t)tile * SEG + i]] = 0u;
+  }
   const unsigned M = ctl->n_c;
   if (ctl->n_rem != 0 || M > (unsigned)RANK_MAX) return;
   const unsigned ti = (M + RK_I - 1) / RK_I, tj = (M + RK_J - 1) / RK_J;
-  const int tid = threadIdx.x;
   for (unsigned tile = blockIdx.x; tile < ti * tj; tile += gridDim.x) {
     const unsigned i0 = (tile / tj) * RK_I, j0 = (tile % tj) * RK_J;
     __syncthreads();
@@ -878,10 +891,9 @@ __global__ __launch_bounds__(NT) void nms_rank_kernel(const unsigned long long* 
   }
 }
 
-constexpr int SEL_T = 1024;       // threads of the single-workgroup kernels
+constexpr int SEL_T = 1024;       // threads of the single-workgroup kernel
 constexpr int CHUNK = 8192;       // entries sorted in LDS at a time
 constexpr int MAX_N = 16384;      // keypoints
-constexpr int NMS_ROUNDS = 2;     // launches of the tile-local greedy rounds before the final stage
 
 __device__ __forceinline__ void write_keypoints(const unsigned* sel, unsigned nsel, unsigned edge, int W, int N,
                                                 double* __restrict__ kp_xy, float* __restrict__ kp_f32) {
@@ -904,32 +916,6 @@ __device__ __forceinline__ void write_keypoints(const unsigned* sel, unsigned ns
       kp_f32[2 * i + 1] = (float)y;
     }
   }
-}
-
-__global__ __launch_bounds__(SEL_T) void nms_emit_kernel(const unsigned* __restrict__ idx_c, nms_ctl* ctl,
-                                                         unsigned* __restrict__ rank, int W, int N, int r,
-                                                         unsigned* sel, double* __restrict__ kp_xy,
-                                                         float* __restrict__ kp_f32) {
-  __shared__ unsigned s_edge;
-  const unsigned M = ctl->n_c;
-  if (ctl->n_rem != 0 || M > (unsigned)RANK_MAX) return;
-  if (threadIdx.x == 0) s_edge = 0xffffffffu;
-  __syncthreads();
-  for (unsigned i = threadIdx.x; i < M; i += SEL_T) {
-    const unsigned rk = rank[i];
-    rank[i] = 0;
-    if (rk < (unsigned)N) {
-      const unsigned idx = idx_c[i] >> 1;
-      sel[rk] = idx;
-      const unsigned py = idx / (unsigned)W, px = idx - py * (unsigned)W;
-      if ((int)py < r || (int)px < r) atomicMin(&s_edge, rk);
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  const unsigned nsel = min(M, (unsigned)N);
-  write_keypoints(sel, nsel, s_edge, W, N, kp_xy, kp_f32);
-  if (threadIdx.x == 0) ctl->n_sel = nsel;
 }
 
 // ---------------------------------------------------------------------------------
@@ -957,19 +943,42 @@ __device__ void bitonic_lds_steps(unsigned long long* sk, unsigned* si, int n, u
   }
 }
 
-__global__ __launch_bounds__(SEL_T) void nms_select_kernel(unsigned long long* __restrict__ keys_c,
-                                                           unsigned* __restrict__ idx_c, nms_ctl* ctl,
-                                                           unsigned cap_pow2, int W, int N, int r,
-                                                           unsigned* __restrict__ sel,
-                                                           double* __restrict__ kp_xy,
-                                                           float* __restrict__ kp_f32) {
+// Last stage, one workgroup.  Usual case (nothing undecided, short list): the ranks are final,
+// the first N entries by rank are the keypoints.  Otherwise: sort + sequential walk.
+__global__ __launch_bounds__(SEL_T) void nms_finalize_kernel(unsigned long long* __restrict__ keys_c,
+                                                             unsigned* __restrict__ idx_c, nms_ctl* ctl,
+                                                             unsigned* __restrict__ rank,
+                                                             unsigned cap_pow2, int W, int N, int r,
+                                                             unsigned* __restrict__ sel,
+                                                             double* __restrict__ kp_xy,
+                                                             float* __restrict__ kp_f32) {
   __shared__ __align__(16) unsigned long long s_keys[CHUNK];   // 64 KiB
   __shared__ __align__(16) unsigned s_idx[CHUNK];              // 32 KiB
   __shared__ unsigned s_wsum[SEL_T / 64];
   __shared__ unsigned s_nsel, s_nsela, s_nalist, s_flag, s_edge;
   const int tid = threadIdx.x;
 
-  if (ctl->n_rem == 0 && ctl->n_c <= (unsigned)RANK_MAX) return;   // the rank/emit kernels handle this call
+  if (ctl->n_rem == 0 && ctl->n_c <= (unsigned)RANK_MAX) {
+    const unsigned Mr = ctl->n_c;
+    if (tid == 0) s_edge = 0xffffffffu;
+    __syncthreads();
+    for (unsigned i = tid; i < Mr; i += SEL_T) {
+      const unsigned rk = rank[i];
+      rank[i] = 0;   // all-zero again for the next call
+      if (rk < (unsigned)N) {
+        const unsigned idx = idx_c[i] >> 2;
+        sel[rk] = idx;
+        const unsigned py = idx / (unsigned)W, px = idx - py * (unsigned)W;
+        if ((int)py < r || (int)px < r) atomicMin(&s_edge, rk);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const unsigned nsel = min(Mr, (unsigned)N);
+    write_keypoints(sel, nsel, s_edge, W, N, kp_xy, kp_f32);
+    if (tid == 0) ctl->n_sel = nsel;
+    return;
+  }
   const unsigned M = min(ctl->n_c, cap_pow2);
   unsigned Mp = 1;
   while (Mp < M) Mp <<= 1;
@@ -1048,8 +1057,9 @@ __global__ __launch_bounds__(SEL_T) void nms_select_kernel(unsigned long long* _
     const unsigned j = base + tid;
     const bool valid = j < M;
     unsigned e = valid ? idx_c[j] : 0u;
-    const bool is_a = (e & 1u) != 0;
-    const unsigned idx = e >> 1;
+    const bool is_a = (e & ENT_UNDECIDED) != 0;            // still needs the greedy test
+    const bool is_cand = (e & (ENT_UNDECIDED | ENT_CAND)) != 0;   // once selected it suppresses later undecided entries
+    const unsigned idx = e >> 2;
     const int py = (int)(idx / (unsigned)W), px = (int)(idx - (unsigned)py * (unsigned)W);
     unsigned stat = !valid ? 2u : (is_a ? 0u : 1u);
     if (tid == 0) s_nalist = 0;
@@ -1070,15 +1080,17 @@ __global__ __launch_bounds__(SEL_T) void nms_select_kernel(unsigned long long* _
     __syncthreads();
     // ordered list of undecided A1 entries of this batch
     {
-      unsigned long long m = __ballot(stat == 0u);
+      // ... and of the candidates of this batch that are already selected: they suppress too
+      const bool listed = stat == 0u || (valid && is_cand && stat == 1u);
+      unsigned long long m = __ballot(listed);
       unsigned lane = tid & 63, wv = tid >> 6;
       unsigned before = __popcll(m & ((1ull << lane) - 1ull));
       if (lane == 0) s_wsum[wv] = __popcll(m);
       __syncthreads();
       unsigned off = 0;
       for (unsigned w = 0; w < wv; ++w) off += s_wsum[w];
-      if (stat == 0u) b_alist[off + before] = tid;
-      if (tid == SEL_T - 1) s_nalist = off + before + (stat == 0u ? 1u : 0u);
+      if (listed) b_alist[off + before] = tid;
+      if (tid == SEL_T - 1) s_nalist = off + before + (listed ? 1u : 0u);
       __syncthreads();
     }
     // resolve the undecided entries among themselves (rounds of the greedy rule)
@@ -1136,7 +1148,7 @@ __global__ __launch_bounds__(SEL_T) void nms_select_kernel(unsigned long long* _
           sel[pos] = idx;
           if (py < r || px < r) atomicMin(&s_edge, pos);   // reference: empty slice, no suppression
         }
-        if (is_a) {
+        if (is_cand) {
           unsigned q = atomicAdd(&s_nsela, 1u);
           if (q < (unsigned)MAX_N) s_sela[q] = (unsigned)px | ((unsigned)py << 16);
         }
@@ -1206,7 +1218,7 @@ int vo_harris_response_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int 
     static bool lds_opt_in = false;   // dynamic LDS above 64 KiB must be requested per kernel
     if (!lds_opt_in) {
       VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&harris_response_kernel<0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)response_lds_bytes(31)));
       lds_opt_in = true;
     }
     vo_prof_scope ps(ctx, VO_K_HARRIS_RESPONSE);
@@ -1243,8 +1255,8 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   VO_TRY(vo_ensure(ctx, ctx->nms_idx_c, (size_t)cap_c * 4));
   VO_TRY(vo_ensure(ctx, ctx->nms_sel, (size_t)MAX_N * 4));
   if (!ctx->nms_hist.p) {
-    VO_TRY(vo_ensure(ctx, ctx->nms_hist, (size_t)HIST_BINS * 4));
-    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_hist.p, 0, (size_t)HIST_BINS * 4, ctx->stream));
+    VO_TRY(vo_ensure(ctx, ctx->nms_hist, (size_t)HIST_TOTAL * 4));
+    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_hist.p, 0, (size_t)HIST_TOTAL * 4, ctx->stream));
   }
   if (!ctx->nms_rank.p) {
     VO_TRY(vo_ensure(ctx, ctx->nms_rank, (size_t)RANK_MAX * 4));
@@ -1256,8 +1268,7 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
     ctx->nms_alive_dirty = false;
   }
   VO_TRY(vo_ensure(ctx, ctx->nms_ctl, sizeof(nms_ctl)));
-  nms_ctl* ctl = (nms_ctl*)ctx->nms_ctl.p;
-  VO_HIP_TRY(ctx, hipMemsetAsync(ctl, 0, sizeof(nms_ctl), ctx->stream));
+  nms_ctl* ctl = (nms_ctl*)ctx->nms_ctl.p;   // its counters are reset by the threshold kernel
 
   unsigned long long* keys_l1 = (unsigned long long*)ctx->nms_keys_l1.p;
   unsigned long long* keys_a1 = (unsigned long long*)ctx->nms_keys_a1.p;
@@ -1274,10 +1285,11 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   {
     static bool lds_opt_in = false;   // dynamic LDS above 64 KiB must be requested per kernel
     if (!lds_opt_in) {
+      const int max_dyn = (int)candidates_lds_bytes(12);   // largest radius accepted above
       VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_candidates_kernel<5>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
       VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_candidates_kernel<0>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn));
       lds_opt_in = true;
     }
     vo_prof_scope ps(ctx, VO_K_NMS_CANDIDATES);
@@ -1292,54 +1304,48 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   VO_TRY(vo_check_launch(ctx, "nms_candidates_kernel"));
   {
     vo_prof_scope ps(ctx, VO_K_NMS_THRESHOLD);
-    hipLaunchKernelGGL(nms_threshold_kernel, dim3(1), dim3(1024), 0, st, hist, ctl, N);
+    hipLaunchKernelGGL(nms_threshold_kernel, dim3(1), dim3(256), 0, st, hist, ctl, N);
   }
   VO_TRY(vo_check_launch(ctx, "nms_threshold_kernel"));
   ctx->nms_alive_dirty = true;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_COMPACT);
     hipLaunchKernelGGL(nms_compact_kernel, dim3(nblk), dim3(NT), 0, st, keys_l1, idx_l1, keys_a1, idx_a1, segcnt,
-                       cand, keys_c, idx_c, alive, ctl, cap_c);
+                       cand, keys_c, idx_c, alive, ctl, cap_c, hist);
   }
   VO_TRY(vo_check_launch(ctx, "nms_compact_kernel"));
   const size_t round_lds = ((size_t)(CX + 2 * r) * (CY + 2 * r) + (size_t)(CY + 2 * r) * CX + (size_t)CY * CX) * 4;
-  for (int round = 0; round < NMS_ROUNDS; ++round) {
+  for (int round = 0; round < 2; ++round) {
     vo_prof_scope ps(ctx, VO_K_NMS_ROUND);
-    if (r == 5)
-      hipLaunchKernelGGL(nms_round_kernel<5>, dim3(nblk), dim3(NT), round_lds, st, d_scores, alive, segcnt, cand,
-                         keys_c, idx_c, ctl, cap_c, H, W, r, (int)grid.x);
+    const dim3 g(nblk), b(NT);
+    if (r == 5 && round == 0)
+      hipLaunchKernelGGL((nms_round_kernel<5, false>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
+                         idx_c, ctl, cap_c, H, W, r, (int)grid.x);
+    else if (r == 5)
+      hipLaunchKernelGGL((nms_round_kernel<5, true>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
+                         idx_c, ctl, cap_c, H, W, r, (int)grid.x);
+    else if (round == 0)
+      hipLaunchKernelGGL((nms_round_kernel<0, false>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
+                         idx_c, ctl, cap_c, H, W, r, (int)grid.x);
     else
-      hipLaunchKernelGGL(nms_round_kernel<0>, dim3(nblk), dim3(NT), round_lds, st, d_scores, alive, segcnt, cand,
-                         keys_c, idx_c, ctl, cap_c, H, W, r, (int)grid.x);
+      hipLaunchKernelGGL((nms_round_kernel<0, true>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
+                         idx_c, ctl, cap_c, H, W, r, (int)grid.x);
   }
   VO_TRY(vo_check_launch(ctx, "nms_round_kernel"));
   {
-    vo_prof_scope ps(ctx, VO_K_NMS_COLLECT);
-    hipLaunchKernelGGL(nms_collect_kernel, dim3(nblk), dim3(NT), 0, st, d_scores, alive, segcnt, cand, keys_c, idx_c,
-                       ctl, cap_c);
-  }
-  VO_TRY(vo_check_launch(ctx, "nms_collect_kernel"));
-  ctx->nms_alive_dirty = false;
-  {
-    // usual case: nothing undecided and a short list -> rank by counting, emit
+    // ranks for the usual case (nothing undecided, short list); returns the state map to all-zero
     vo_prof_scope ps(ctx, VO_K_NMS_RANK);
-    hipLaunchKernelGGL(nms_rank_kernel, dim3(RK_BLOCKS), dim3(NT), 0, st, keys_c, idx_c, ctl,
-                       rank);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3(RK_BLOCKS), dim3(NT), 0, st, keys_c, idx_c, ctl, rank, alive, segcnt,
+                       cand, nblk);
   }
   VO_TRY(vo_check_launch(ctx, "nms_rank_kernel"));
+  ctx->nms_alive_dirty = false;
   {
-    vo_prof_scope ps(ctx, VO_K_NMS_EMIT);
-    hipLaunchKernelGGL(nms_emit_kernel, dim3(1), dim3(SEL_T), 0, st, idx_c, ctl, rank, W, N, r,
-                       (unsigned*)ctx->nms_sel.p, d_kp_xy, ctx->nms_kp_f32);
-  }
-  VO_TRY(vo_check_launch(ctx, "nms_emit_kernel"));
-  {
-    // general case (exits at once when the rank path applied): sort + sequential walk
     vo_prof_scope ps(ctx, VO_K_NMS_SELECT);
-    hipLaunchKernelGGL(nms_select_kernel, dim3(1), dim3(SEL_T), 0, st, keys_c, idx_c, ctl, cap_c, W, N, r,
+    hipLaunchKernelGGL(nms_finalize_kernel, dim3(1), dim3(SEL_T), 0, st, keys_c, idx_c, ctl, rank, cap_c, W, N, r,
                        (unsigned*)ctx->nms_sel.p, d_kp_xy, ctx->nms_kp_f32);
   }
-  return vo_check_launch(ctx, "nms_select_kernel");
+  return vo_check_launch(ctx, "nms_finalize_kernel");
 }
 
 int vo_patch_descriptors_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, const double* d_kp_xy, int N,

@@ -19,8 +19,7 @@ struct vo_pipeline {
   vo_ctx* ctx = nullptr;
   vo_ctx* det = nullptr;            // second context (own stream + NMS workspace): detection runs beside tracking
   hipEvent_t evDetStart = nullptr, evDetDone = nullptr;
-  uint8_t* d_det_img = nullptr;     // detection input (the frame is copied here so the captured graph is frame-independent)
-  hipGraphExec_t det_graph[2] = {nullptr, nullptr};   // Harris + NMS into d_kp[0] / d_kp[1], captured once
+  std::vector<hipGraphExec_t> det_graph;   // Harris + NMS of frame f into d_kp[s]: entry 2 f + s, captured on first use
   bool det_warm = false;
   vo_pipeline_config cfg;
   int n_levels = 1;
@@ -268,7 +267,6 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     PA(dev_alloc(ctx, &p->d_kp[k], (size_t)N * 2));
   }
   PA(dev_alloc(ctx, &p->d_scores, px));
-  PA(dev_alloc(ctx, &p->d_det_img, px));
   PA(dev_alloc(ctx, &p->d_kp_f32[0], (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_kp_f32[1], (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_next_f32, (size_t)N * 2));
@@ -345,9 +343,9 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   (void)hipStreamSynchronize(p->ctx->stream);
   for (auto q : p->d_img) (void)hipFree(q);
   for (auto q : p->d_depth) (void)hipFree(q);
-  for (int k = 0; k < 2; ++k)
-    if (p->det_graph[k]) (void)hipGraphExecDestroy(p->det_graph[k]);
-  void* dev[] = {p->d_det_img, p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_kp_f32[0], p->d_kp_f32[1],
+  for (hipGraphExec_t g : p->det_graph)
+    if (g) (void)hipGraphExecDestroy(g);
+  void* dev[] = {p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_kp_f32[0], p->d_kp_f32[1],
                  p->d_next_f32, p->d_err, p->d_status, p->d_prev_c[0], p->d_next_c[0], p->d_land_c[0], p->d_prev_c[1],
                  p->d_next_c[1], p->d_land_c[1], p->d_tri,
                  p->d_ntracked, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks};
@@ -388,10 +386,10 @@ int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
 // by detect_join().  The ~15 launches are replayed from a hipGraph captured once per output
 // buffer (the host-side launch cost, not the kernels, was the bottleneck of the step); the
 // plain launch path is kept for the first call (allocations) and for per-kernel profiling.
-static int detect_launches(vo_pipeline* p, double* d_kp) {
+static int detect_launches(vo_pipeline* p, int frame, double* d_kp) {
   const vo_pipeline_config& c = p->cfg;
   p->det->nms_kp_f32 = p->d_kp_f32[d_kp == p->d_kp[0] ? 0 : 1];   // the tracker's float copy of the keypoints
-  int rc = vo_harris_response_dev(p->det, p->d_det_img, c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
+  int rc = vo_harris_response_dev(p->det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
   if (rc == VO_OK) rc = vo_nms_keypoints_dev(p->det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, d_kp);
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->det));
   return VO_OK;
@@ -406,17 +404,17 @@ static int detect(vo_pipeline* p, int frame, double* d_kp, bool after_main) {
     VO_HIP_TRY(ctx, hipEventRecord(p->evDetStart, ctx->stream));
     VO_HIP_TRY(ctx, hipStreamWaitEvent(ds, p->evDetStart, 0));
   }
-  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_det_img, p->d_img[frame], (size_t)p->cfg.H * p->cfg.W, hipMemcpyDeviceToDevice, ds));
-  const int slot = d_kp == p->d_kp[0] ? 0 : 1;
+  const int slot = 2 * frame + (d_kp == p->d_kp[0] ? 0 : 1);
+  if (p->det_graph.empty()) p->det_graph.assign((size_t)2 * p->cfg.n_frames, nullptr);
   static const bool no_graph = getenv("VO_NO_GRAPH") != nullptr;
   if (!p->det_warm || ctx->prof_on || no_graph) {
-    VO_TRY(detect_launches(p, d_kp));
+    VO_TRY(detect_launches(p, frame, d_kp));
     p->det_warm = true;
   } else {
     if (!p->det_graph[slot]) {
       hipGraph_t g = nullptr;
       VO_HIP_TRY(ctx, hipStreamBeginCapture(ds, hipStreamCaptureModeThreadLocal));
-      const int rc = detect_launches(p, d_kp);
+      const int rc = detect_launches(p, frame, d_kp);
       const hipError_t e = hipStreamEndCapture(ds, &g);
       if (rc != VO_OK) {
         if (g) (void)hipGraphDestroy(g);
