@@ -311,6 +311,308 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
   }
 }
 
+// ---------------------------------------------------------------------------------
+// 15x15 windows: one DPP row of 16 lanes per keypoint, four keypoints per wavefront
+// ---------------------------------------------------------------------------------
+// The kernel above spends most of its issue slots on work that is uniform per keypoint
+// (window position, bilinear weights, the 2x2 solve, the reduction tree), replicated over the
+// 64 lanes of a wave and paid once per keypoint.  Here a keypoint owns 16 lanes: lane r holds
+// window row r -- the 16 source bytes of the row come from LDS in one read, the template row
+// (patch value, Ix, Iy for 15 pixels) stays in registers for all iterations, the derivative
+// row below is fetched from the neighbouring lane with a DPP row shift, and the window sums
+// are four DPP adds inside the row.  The uniform work is now shared by four keypoints.
+// Same arithmetic, in the same order per keypoint, as klt_track_kernel (integer sums are
+// exact, so their order is free).
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+typedef short v2i16 __attribute__((ext_vector_type(2)));
+typedef unsigned u32_any __attribute__((aligned(1)));
+typedef unsigned short u16_any __attribute__((aligned(1)));
+
+constexpr int K16_PITCH = 24;                   // LDS bytes per staged row
+constexpr int K16_SLICE = K16_PITCH * 24;       // LDS bytes per keypoint (24 rows)
+
+__device__ __forceinline__ int row_sum_i32(int v) {   // sum over the 16 lanes of a row, in all of them
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+  return v;
+}
+// exact sum of per-lane 32-bit partials (two 16-bit limbs), as a double (|sum| < 2^53)
+__device__ __forceinline__ double row_sum_exact(int v) {
+  const int lo = row_sum_i32(v & 0xffff);
+  const int hi = row_sum_i32(v >> 16);
+  return (double)hi * 65536.0 + (double)lo;
+}
+
+__device__ __forceinline__ int byte_at(const unsigned* w, int c) { return (int)((w[c >> 2] >> ((c & 3) * 8)) & 0xffu); }
+// (byte c) | (byte c+1) << 16 of a little-endian word array
+__device__ __forceinline__ unsigned pair_at(const unsigned* w, int c) {
+  const int k = c >> 2, b = c & 3;
+  const unsigned sel = (unsigned)b | 0x0c00u | ((unsigned)(b + 1) << 16) | 0x0c000000u;
+  return __builtin_amdgcn_perm(b == 3 ? w[k + 1] : 0u, w[k], sel);   // byte index 4 = first byte of the next word
+}
+__device__ __forceinline__ int udot2(unsigned a, unsigned b, int c) {
+  return (int)__builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a), __builtin_bit_cast(v2u16, b), (unsigned)c, false);
+}
+__device__ __forceinline__ int sdot2(unsigned a, unsigned b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2i16, a), __builtin_bit_cast(v2i16, b), c, false);
+}
+
+// rows [0, NR) x bytes [0, NC) of the image block whose top-left pixel is (x0, y0) -> s, pitch
+// K16_PITCH.  NC is 18 or 24; lane r takes rows r and r + 16.
+template <int NC, int NR>
+__device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int H, int W, int x0, int y0, uint8_t* s,
+                                        int r) {
+  const bool inside = x0 >= 0 && y0 >= 0 && x0 + NC <= W && y0 + NR <= H;
+  if (inside) {
+    unsigned v[2][6];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = r + 16 * pass;
+      const bool on = row < NR;
+      const uint8_t* src = img + (size_t)(y0 + (on ? row : 0)) * W + x0;
+#pragma unroll
+      for (int k = 0; k < NC / 4; ++k) v[pass][k] = *(const u32_any*)(src + 4 * k);
+      if (NC & 2) v[pass][NC / 4] = *(const u16_any*)(src + (NC & ~3));
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = r + 16 * pass;
+      if (row < NR) {
+        unsigned* d = reinterpret_cast<unsigned*>(s + row * K16_PITCH);
+#pragma unroll
+        for (int k = 0; k < (NC + 3) / 4; ++k) d[k] = v[pass][k];
+      }
+    }
+  } else {
+    // border: reflect-101 per pixel (rare)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = r + 16 * pass;
+      if (row < NR) {
+        const uint8_t* src = img + (size_t)reflect101(y0 + row, H) * W;
+        uint8_t v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = src[reflect101(x0 + c, W)];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s[row * K16_PITCH + c] = v[c];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, int max_iter,
+                                                         double eps2, float min_eig_thr, float* __restrict__ next_xy,
+                                                         uint8_t* __restrict__ status, float* __restrict__ err) {
+  __shared__ __align__(16) uint8_t smem[4 * K16_SLICE];
+  constexpr int win = 15, ww = 225, RS = 24;
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * 4 + (lane >> 4);
+  if (i >= N) return;                                  // a whole row of lanes leaves together
+  const int r = lane & 15;                             // window row of this lane (row 15 only feeds row 14's derivatives)
+  uint8_t* s_reg = smem + (lane >> 4) * K16_SLICE;
+  const int live = r < win ? 1 : 0;
+  const int rr = r < win ? r : win - 1;                // row whose pixels this lane reads in the search loop
+
+  const float half = (float)(win - 1) * 0.5f;
+  const float FLT_SCALE = 1.f / (float)(1 << 20);
+  const float p0x = prev_xy[2 * i], p0y = prev_xy[2 * i + 1];
+  bool ok = true;
+  float e_out = 0.f;
+  float nx = 0.f, ny = 0.f;
+
+  for (int level = P.n_levels - 1; level >= 0; --level) {
+    const uint8_t* I = P.prev[level];
+    const uint8_t* J = P.next[level];
+    const int H = P.H[level], W = P.W[level];
+    const float sc = (float)(1. / (double)(1 << level));
+    float px = p0x * sc, py = p0y * sc;
+    float qx, qy;
+    if (level == P.n_levels - 1) {
+      qx = px;
+      qy = py;
+    } else {
+      qx = nx * 2.f;
+      qy = ny * 2.f;
+    }
+    nx = qx;
+    ny = qy;
+    px -= half;
+    py -= half;
+    const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+    if (ipx < -win || ipx >= W || ipy < -win || ipy >= H) {
+      if (level == 0) {
+        ok = false;
+        e_out = 0.f;
+      }
+      continue;
+    }
+    int w00, w01, w10, w11;
+    bilinear_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
+    unsigned wa = (unsigned)w00 | ((unsigned)w01 << 16), wb = (unsigned)w10 | ((unsigned)w11 << 16);
+
+    // ---- template: image block, Scharr derivatives, interpolated patch (all in registers) ----
+    wave_sync();
+    stage16<18, 18>(I, H, W, ipx - 1, ipy - 1, s_reg, r);
+    wave_sync();
+    int tI[win], tX[win], tY[win];
+    int a11 = 0, a12 = 0, a22 = 0;   // per-lane partial sums stay below 2^31
+    {
+      unsigned A0[5], A1[5], A2[5];   // block rows r, r+1, r+2 (18 bytes each): the rows around derivative row r
+      {
+        const unsigned* q0 = reinterpret_cast<const unsigned*>(s_reg + r * K16_PITCH);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          A0[k] = q0[k];
+          A1[k] = q0[k + K16_PITCH / 4];
+          A2[k] = q0[k + 2 * (K16_PITCH / 4)];
+        }
+      }
+      int cs[18], cd[18];             // per column: 3 (a0 + a2) + 10 a1, a2 - a0
+#pragma unroll
+      for (int c = 0; c < 18; ++c) {
+        const int b0 = byte_at(A0, c), b1 = byte_at(A1, c), b2 = byte_at(A2, c);
+        cs[c] = (b0 + b2) * 3 + b1 * 10;
+        cd[c] = b2 - b0;
+      }
+      const int gy = ipy + r;
+      const bool row_in = gy >= 0 && gy < H;
+      unsigned der[16], dern[16];     // (dx & 0xffff) | dy << 16 of derivative rows r and r + 1
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int gx = ipx + x;
+        int dx = cs[x + 2] - cs[x];
+        int dy = (cd[x + 2] + cd[x]) * 3 + cd[x + 1] * 10;
+        if (!(row_in && gx >= 0 && gx < W)) {
+          dx = 0;
+          dy = 0;
+        }
+        der[x] = ((unsigned)dx & 0xffffu) | ((unsigned)dy << 16);
+      }
+#pragma unroll
+      for (int x = 0; x < 16; ++x)
+        dern[x] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)der[x], 0x101, 0xF, 0xF, true);   // row_shl:1: lane r reads r + 1
+#pragma unroll
+      for (int x = 0; x < win; ++x) {
+        const int ival = udot2(pair_at(A1, x + 1), wa, udot2(pair_at(A2, x + 1), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        const unsigned dxa = __builtin_amdgcn_perm(der[x + 1], der[x], 0x05040100u);
+        const unsigned dya = __builtin_amdgcn_perm(der[x + 1], der[x], 0x07060302u);
+        const unsigned dxb = __builtin_amdgcn_perm(dern[x + 1], dern[x], 0x05040100u);
+        const unsigned dyb = __builtin_amdgcn_perm(dern[x + 1], dern[x], 0x07060302u);
+        const int ix = live * (sdot2(dxa, wa, sdot2(dxb, wb, 1 << (W_BITS - 1))) >> W_BITS);
+        const int iy = live * (sdot2(dya, wa, sdot2(dyb, wb, 1 << (W_BITS - 1))) >> W_BITS);
+        tI[x] = ival;
+        tX[x] = ix;
+        tY[x] = iy;
+        a11 += ix * ix;
+        a12 += ix * iy;
+        a22 += iy * iy;
+      }
+    }
+    const float A11 = (float)row_sum_exact(a11) * FLT_SCALE;
+    const float A12 = (float)row_sum_exact(a12) * FLT_SCALE;
+    const float A22 = (float)row_sum_exact(a22) * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww);
+    if (minEig < min_eig_thr || D < 1.1920929e-07f) {
+      if (level == 0) ok = false;
+      continue;
+    }
+    D = 1.f / D;
+    qx -= half;
+    qy -= half;
+    float pdx = 0.f, pdy = 0.f;
+    // search region of `next`: staged once with KLT_MARGIN pixels of slack, re-staged
+    // only when the window walks out of it
+    int rx0 = 0, ry0 = 0;
+    bool staged = false;
+    for (int j = 0; j < max_iter; ++j) {
+      const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+      if (iqx < -win || iqx >= W || iqy < -win || iqy >= H) {
+        if (level == 0) ok = false;
+        break;
+      }
+      bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
+      wa = (unsigned)w00 | ((unsigned)w01 << 16);
+      wb = (unsigned)w10 | ((unsigned)w11 << 16);
+      if (!staged || iqx < rx0 || iqy < ry0 || iqx + 16 > rx0 + RS || iqy + 16 > ry0 + RS) {
+        rx0 = iqx - KLT_MARGIN;
+        ry0 = iqy - KLT_MARGIN;
+        wave_sync();
+        stage16<24, 24>(J, H, W, rx0, ry0, s_reg, r);
+        wave_sync();
+        staged = true;
+      }
+      const uint8_t* base = s_reg + (iqy - ry0 + rr) * K16_PITCH + (iqx - rx0);
+      unsigned B0[4], B1[4];
+      __builtin_memcpy(B0, base, 16);
+      __builtin_memcpy(B1, base + K16_PITCH, 16);
+      int b1 = 0, b2 = 0;
+#pragma unroll
+      for (int x = 0; x < win; ++x) {
+        const int jv = udot2(pair_at(B0, x), wa, udot2(pair_at(B1, x), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        const int diff = jv - tI[x];
+        b1 += diff * tX[x];
+        b2 += diff * tY[x];
+      }
+      const float fb1 = (float)row_sum_exact(b1) * FLT_SCALE;
+      const float fb2 = (float)row_sum_exact(b2) * FLT_SCALE;
+      const float ddx = (A12 * fb2 - A22 * fb1) * D;
+      const float ddy = (A12 * fb1 - A11 * fb2) * D;
+      qx += ddx;
+      qy += ddy;
+      nx = qx + half;
+      ny = qy + half;
+      if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= eps2) break;
+      if (j > 0 && fabsf(ddx + pdx) < 0.01f && fabsf(ddy + pdy) < 0.01f) {
+        nx -= ddx * 0.5f;
+        ny -= ddy * 0.5f;
+        break;
+      }
+      pdx = ddx;
+      pdy = ddy;
+    }
+    if (ok && level == 0) {
+      const float ex = nx - half, ey = ny - half;
+      const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+      if (iex < -win || iex >= W || iey < -win || iey >= H) {
+        ok = false;
+        continue;
+      }
+      bilinear_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);
+      wa = (unsigned)w00 | ((unsigned)w01 << 16);
+      wb = (unsigned)w10 | ((unsigned)w11 << 16);
+      if (!staged || iex < rx0 || iey < ry0 || iex + 16 > rx0 + RS || iey + 16 > ry0 + RS) {
+        rx0 = iex - KLT_MARGIN;
+        ry0 = iey - KLT_MARGIN;
+        wave_sync();
+        stage16<24, 24>(J, H, W, rx0, ry0, s_reg, r);
+        wave_sync();
+        staged = true;
+      }
+      const uint8_t* base = s_reg + (iey - ry0 + rr) * K16_PITCH + (iex - rx0);
+      unsigned B0[4], B1[4];
+      __builtin_memcpy(B0, base, 16);
+      __builtin_memcpy(B1, base + K16_PITCH, 16);
+      int sabs = 0;
+#pragma unroll
+      for (int x = 0; x < win; ++x) {
+        const int jv = udot2(pair_at(B0, x), wa, udot2(pair_at(B1, x), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        const int diff = jv - tI[x];
+        sabs += diff < 0 ? -diff : diff;
+      }
+      e_out = (float)row_sum_i32(live * sabs) / (float)(32 * ww);
+    }
+  }
+  if (r == 0) {
+    next_xy[2 * i] = nx;
+    next_xy[2 * i + 1] = ny;
+    status[i] = ok ? 1 : 0;
+    err[i] = e_out;
+  }
+}
+
 size_t klt_lds_bytes(int win) {
   const int n1 = win + 1, n3 = win + 3, RS = n1 + 2 * KLT_MARGIN;
   const int reg = n3 * n3 > RS * RS ? n3 * n3 : RS * RS;
@@ -409,8 +711,8 @@ int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_p
     const dim3 kgrid(vo_cdiv(N, KLT_WAVES)), kblock(64 * KLT_WAVES);
     switch (win) {
       case 15:
-        hipLaunchKernelGGL(klt_track_kernel<15>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
-                           me, d_next_xy, d_status, d_err, lds_wave);
+        hipLaunchKernelGGL(klt_track16_kernel, dim3(vo_cdiv(N, 4)), dim3(64), 0, st, P, d_prev_xy, N, max_iter,
+                           eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 17:
         hipLaunchKernelGGL(klt_track_kernel<17>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,

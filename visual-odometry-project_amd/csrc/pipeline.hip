@@ -11,6 +11,8 @@
 //   host:  spins on a sequence word the mirror kernel publishes in mapped memory, replays the
 //          sequential RANSAC rule over (valid, count), takes the winning pose; the DLT of this
 //          step is queued at the start of the next one (or by fetch/export, whichever is first).
+#include <time.h>
+
 #include "vo_internal.h"
 
 #pragma clang fp contract(off)
@@ -72,6 +74,10 @@ struct vo_pipeline {
   bool seeded = false;
   // last step
   int last_ntracked = 0, last_best = -1, last_words = 0;
+  // VO_DEBUG_TIMING=1: host-side view of a step, printed by vo_pipeline_destroy
+  long dbg_steps = 0, dbg_det_late = 0;
+  double dbg_t[4] = {0, 0, 0, 0};   // entry->enqueued, enqueued->results, results->return, return->next entry
+  double dbg_last_return = 0;
 };
 
 namespace {
@@ -339,6 +345,10 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
 
 void vo_pipeline_destroy(vo_pipeline* p) {
   if (!p) return;
+  if (p->dbg_steps > 0)
+    fprintf(stderr, "[vo_pipeline] %ld steps: enqueue %.1f us, wait %.1f us, replay %.1f us, between steps %.1f us; "
+            "detection still running at step entry in %ld steps\n", p->dbg_steps, p->dbg_t[0] / p->dbg_steps,
+            p->dbg_t[1] / p->dbg_steps, p->dbg_t[2] / p->dbg_steps, p->dbg_t[3] / p->dbg_steps, p->dbg_det_late);
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
   for (auto q : p->d_img) (void)hipFree(q);
@@ -493,6 +503,18 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   const bool seq_sampler = getenv("VO_SEQ_SAMPLER") != nullptr;   // test hook: always take the sequential path
   memset(out, 0, sizeof(*out));
   out->best_index = -1;
+  static const bool dbg = getenv("VO_DEBUG_TIMING") != nullptr;
+  auto now = []() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+  };
+  double t_entry = 0, t_enq = 0, t_res = 0;
+  if (dbg) {
+    t_entry = now();
+    if (hipEventQuery(p->evDetDone) == hipErrorNotReady) ++p->dbg_det_late;
+    if (p->dbg_last_return > 0) p->dbg_t[3] += t_entry - p->dbg_last_return;
+  }
 
   // ---- tracking + hypotheses, enqueued back to back ----
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
@@ -525,7 +547,9 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   VO_TRY(flush_dlt(p));
   VO_TRY(detect(p, next_idx, p->d_kp[b], false));
 
+  if (dbg) t_enq = now();
   VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
+  if (dbg) t_res = now();
   const int n = ((volatile int32_t*)p->h_ntracked)[0];
   const bool redo = ((volatile int32_t*)p->h_ntracked)[2] != 0 || seq_sampler;
   out->n_tracked = n;
@@ -603,6 +627,14 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   }
   p->cur = b;
   p->prev_frame = next_idx;
+  if (dbg) {
+    const double t_ret = now();
+    p->dbg_t[0] += t_enq - t_entry;
+    p->dbg_t[1] += t_res - t_enq;
+    p->dbg_t[2] += t_ret - t_res;
+    p->dbg_last_return = t_ret;
+    ++p->dbg_steps;
+  }
   return VO_OK;
 }
 
