@@ -45,10 +45,12 @@ __device__ __forceinline__ bool rotate_pair(double (&A)[6][4], double (&V)[4][4]
   return true;
 }
 
-__global__ __launch_bounds__(128) void dlt_kernel(const double* __restrict__ x1, const double* __restrict__ x2, int n,
+__global__ __launch_bounds__(128) void dlt_kernel(const double* __restrict__ x1, const double* __restrict__ x2, int n_arg,
+                                                  const int* __restrict__ d_n,
                                                   const double* __restrict__ C1, int c1_per_point,
                                                   const double* __restrict__ C2, double* __restrict__ Xout) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = d_n ? min(*d_n, n_arg) : n_arg;   // point count given, or read on the device (pipeline)
   if (i >= n) return;
   const double* c1 = C1 + (c1_per_point ? (size_t)12 * i : 0);
   double A[6][4], V[4][4];
@@ -115,6 +117,20 @@ __global__ __launch_bounds__(128) void dlt_kernel(const double* __restrict__ x1,
 
 }  // namespace
 
+// Pipeline-internal form: at most n_cap points, the actual count is read from *d_n when the
+// kernel runs (so it can be enqueued, or captured in a graph, before the count exists).
+int vo_triangulate_dlt_ndev(vo_ctx* ctx, const double* d_x1, const double* d_x2, const int32_t* d_n, int n_cap,
+                            const double* d_C1, const double* d_C2, double* d_X) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, d_x1 && d_x2 && d_n && d_C1 && d_C2 && d_X && n_cap >= 1, "triangulate_dlt_n: bad arguments");
+  {
+    vo_prof_scope ps(ctx, VO_K_DLT);
+    hipLaunchKernelGGL(dlt_kernel, dim3(vo_cdiv(n_cap, 128)), dim3(128), 0, ctx->stream, d_x1, d_x2, n_cap, d_n, d_C1,
+                       0, d_C2, d_X);
+  }
+  return vo_check_launch(ctx, "dlt_kernel");
+}
+
 extern "C" {
 
 int vo_triangulate_dlt_dev(vo_ctx* ctx, const double* d_x1, const double* d_x2, int n, const double* d_C1,
@@ -126,8 +142,8 @@ int vo_triangulate_dlt_dev(vo_ctx* ctx, const double* d_x1, const double* d_x2, 
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   {
     vo_prof_scope ps(ctx, VO_K_DLT);
-    hipLaunchKernelGGL(dlt_kernel, dim3(vo_cdiv(n, 128)), dim3(128), 0, ctx->stream, d_x1, d_x2, n, d_C1,
-                       c1_per_point ? 1 : 0, d_C2, d_X);
+    hipLaunchKernelGGL(dlt_kernel, dim3(vo_cdiv(n, 128)), dim3(128), 0, ctx->stream, d_x1, d_x2, n,
+                       (const int*)nullptr, d_C1, c1_per_point ? 1 : 0, d_C2, d_X);
   }
   return vo_check_launch(ctx, "dlt_kernel");
 }

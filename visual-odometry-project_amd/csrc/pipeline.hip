@@ -2,16 +2,22 @@
 // reference driver's steady-state loop (src/main.py:248-286) with every array kept in
 // HBM between stages.  See include/vo_hip.h for the stage list.
 //
-// Stream plan for one step (two HIP streams, one host wait):
-//   main:  pyramid(next) -> KLT -> gather/compact -> P3P solve -> P3P score -> mirror
-//          all enqueued back to back: the solve kernel derives its samples on the device from
-//          raw PCG64 outputs the host wrote to mapped memory while the KLT kernel ran, and
-//          reads the tracked count the gather left in HBM, so nothing waits for the host.
-//   det:   [DLT of the previous step] -> Harris response + NMS on next (a captured hipGraph)
+// Plan of one step (two branches, one host wait):
+//   tracking:  pyramid(next) -> KLT -> gather/compact -> P3P solve -> P3P score -> mirror
+//          enqueued back to back: the solve kernel derives its samples on the device from raw
+//          PCG64 outputs the host wrote to mapped memory beforehand, and reads the tracked
+//          count the gather left in HBM, so nothing waits for the host.
+//   detection: DLT of the previous step -> Harris response + NMS on next (feeds the next step)
 //   host:  spins on a sequence word the mirror kernel publishes in mapped memory, replays the
-//          sequential RANSAC rule over (valid, count), takes the winning pose; the DLT of this
-//          step is queued at the start of the next one (or by fetch/export, whichever is first).
+//          sequential RANSAC rule over (valid, count), takes the winning pose.
+// The two branches are enqueued by two host threads (the pipeline owns a worker for the
+// detection branch): with ~16 launches per step the host's launch cost, not the GPU, bounded
+// the step when one thread issued them all.  (A captured hipGraph per step was tried and is no
+// faster to launch on this runtime than the individual kernels.)
 #include <time.h>
+
+#include <atomic>
+#include <thread>
 
 #include "vo_internal.h"
 
@@ -20,8 +26,14 @@
 struct vo_pipeline {
   vo_ctx* ctx = nullptr;
   vo_ctx* det = nullptr;            // second context (own stream + NMS workspace): detection runs beside tracking
-  hipEvent_t evDetStart = nullptr, evDetDone = nullptr;
-  std::vector<hipGraphExec_t> det_graph;   // Harris + NMS of frame f into d_kp[s]: entry 2 f + s, captured on first use
+  hipEvent_t evDetDone = nullptr;   // recorded by the worker behind a step's detection branch
+  // detection worker: a mailbox the main thread posts (frame, buffers) to; it enqueues the branch
+  // on det->stream and records evDetDone
+  std::thread worker;
+  std::atomic<unsigned> job_posted{0}, job_done{0};
+  std::atomic<bool> quit{false};
+  struct { int frame, slot, prev_set; bool with_dlt; } job = {0, 0, 0, false};
+  int job_rc = 0;
   bool det_warm = false;
   vo_pipeline_config cfg;
   int n_levels = 1;
@@ -43,8 +55,7 @@ struct vo_pipeline {
   double *d_prev_c[2] = {nullptr, nullptr}, *d_next_c[2] = {nullptr, nullptr}, *d_land_c[2] = {nullptr, nullptr};
   double* d_tri = nullptr;
   int cset = 0;                      // set written by the last step
-  bool dlt_pending = false;          // the last step's DLT has not been enqueued yet
-  int dlt_n = 0, dlt_set = 0;
+  bool dlt_pending = false;          // the last step's DLT has not been enqueued yet (the next step does it)
   int32_t* d_ntracked = nullptr;
   double *d_R = nullptr, *d_t = nullptr;
   uint8_t* d_valid = nullptr;
@@ -75,7 +86,7 @@ struct vo_pipeline {
   // last step
   int last_ntracked = 0, last_best = -1, last_words = 0;
   // VO_DEBUG_TIMING=1: host-side view of a step, printed by vo_pipeline_destroy
-  long dbg_steps = 0, dbg_det_late = 0;
+  long dbg_steps = 0;
   double dbg_t[4] = {0, 0, 0, 0};   // entry->enqueued, enqueued->results, results->return, return->next entry
   double dbg_last_return = 0;
 };
@@ -94,8 +105,7 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
                                                              const double* __restrict__ T_wc,
                                                              double* __restrict__ prev_c, double* __restrict__ next_c,
                                                              double* __restrict__ land_c, int32_t* __restrict__ n_out,
-                                                             int32_t* __restrict__ n_out_host,
-                                                             unsigned* __restrict__ seq_host, unsigned seq) {
+                                                             int cs) {
   __shared__ int s_w[16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -136,9 +146,7 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
   if (tid == 0) {
     n_out[0] = s_base;
     n_out[2] = 0;           // "sampler needs the sequential path" flag of the solve kernel that follows
-    *n_out_host = s_base;   // mapped pinned host memory
-    __threadfence_system();
-    *seq_host = seq;
+    n_out[4 + cs] = s_base; // count of track set cs, for the DLT that runs during the next step
   }
 }
 
@@ -150,7 +158,8 @@ __global__ __launch_bounds__(256) void mirror_hypotheses_kernel(const uint8_t* _
                                                                 const double* __restrict__ t, int hyp,
                                                                 uint8_t* __restrict__ h_valid, int32_t* __restrict__ h_counts,
                                                                 double* __restrict__ h_R, double* __restrict__ h_t,
-                                                                unsigned* __restrict__ seq_host, unsigned seq,
+                                                                unsigned* __restrict__ seq_host,
+                                                                const unsigned* __restrict__ seq_expect,
                                                                 unsigned* __restrict__ done,
                                                                 const int32_t* __restrict__ n_flag,
                                                                 int32_t* __restrict__ h_n_flag) {
@@ -172,6 +181,7 @@ __global__ __launch_bounds__(256) void mirror_hypotheses_kernel(const uint8_t* _
     const unsigned prev = atomicAdd(done, 1u);
     if (prev == gridDim.x - 1) {       // last workgroup: everything above is visible to the host
       *done = 0;
+      const unsigned seq = *seq_expect;   // written by the host (mapped memory) before this launch
       __threadfence_system();
       *seq_host = seq;
     }
@@ -233,6 +243,9 @@ void k_times_rt(const double* K, const double* Rt34, double* C) {
 
 }  // namespace
 
+static void worker_main(vo_pipeline* p);
+static int worker_idle(vo_pipeline* p);
+
 extern "C" {
 
 int vo_klt_num_levels(int H, int W, int win, int max_level);
@@ -284,7 +297,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     PA(dev_alloc(ctx, &p->d_land_c[k], (size_t)N * 3));
   }
   PA(dev_alloc(ctx, &p->d_tri, (size_t)N * 3));
-  PA(dev_alloc(ctx, &p->d_ntracked, 4));
+  PA(dev_alloc(ctx, &p->d_ntracked, 8));
   PA(dev_alloc(ctx, &p->d_R, (size_t)Hyp * 9));
   PA(dev_alloc(ctx, &p->d_t, (size_t)Hyp * 3));
   PA(dev_alloc(ctx, &p->d_valid, (size_t)Hyp));
@@ -320,14 +333,13 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
 #undef PA
   if (rc == VO_OK && (hipEventCreateWithFlags(&p->evA, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evB, hipEventDisableTiming) != hipSuccess ||
-                      hipEventCreateWithFlags(&p->evDetStart, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evDetDone, hipEventDisableTiming) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   if (rc != VO_OK) {
     vo_pipeline_destroy(p);
     return rc;
   }
-  if (hipMemset(p->d_ntracked, 0, 16) != hipSuccess) {
+  if (hipMemset(p->d_ntracked, 0, 32) != hipSuccess) {
     vo_pipeline_destroy(p);
     return vo_set_error(ctx, VO_EHIP, "pipeline: hipMemset failed");
   }
@@ -339,6 +351,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   const int64_t k0 = vo_ransac_num_iterations(p->rs.confidence, p->rs.outlier_ratio, 4);
   p->rs.n_iterations = (p->rs.max_iterations >= 0 && p->rs.max_iterations < k0) ? p->rs.max_iterations : k0;
   memset(&p->rng, 0, sizeof(p->rng));
+  p->worker = std::thread(worker_main, p);
   *out = p;
   return VO_OK;
 }
@@ -346,15 +359,17 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
 void vo_pipeline_destroy(vo_pipeline* p) {
   if (!p) return;
   if (p->dbg_steps > 0)
-    fprintf(stderr, "[vo_pipeline] %ld steps: enqueue %.1f us, wait %.1f us, replay %.1f us, between steps %.1f us; "
-            "detection still running at step entry in %ld steps\n", p->dbg_steps, p->dbg_t[0] / p->dbg_steps,
-            p->dbg_t[1] / p->dbg_steps, p->dbg_t[2] / p->dbg_steps, p->dbg_t[3] / p->dbg_steps, p->dbg_det_late);
+    fprintf(stderr, "[vo_pipeline] %ld steps: enqueue %.1f us, wait %.1f us, replay %.1f us, between steps %.1f us\n",
+            p->dbg_steps, p->dbg_t[0] / p->dbg_steps, p->dbg_t[1] / p->dbg_steps, p->dbg_t[2] / p->dbg_steps,
+            p->dbg_t[3] / p->dbg_steps);
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
   for (auto q : p->d_img) (void)hipFree(q);
   for (auto q : p->d_depth) (void)hipFree(q);
-  for (hipGraphExec_t g : p->det_graph)
-    if (g) (void)hipGraphExecDestroy(g);
+  if (p->worker.joinable()) {
+    p->quit.store(true, std::memory_order_release);
+    p->worker.join();
+  }
   void* dev[] = {p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_kp_f32[0], p->d_kp_f32[1],
                  p->d_next_f32, p->d_err, p->d_status, p->d_prev_c[0], p->d_next_c[0], p->d_land_c[0], p->d_prev_c[1],
                  p->d_next_c[1], p->d_land_c[1], p->d_tri,
@@ -366,7 +381,6 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (q) (void)hipHostFree(q);
   if (p->evA) (void)hipEventDestroy(p->evA);
   if (p->evB) (void)hipEventDestroy(p->evB);
-  if (p->evDetStart) (void)hipEventDestroy(p->evDetStart);
   if (p->evDetDone) (void)hipEventDestroy(p->evDetDone);
   if (p->det) vo_destroy(p->det);
   delete p;
@@ -392,56 +406,108 @@ int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
   return VO_OK;
 }
 
-// Harris response + NMS of `frame` on the detection stream, joined back into the main stream
-// by detect_join().  The ~15 launches are replayed from a hipGraph captured once per output
-// buffer (the host-side launch cost, not the kernels, was the bottleneck of the step); the
-// plain launch path is kept for the first call (allocations) and for per-kernel profiling.
-static int detect_launches(vo_pipeline* p, int frame, double* d_kp) {
+// ---- launches of one step -----------------------------------------------------------------
+
+// detection branch: DLT of the previous step's tracks, then Harris response + NMS of `frame`
+static int enqueue_detection(vo_pipeline* p, int frame, int slot, int prev_set, bool with_dlt) {
   const vo_pipeline_config& c = p->cfg;
-  p->det->nms_kp_f32 = p->d_kp_f32[d_kp == p->d_kp[0] ? 0 : 1];   // the tracker's float copy of the keypoints
-  int rc = vo_harris_response_dev(p->det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
-  if (rc == VO_OK) rc = vo_nms_keypoints_dev(p->det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, d_kp);
-  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->det));
+  vo_ctx* det = p->det;
+  int rc = VO_OK;
+  // cameras are read from mapped host memory (set s is rewritten two steps later at the earliest),
+  // the point count from the word the gather kernel of that step left in HBM
+  if (with_dlt)
+    rc = vo_triangulate_dlt_ndev(det, p->d_prev_c[prev_set], p->d_next_c[prev_set], p->d_ntracked + 4 + prev_set,
+                                 c.n_keypoints, p->m_C + 24 * prev_set, p->m_C + 24 * prev_set + 12, p->d_tri);
+  det->nms_kp_f32 = p->d_kp_f32[slot];   // the tracker's float copy of the keypoints
+  if (rc == VO_OK)
+    rc = vo_harris_response_dev(det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
+  if (rc == VO_OK) rc = vo_nms_keypoints_dev(det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, p->d_kp[slot]);
+  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(det));
   return VO_OK;
 }
 
-static int detect(vo_pipeline* p, int frame, double* d_kp, bool after_main) {
+// tracking branch up to the mirror kernel (main stream)
+static void post_detection(vo_pipeline* p, int frame, int slot, int prev_set, bool with_dlt);
+
+static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, int b, int cs, int det_pos) {
   vo_ctx* ctx = p->ctx;
-  hipStream_t ds = p->det->stream;
-  p->det->prof_on = ctx->prof_on;
-  p->det->prof_kernel = ctx->prof_kernel;
-  if (after_main) {
-    VO_HIP_TRY(ctx, hipEventRecord(p->evDetStart, ctx->stream));
-    VO_HIP_TRY(ctx, hipStreamWaitEvent(ds, p->evDetStart, 0));
+  const vo_pipeline_config& c = p->cfg;
+  const int N = c.n_keypoints;
+  const double fx = c.K[0], fy = c.K[4], cx = c.K[2], cy = c.K[5];
+  VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
+                          p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
+                          p->d_next_f32, p->d_status, p->d_err));
+  if (det_pos == 1) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
+  {
+    vo_prof_scope ps(ctx, VO_K_GATHER);
+    hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->d_kp[a], p->d_next_f32,
+                       p->d_status, p->d_err, N, (float)c.klt_err_threshold, p->d_depth[prev_idx], c.H, c.W, fx, fy, cx,
+                       cy, p->d_T_wc + (size_t)prev_idx * 16, p->d_prev_c[cs], p->d_next_c[cs], p->d_land_c[cs],
+                       p->d_ntracked, cs);
   }
-  const int slot = 2 * frame + (d_kp == p->d_kp[0] ? 0 : 1);
-  if (p->det_graph.empty()) p->det_graph.assign((size_t)2 * p->cfg.n_frames, nullptr);
-  static const bool no_graph = getenv("VO_NO_GRAPH") != nullptr;
-  if (!p->det_warm || ctx->prof_on || no_graph) {
-    VO_TRY(detect_launches(p, frame, d_kp));
-    p->det_warm = true;
-  } else {
-    if (!p->det_graph[slot]) {
-      hipGraph_t g = nullptr;
-      VO_HIP_TRY(ctx, hipStreamBeginCapture(ds, hipStreamCaptureModeThreadLocal));
-      const int rc = detect_launches(p, frame, d_kp);
-      const hipError_t e = hipStreamEndCapture(ds, &g);
-      if (rc != VO_OK) {
-        if (g) (void)hipGraphDestroy(g);
-        return rc;
-      }
-      VO_HIP_TRY(ctx, e);
-      const hipError_t ei = hipGraphInstantiate(&p->det_graph[slot], g, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(g);
-      VO_HIP_TRY(ctx, ei);
+  VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
+  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], p->d_ntracked, N, c.K, p->m_raw, c.hyp,
+                                   c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks,
+                                   (uint32_t*)p->d_ntracked + 2));
+  return VO_OK;
+}
+
+static int launch_mirror(vo_pipeline* p, bool with_count) {
+  const vo_pipeline_config& c = p->cfg;
+  hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, p->ctx->stream, p->d_valid, p->d_counts, p->d_R,
+                     p->d_t, c.hyp, p->m_valid, p->m_counts, p->m_R, p->m_t, p->m_seq + 1, p->m_seq + 2,
+                     (unsigned*)p->d_ntracked + 1, with_count ? (const int32_t*)p->d_ntracked : (const int32_t*)nullptr,
+                     p->m_ntracked);
+  return vo_check_launch(p->ctx, "mirror_hypotheses_kernel");
+}
+
+// ---- detection worker ---------------------------------------------------------------------
+static void worker_main(vo_pipeline* p) {
+  (void)hipSetDevice(p->ctx->device);
+  unsigned seen = 0;
+  long idle = 0;
+  for (;;) {
+    const unsigned posted = p->job_posted.load(std::memory_order_acquire);
+    if (posted == seen) {
+      if (p->quit.load(std::memory_order_acquire)) return;
+      if (++idle < 200000) __builtin_ia32_pause();            // a step is ~150 us: stay hot between steps
+      else std::this_thread::sleep_for(std::chrono::microseconds(200));
+      continue;
     }
-    VO_HIP_TRY(ctx, hipGraphLaunch(p->det_graph[slot], ds));
+    idle = 0;
+    seen = posted;
+    int rc = enqueue_detection(p, p->job.frame, p->job.slot, p->job.prev_set, p->job.with_dlt);
+    if (rc == VO_OK && hipEventRecord(p->evDetDone, p->det->stream) != hipSuccess) rc = VO_EHIP;
+    p->job_rc = rc;
+    p->job_done.store(seen, std::memory_order_release);
   }
-  VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, ds));
+}
+
+// hands the detection branch of a step to the worker
+static void post_detection(vo_pipeline* p, int frame, int slot, int prev_set, bool with_dlt) {
+  p->det->prof_on = p->ctx->prof_on;
+  p->det->prof_kernel = p->ctx->prof_kernel;
+  p->job.frame = frame;
+  p->job.slot = slot;
+  p->job.prev_set = prev_set;
+  p->job.with_dlt = with_dlt;
+  p->job_posted.store(p->job_posted.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+}
+
+// waits (host) until the worker has enqueued everything it was given, evDetDone included
+static int worker_idle(vo_pipeline* p) {
+  const unsigned posted = p->job_posted.load(std::memory_order_relaxed);
+  while (p->job_done.load(std::memory_order_acquire) != posted) __builtin_ia32_pause();
+  if (p->job_rc != VO_OK) {
+    const int rc = p->job_rc;
+    p->job_rc = VO_OK;
+    return vo_set_error(p->ctx, rc, "detection branch: %s", vo_last_error(p->det));
+  }
   return VO_OK;
 }
 
 static int detect_join(vo_pipeline* p) {
+  VO_TRY(worker_idle(p));
   VO_HIP_TRY(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->evDetDone, 0));
   return VO_OK;
 }
@@ -455,37 +521,29 @@ int vo_pipeline_prime(vo_pipeline* p, int idx) {
   p->cur = 0;
   p->dlt_pending = false;
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[idx], p->cfg.H, p->cfg.W, p->n_levels, p->d_pyr[0]));
-  VO_TRY(detect(p, idx, p->d_kp[0], true));
+  VO_TRY(worker_idle(p));
+  post_detection(p, idx, 0, 0, false);
   VO_TRY(detect_join(p));
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   p->prev_frame = idx;
   return VO_OK;
 }
 
-// The DLT of the last step is enqueued lazily on the detection stream: it is not on the path
-// to the next pose, only fetch / export / the shared-map exchange read it.
+// The DLT of the last step normally runs at the start of the next one (it is not on the path to
+// the next pose); fetch / export, which read its result, run it now.
 static int flush_dlt(vo_pipeline* p) {
   if (!p->dlt_pending) return VO_OK;
   vo_ctx* ctx = p->ctx;
   p->dlt_pending = false;
+  VO_TRY(worker_idle(p));
   p->det->prof_on = ctx->prof_on;
   p->det->prof_kernel = ctx->prof_kernel;
-  const int s = p->dlt_set;
-  // cameras are read from mapped host memory (set s is rewritten two steps later at the earliest)
-  const int rc = vo_triangulate_dlt_dev(p->det, p->d_prev_c[s], p->d_next_c[s], p->dlt_n, p->m_C + 24 * s, 0,
-                                        p->m_C + 24 * s + 12, p->d_tri);
+  const int s = p->cset;
+  const int rc = vo_triangulate_dlt_ndev(p->det, p->d_prev_c[s], p->d_next_c[s], p->d_ntracked + 4 + s,
+                                         p->cfg.n_keypoints, p->m_C + 24 * s, p->m_C + 24 * s + 12, p->d_tri);
   if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->det));
   VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, p->det->stream));
   return VO_OK;
-}
-
-static int launch_mirror(vo_pipeline* p, unsigned seq, bool with_count) {
-  const vo_pipeline_config& c = p->cfg;
-  hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, p->ctx->stream, p->d_valid, p->d_counts, p->d_R,
-                     p->d_t, c.hyp, p->m_valid, p->m_counts, p->m_R, p->m_t, p->m_seq + 1, seq,
-                     (unsigned*)p->d_ntracked + 1, with_count ? (const int32_t*)p->d_ntracked : (const int32_t*)nullptr,
-                     p->m_ntracked);
-  return vo_check_launch(p->ctx, "mirror_hypotheses_kernel");
 }
 
 int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out) {
@@ -496,10 +554,8 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   VO_REQUIRE(ctx, prev_idx == p->prev_frame, "pipeline_step: prev frame %d is not the frame last processed (%d)",
              prev_idx, p->prev_frame);
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
   const int N = c.n_keypoints, a = p->cur, b = 1 - p->cur;
   const int cs = 1 - p->cset;                       // track set this step fills
-  const double fx = c.K[0], fy = c.K[4], cx = c.K[2], cy = c.K[5];
   const bool seq_sampler = getenv("VO_SEQ_SAMPLER") != nullptr;   // test hook: always take the sequential path
   memset(out, 0, sizeof(*out));
   out->best_index = -1;
@@ -512,40 +568,27 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   double t_entry = 0, t_enq = 0, t_res = 0;
   if (dbg) {
     t_entry = now();
-    if (hipEventQuery(p->evDetDone) == hipErrorNotReady) ++p->dbg_det_late;
     if (p->dbg_last_return > 0) p->dbg_t[3] += t_entry - p->dbg_last_return;
   }
 
-  // ---- tracking + hypotheses, enqueued back to back ----
-  VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
-  VO_TRY(detect_join(p));   // keypoints of `prev` (detected during the previous step)
-  VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
-                          p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
-                          p->d_next_f32, p->d_status, p->d_err));
-  const unsigned seq_a = ++p->seq;
-  {
-    vo_prof_scope ps(ctx, VO_K_GATHER);
-    hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, st, p->d_kp[a], p->d_next_f32, p->d_status,
-                       p->d_err, N, (float)c.klt_err_threshold, p->d_depth[prev_idx], c.H, c.W, fx, fy, cx, cy,
-                       p->d_T_wc + (size_t)prev_idx * 16, p->d_prev_c[cs], p->d_next_c[cs], p->d_land_c[cs],
-                       p->d_ntracked, p->m_ntracked, p->m_seq, seq_a);
-  }
-  VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
   // Generator outputs for the device-side sampler: drawn from a copy, the real generator
-  // advances by what the sequential rule consumes (below).  The KLT kernel is running meanwhile.
+  // advances by what the sequential rule consumes (below).
   vo_pcg64 g = p->rng;
   vo_rng_raw32(&g, 7 * c.hyp, p->h_raw);
-  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], p->d_ntracked, N, c.K, p->m_raw, c.hyp,
-                                   c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks,
-                                   (uint32_t*)p->d_ntracked + 2));
-  unsigned seq_b = ++p->seq;
-  VO_TRY(launch_mirror(p, seq_b, true));
+  const unsigned seq_b0 = ++p->seq;
+  p->h_seq[2] = seq_b0;                               // the mirror kernel publishes this value when it is done
 
-  // ---- the other stream: last step's DLT, then detection on the new frame (feeds the next step).
-  // The keypoint buffer it overwrites was last read by the previous step's tracking, which the
-  // host has already waited for. ----
-  VO_TRY(flush_dlt(p));
-  VO_TRY(detect(p, next_idx, p->d_kp[b], false));
+  // ---- all launches of the step: detection from the worker thread, tracking from this one ----
+  VO_TRY(worker_idle(p));
+  VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDetDone, 0));   // keypoints of `prev` (the last step's detection)
+  static const int det_pos = getenv("VO_DET_POS") ? atoi(getenv("VO_DET_POS")) : 0;
+  if (det_pos == 0) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
+  VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, det_pos));
+  VO_TRY(launch_mirror(p, true));
+  if (det_pos == 2) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
+  p->dlt_pending = false;
+  unsigned seq_b = seq_b0;
 
   if (dbg) t_enq = now();
   VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
@@ -569,10 +612,11 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     while (!finished) {
       if (!have_batch) {
         VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, p->h_samples));
+        seq_b = ++p->seq;
+        p->h_seq[2] = seq_b;
         VO_TRY(vo_p3p_hypotheses_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], n, c.K, p->m_samples, c.hyp, c.p3p_thr_sq,
                                      p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks));
-        seq_b = ++p->seq;
-        VO_TRY(launch_mirror(p, seq_b, false));
+        VO_TRY(launch_mirror(p, false));
         VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
         words = vo_cdiv(n, 64);
       }
@@ -607,7 +651,7 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     out->draws_consumed = total_consumed;
     out->hyp_valid = hyp_valid;
 
-    // ---- DLT triangulation of the tracked pairs: C1 = K T_cw(prev) (stream pose), C2 = K [R | t] ----
+    // ---- cameras for the DLT of the tracked pairs: C1 = K T_cw(prev) (stream pose), C2 = K [R | t] ----
     if (best_idx >= 0) {
       double Tcw[16], Rt[12];
       double* hC = p->h_C + 24 * cs;
@@ -621,8 +665,6 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
       }
       k_times_rt(c.K, Rt, hC + 12);
       p->dlt_pending = true;
-      p->dlt_n = n;
-      p->dlt_set = cs;
     }
   }
   p->cur = b;
@@ -664,6 +706,7 @@ int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64
   if (!p) return VO_EINVAL;
   double a = 0, b = 0;
   int64_t na = 0, nb = 0;
+  VO_TRY(worker_idle(p));
   VO_TRY(vo_prof_read(p->ctx, kernel_id, &a, &na));
   int rc = vo_prof_read(p->det, kernel_id, &b, &nb);
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->det));
@@ -674,6 +717,7 @@ int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64
 
 int vo_pipeline_prof_reset(vo_pipeline* p) {
   if (!p) return VO_EINVAL;
+  VO_TRY(worker_idle(p));
   VO_TRY(vo_prof_reset(p->ctx));
   return vo_prof_reset(p->det);
 }

@@ -22,6 +22,11 @@ struct vo_prof_slot {
   int64_t launches = 0;
 };
 
+struct vo_prof_pair {
+  int k;
+  hipEvent_t a, b;
+};
+
 struct vo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -33,7 +38,7 @@ struct vo_ctx {
   int prof_kernel = -1;
   vo_prof_slot prof[VO_K_COUNT];
   std::vector<hipEvent_t> ev_free;
-  struct pending_ev { int k; hipEvent_t a, b; };
+  typedef vo_prof_pair pending_ev;
   std::vector<pending_ev> ev_pending;
 
   // workspace (device)
@@ -99,3 +104,6 @@ int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x,
                               double* d_t, uint8_t* d_valid, int32_t* d_counts, uint64_t* d_masks, uint32_t* d_flag);
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
 void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
+// DLT with a device-resident point count (dlt.hip)
+int vo_triangulate_dlt_ndev(vo_ctx* ctx, const double* d_x1, const double* d_x2, const int32_t* d_n, int n_cap,
+                            const double* d_C1, const double* d_C2, double* d_X);
