@@ -172,16 +172,21 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
                                                        int Hyp, double fx,
                                                        double fy, double cx, double cy, double* __restrict__ Rout,
                                                        double* __restrict__ tout, uint8_t* __restrict__ valid) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= Hyp) return;
+  // four lanes (a DPP quad) per hypothesis: the set-up and the quartic are computed by all four,
+  // then lane `sub` takes root `sub` through the triad alignment and the fourth-point test
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = gt >> 2, sub = gt & 3;
+  if (h >= Hyp) return;                 // whole quads leave together
   int sidx[4];
   if (RAW) {
     const int n = *d_n;
     if (n < 8) {
-      if (h == 0) atomicOr(flag, 1u);
-      for (int k = 0; k < 9; ++k) Rout[9 * h + k] = 0.0;
-      for (int k = 0; k < 3; ++k) tout[3 * h + k] = 0.0;
-      valid[h] = 0;
+      if (gt == 0) atomicOr(flag, 1u);
+      if (sub == 0) {
+        for (int k = 0; k < 9; ++k) Rout[9 * h + k] = 0.0;
+        for (int k = 0; k < 3; ++k) tout[3 * h + k] = 0.0;
+        valid[h] = 0;
+      }
       return;
     }
     unsigned rw[7];
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
         if (q == j) sidx[q] = vi;
       sidx[i] = vj;
     }
-    if (risky) atomicOr(flag, 1u);
+    if (risky && sub == 0) atomicOr(flag, 1u);
   } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) sidx[k] = samples[4 * h + k];
@@ -261,23 +266,27 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
     const double q0 = n0 * n0 - tc * nd0 + w0 * dd0;
     double roots[4];
     const int nr = quartic_roots(q0, q1, q2, q3, q4, roots);
-    for (int i = 0; i < nr; ++i) {
-      const double v = roots[i];
-      if (!(v > 0.0)) continue;
+    do {
+      if (sub >= nr) break;
+      double v = roots[0];
+      if (sub == 1) v = roots[1];
+      if (sub == 2) v = roots[2];
+      if (sub == 3) v = roots[3];
+      if (!(v > 0.0)) break;
       const double Dd = e1 * v + e0;
-      if (fabs(Dd) < 1e-12) continue;
+      if (fabs(Dd) < 1e-12) break;
       const double Nn = (n2 * v + n1) * v + n0;
       const double u = Nn / Dd;
-      if (!(u > 0.0)) continue;
+      if (!(u > 0.0)) break;
       const double qv = (v - 2.0 * c13) * v + 1.0;
-      if (!(qv > 0.0)) continue;
+      if (!(qv > 0.0)) break;
       const double s1 = sqrt(d13s / qv);
       const double s2 = u * s1, s3 = v * s1;
       const double C1[3] = {s1 * f[0][0], s1 * f[0][1], s1 * f[0][2]};
       const double C2[3] = {s2 * f[1][0], s2 * f[1][1], s2 * f[1][2]};
       const double C3[3] = {s3 * f[2][0], s3 * f[2][1], s3 * f[2][2]};
       double Ec[9];
-      if (!frame_of(C1, C2, C3, Ec)) continue;
+      if (!frame_of(C1, C2, C3, Ec)) break;
       double R[9], t[3];
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
@@ -285,18 +294,49 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
       for (int r = 0; r < 3; ++r)
         t[r] = C1[r] - (R[3 * r] * P[0][0] + R[3 * r + 1] * P[0][1] + R[3 * r + 2] * P[0][2]);
       const double e = reproj_sq(R, t, fx, fy, cx, cy, P[3][0], P[3][1], P[3][2], px[3][0], px[3][1]);
-      if (!(e == e)) continue;
-      if (!found || e < best) {
-        found = true;
-        best = e;
-        for (int k = 0; k < 9; ++k) bestR[k] = R[k];
-        for (int k = 0; k < 3; ++k) bestt[k] = t[k];
+      if (!(e == e)) break;
+      found = true;
+      best = e;
+      for (int k = 0; k < 9; ++k) bestR[k] = R[k];
+      for (int k = 0; k < 3; ++k) bestt[k] = t[k];
+    } while (0);
+  }
+  // the sequential rule keeps the first root with the smallest fourth-point error: the minimum
+  // of (error, root index) over the quad's candidates; lanes without a candidate sort last
+  {
+    double ke = found ? best : __longlong_as_double(0x7ff0000000000000ll);
+    int ki = found ? sub : sub + 4;
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+      const int lo = __double2loint(ke), hi = __double2hiint(ke);
+      int olo, ohi, oi;
+      if (step == 0) {
+        olo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        ohi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true);
+        oi = __builtin_amdgcn_update_dpp(0, ki, 0xB1, 0xF, 0xF, true);
+      } else {
+        olo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        ohi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true);
+        oi = __builtin_amdgcn_update_dpp(0, ki, 0x4E, 0xF, 0xF, true);
+      }
+      const double oe = __hiloint2double(ohi, olo);
+      if (oe < ke || (oe == ke && oi < ki)) {
+        ke = oe;
+        ki = oi;
       }
     }
+    if (ki >= 4) {                       // no root gave a pose
+      if (sub == 0) {
+        for (int k = 0; k < 9; ++k) Rout[9 * h + k] = 0.0;
+        for (int k = 0; k < 3; ++k) tout[3 * h + k] = 0.0;
+        valid[h] = 0;
+      }
+    } else if (ki == sub) {
+      for (int k = 0; k < 9; ++k) Rout[9 * h + k] = bestR[k];
+      for (int k = 0; k < 3; ++k) tout[3 * h + k] = bestt[k];
+      valid[h] = 1;
+    }
   }
-  for (int k = 0; k < 9; ++k) Rout[9 * h + k] = found ? bestR[k] : 0.0;
-  for (int k = 0; k < 3; ++k) tout[3 * h + k] = found ? bestt[k] : 0.0;
-  valid[h] = found ? 1 : 0;
 }
 
 constexpr int SC_T = 256;
@@ -375,7 +415,7 @@ int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x,
   const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
-    hipLaunchKernelGGL(p3p_solve_kernel<true>, dim3(vo_cdiv(Hyp, 64)), dim3(64), 0, ctx->stream, d_X, d_x,
+    hipLaunchKernelGGL(p3p_solve_kernel<true>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
                        (const int*)nullptr, d_raws, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
@@ -400,7 +440,7 @@ int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int
   const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
-    hipLaunchKernelGGL(p3p_solve_kernel<false>, dim3(vo_cdiv(Hyp, 64)), dim3(64), 0, ctx->stream, d_X, d_x,
+    hipLaunchKernelGGL(p3p_solve_kernel<false>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
                        d_samples, (const unsigned*)nullptr, (const int*)nullptr, (unsigned*)nullptr, Hyp, fx, fy, cx,
                        cy, d_R, d_t, d_valid);
   }

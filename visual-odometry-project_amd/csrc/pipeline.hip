@@ -106,41 +106,67 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
                                                              double* __restrict__ prev_c, double* __restrict__ next_c,
                                                              double* __restrict__ land_c, int32_t* __restrict__ n_out,
                                                              int cs) {
-  __shared__ int s_w[16];
+  // All loads of up to four passes (4096 keypoints) go out before anything is consumed: one
+  // round trip for the tracker's outputs, one for the depth look-ups that depend on them.
+  constexpr int GE = 4;
+  __shared__ int s_w[GE][16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) s_base = 0;
-  __syncthreads();
-  for (int b0 = 0; b0 < N; b0 += 1024) {
-    const int i = b0 + tid;
-    const bool keep = i < N && status[i] != 0 && err[i] < err_thr;
-    const unsigned long long m = __ballot(keep);
-    const int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) s_w[wv] = __popcll(m);
-    __syncthreads();
-    int off = s_base, tot = 0;
-    for (int w = 0; w < 16; ++w) {
-      if (w < wv) off += s_w[w];
-      tot += s_w[w];
+  double Tm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Tm[k] = T_wc[k];
+  for (int c0 = 0; c0 < N; c0 += GE * 1024) {
+    bool keep[GE];
+    double x[GE], y[GE], z[GE];
+    float nxv[GE], nyv[GE];
+#pragma unroll
+    for (int k = 0; k < GE; ++k) {
+      const int i = c0 + k * 1024 + tid;
+      const bool in = i < N;
+      const int ii = in ? i : 0;
+      keep[k] = in && status[ii] != 0 && err[ii] < err_thr;
+      x[k] = kp_prev[2 * ii];
+      y[k] = kp_prev[2 * ii + 1];
+      nxv[k] = next_xy[2 * ii];
+      nyv[k] = next_xy[2 * ii + 1];
     }
-    if (keep) {
-      const int o = off + before;
-      const double x = kp_prev[2 * i], y = kp_prev[2 * i + 1];
-      prev_c[2 * o] = x;
-      prev_c[2 * o + 1] = y;
-      next_c[2 * o] = (double)next_xy[2 * i];
-      next_c[2 * o + 1] = (double)next_xy[2 * i + 1];
-      int xi = (int)x, yi = (int)y;
+#pragma unroll
+    for (int k = 0; k < GE; ++k) {
+      int xi = (int)x[k], yi = (int)y[k];
       xi = min(max(xi, 0), W - 1);
       yi = min(max(yi, 0), H - 1);
-      const double z = (double)depth[(size_t)yi * W + xi];
-      const double xc = (x - cx) / fx * z, yc = (y - cy) / fy * z;
-      land_c[3 * o] = T_wc[0] * xc + T_wc[1] * yc + T_wc[2] * z + T_wc[3];
-      land_c[3 * o + 1] = T_wc[4] * xc + T_wc[5] * yc + T_wc[6] * z + T_wc[7];
-      land_c[3 * o + 2] = T_wc[8] * xc + T_wc[9] * yc + T_wc[10] * z + T_wc[11];
+      z[k] = (double)depth[(size_t)yi * W + xi];
+    }
+    unsigned long long m[GE];
+#pragma unroll
+    for (int k = 0; k < GE; ++k) {
+      m[k] = __ballot(keep[k]);
+      if (lane == 0) s_w[k][wv] = __popcll(m[k]);
     }
     __syncthreads();
-    if (tid == 0) s_base += tot;
+    int off = s_base;
+#pragma unroll
+    for (int k = 0; k < GE; ++k) {
+      int mine = off;
+      for (int w = 0; w < 16; ++w) {
+        if (w < wv) mine += s_w[k][w];
+        off += s_w[k][w];
+      }
+      if (keep[k]) {
+        const int o = mine + __popcll(m[k] & ((1ull << lane) - 1ull));
+        prev_c[2 * o] = x[k];
+        prev_c[2 * o + 1] = y[k];
+        next_c[2 * o] = (double)nxv[k];
+        next_c[2 * o + 1] = (double)nyv[k];
+        const double xc = (x[k] - cx) / fx * z[k], yc = (y[k] - cy) / fy * z[k];
+        land_c[3 * o] = Tm[0] * xc + Tm[1] * yc + Tm[2] * z[k] + Tm[3];
+        land_c[3 * o + 1] = Tm[4] * xc + Tm[5] * yc + Tm[6] * z[k] + Tm[7];
+        land_c[3 * o + 2] = Tm[8] * xc + Tm[9] * yc + Tm[10] * z[k] + Tm[11];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_base = off;
     __syncthreads();
   }
   if (tid == 0) {
