@@ -386,17 +386,34 @@ __device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int H, 
       }
     }
   } else {
-    // border: reflect-101 per pixel (rare)
+    // border: reflect-101 per pixel.  The block reaches at most 19 pixels past an edge, so one
+    // reflection step is enough unless the level itself is smaller than that (general loop).
+    const bool one_step = W >= 20 && H >= 20;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int row = r + 16 * pass;
       if (row < NR) {
-        const uint8_t* src = img + (size_t)reflect101(y0 + row, H) * W;
+        int gy = y0 + row;
+        if (one_step) gy = gy < 0 ? -gy : (gy >= H ? 2 * (H - 1) - gy : gy);
+        else gy = reflect101(gy, H);
+        const uint8_t* src = img + (size_t)gy * W;
         uint8_t v[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = src[reflect101(x0 + c, W)];
+        for (int c = 0; c < NC; ++c) {
+          int gx = x0 + c;
+          if (one_step) gx = gx < 0 ? -gx : (gx >= W ? 2 * (W - 1) - gx : gx);
+          else gx = reflect101(gx, W);
+          v[c] = src[gx];
+        }
+        unsigned* d = reinterpret_cast<unsigned*>(s + row * K16_PITCH);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) s[row * K16_PITCH + c] = v[c];
+        for (int k = 0; k < (NC + 3) / 4; ++k) {
+          unsigned w = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (4 * k + b < NC) w |= (unsigned)v[4 * k + b] << (8 * b);
+          d[k] = w;
+        }
       }
     }
   }
