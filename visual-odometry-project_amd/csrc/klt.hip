@@ -23,12 +23,22 @@ constexpr int MAX_LEVELS = 8;
 constexpr int MAX_WIN = 31;
 constexpr int W_BITS = 14;
 
+// Every level (level 0 included) is kept with PYR_PAD pixels of reflect-101 border on all
+// sides, so the tracker's blocks -- which reach at most 19 pixels past an edge for windows up
+// to 15 -- are plain in-bounds reads.  prev/next point at the interior origin of each level.
+constexpr int PYR_PAD = 24;
+
 struct pyr_t {
   const uint8_t* prev[MAX_LEVELS];
   const uint8_t* next[MAX_LEVELS];
-  int H[MAX_LEVELS], W[MAX_LEVELS];
+  int H[MAX_LEVELS], W[MAX_LEVELS], pitch[MAX_LEVELS];
   int n_levels;
 };
+
+__host__ __device__ inline int pyr_pitch(int W) { return (W + 2 * PYR_PAD + 3) & ~3; }
+inline size_t pyr_level_bytes(int H, int W) {
+  return ((size_t)(H + 2 * PYR_PAD) * pyr_pitch(W) + 255) & ~size_t(255);
+}
 
 __device__ __forceinline__ int reflect101(int c, int n) {
   if (n == 1) return 0;
@@ -36,23 +46,35 @@ __device__ __forceinline__ int reflect101(int c, int n) {
   return c;
 }
 
-__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src, int H, int W,
-                                                       uint8_t* __restrict__ dst, int Hd, int Wd) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= Wd || y >= Hd) return;
+// One thread per pixel of the padded destination level: the border pixels take the value of
+// the interior pixel they mirror.  src points at the interior origin of the level above.
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src, int spitch, int H, int W,
+                                                       uint8_t* __restrict__ dst, int dpitch, int Hd, int Wd) {
+  const int xp = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int yp = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (xp >= Wd + 2 * PYR_PAD || yp >= Hd + 2 * PYR_PAD) return;
+  const int x = reflect101(xp - PYR_PAD, Wd), y = reflect101(yp - PYR_PAD, Hd);
   int xs[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) xs[i] = reflect101(2 * x + i - 2, W);
   int sum = 0;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
-    const uint8_t* row = src + (size_t)reflect101(2 * y + j - 2, H) * W;
+    const uint8_t* row = src + (size_t)reflect101(2 * y + j - 2, H) * spitch;
     const int r = row[xs[0]] + 4 * row[xs[1]] + 6 * row[xs[2]] + 4 * row[xs[3]] + row[xs[4]];
     const int wj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
     sum += wj * r;
   }
-  dst[(size_t)y * Wd + x] = (uint8_t)((sum + 128) >> 8);
+  dst[(size_t)yp * dpitch + xp] = (uint8_t)((sum + 128) >> 8);
+}
+
+// level 0: the frame itself with its reflected border
+__global__ __launch_bounds__(256) void pad_reflect_kernel(const uint8_t* __restrict__ src, int H, int W,
+                                                          uint8_t* __restrict__ dst, int dpitch) {
+  const int xp = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int yp = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (xp >= W + 2 * PYR_PAD || yp >= H + 2 * PYR_PAD) return;
+  dst[(size_t)yp * dpitch + xp] = src[(size_t)reflect101(yp - PYR_PAD, H) * W + reflect101(xp - PYR_PAD, W)];
 }
 
 // Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic), result in
@@ -87,8 +109,8 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int
 // stage the (n x n) block of image pixels whose top-left is (x0, y0) into LDS, reflect-101.
 // Loads go out in batches of 8 per lane before any is written to LDS (one memory round
 // trip per batch instead of one per byte).
-__device__ __forceinline__ void stage_region(const uint8_t* __restrict__ img, int H, int W, int x0, int y0, int n,
-                                             uint8_t* s, int lane) {
+__device__ __forceinline__ void stage_region(const uint8_t* __restrict__ img, int pitch, int H, int W, int x0, int y0,
+                                             int n, uint8_t* s, int lane) {
   const bool inside = x0 >= 0 && y0 >= 0 && x0 + n <= W && y0 + n <= H;
   const int total = n * n;
   for (int b0 = 0; b0 < total; b0 += 8 * 64) {
@@ -100,7 +122,7 @@ __device__ __forceinline__ void stage_region(const uint8_t* __restrict__ img, in
       const int ly = ii / n, lx = ii - ly * n;
       const int gy = inside ? y0 + ly : reflect101(y0 + ly, H);
       const int gx = inside ? x0 + lx : reflect101(x0 + lx, W);
-      v[k] = img[(size_t)gy * W + gx];
+      v[k] = img[(size_t)gy * pitch + gx];
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -151,7 +173,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
   for (int level = P.n_levels - 1; level >= 0; --level) {
     const uint8_t* I = P.prev[level];
     const uint8_t* J = P.next[level];
-    const int H = P.H[level], W = P.W[level];
+    const int H = P.H[level], W = P.W[level], pitch = P.pitch[level];
     const float sc = (float)(1. / (double)(1 << level));
     float px = p0x * sc, py = p0y * sc;
     float qx, qy;
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
 
     // ---- template: image block, Scharr derivatives, interpolated patch ----
     wave_sync();
-    stage_region(I, H, W, ipx - 1, ipy - 1, n3, s_reg, lane);
+    stage_region(I, pitch, H, W, ipx - 1, ipy - 1, n3, s_reg, lane);
     wave_sync();
     for (int k = lane; k < n1 * n1; k += 64) {
       const int ly = k / n1, lx = k - ly * n1;
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
         rx0 = iqx - KLT_MARGIN;
         ry0 = iqy - KLT_MARGIN;
         wave_sync();
-        stage_region(J, H, W, rx0, ry0, RS, s_reg, lane);
+        stage_region(J, pitch, H, W, rx0, ry0, RS, s_reg, lane);
         wave_sync();
         staged = true;
       }
@@ -287,7 +309,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
         rx0 = iex - KLT_MARGIN;
         ry0 = iey - KLT_MARGIN;
         wave_sync();
-        stage_region(J, H, W, rx0, ry0, RS, s_reg, lane);
+        stage_region(J, pitch, H, W, rx0, ry0, RS, s_reg, lane);
         wave_sync();
         staged = true;
       }
@@ -360,61 +382,27 @@ __device__ __forceinline__ int sdot2(unsigned a, unsigned b, int c) {
 }
 
 // rows [0, NR) x bytes [0, NC) of the image block whose top-left pixel is (x0, y0) -> s, pitch
-// K16_PITCH.  NC is 18 or 24; lane r takes rows r and r + 16.
+// K16_PITCH.  NC is 18 or 24; lane r takes rows r and r + 16.  The block may hang over the
+// image by up to 19 pixels: the level is stored with PYR_PAD pixels of reflected border.
 template <int NC, int NR>
-__device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int H, int W, int x0, int y0, uint8_t* s,
-                                        int r) {
-  const bool inside = x0 >= 0 && y0 >= 0 && x0 + NC <= W && y0 + NR <= H;
-  if (inside) {
-    unsigned v[2][6];
+__device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pitch, int x0, int y0, uint8_t* s, int r) {
+  unsigned v[2][6];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = r + 16 * pass;
-      const bool on = row < NR;
-      const uint8_t* src = img + (size_t)(y0 + (on ? row : 0)) * W + x0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = r + 16 * pass;
+    const bool on = row < NR;
+    const uint8_t* src = img + (ptrdiff_t)(y0 + (on ? row : 0)) * pitch + x0;
 #pragma unroll
-      for (int k = 0; k < NC / 4; ++k) v[pass][k] = *(const u32_any*)(src + 4 * k);
-      if (NC & 2) v[pass][NC / 4] = *(const u16_any*)(src + (NC & ~3));
-    }
+    for (int k = 0; k < NC / 4; ++k) v[pass][k] = *(const u32_any*)(src + 4 * k);
+    if (NC & 2) v[pass][NC / 4] = *(const u16_any*)(src + (NC & ~3));
+  }
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = r + 16 * pass;
-      if (row < NR) {
-        unsigned* d = reinterpret_cast<unsigned*>(s + row * K16_PITCH);
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = r + 16 * pass;
+    if (row < NR) {
+      unsigned* d = reinterpret_cast<unsigned*>(s + row * K16_PITCH);
 #pragma unroll
-        for (int k = 0; k < (NC + 3) / 4; ++k) d[k] = v[pass][k];
-      }
-    }
-  } else {
-    // border: reflect-101 per pixel.  The block reaches at most 19 pixels past an edge, so one
-    // reflection step is enough unless the level itself is smaller than that (general loop).
-    const bool one_step = W >= 20 && H >= 20;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = r + 16 * pass;
-      if (row < NR) {
-        int gy = y0 + row;
-        if (one_step) gy = gy < 0 ? -gy : (gy >= H ? 2 * (H - 1) - gy : gy);
-        else gy = reflect101(gy, H);
-        const uint8_t* src = img + (size_t)gy * W;
-        uint8_t v[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          int gx = x0 + c;
-          if (one_step) gx = gx < 0 ? -gx : (gx >= W ? 2 * (W - 1) - gx : gx);
-          else gx = reflect101(gx, W);
-          v[c] = src[gx];
-        }
-        unsigned* d = reinterpret_cast<unsigned*>(s + row * K16_PITCH);
-#pragma unroll
-        for (int k = 0; k < (NC + 3) / 4; ++k) {
-          unsigned w = 0;
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-            if (4 * k + b < NC) w |= (unsigned)v[4 * k + b] << (8 * b);
-          d[k] = w;
-        }
-      }
+      for (int k = 0; k < (NC + 3) / 4; ++k) d[k] = v[pass][k];
     }
   }
 }
@@ -442,7 +430,7 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   for (int level = P.n_levels - 1; level >= 0; --level) {
     const uint8_t* I = P.prev[level];
     const uint8_t* J = P.next[level];
-    const int H = P.H[level], W = P.W[level];
+    const int H = P.H[level], W = P.W[level], pitch = P.pitch[level];
     const float sc = (float)(1. / (double)(1 << level));
     float px = p0x * sc, py = p0y * sc;
     float qx, qy;
@@ -471,7 +459,7 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
 
     // ---- template: image block, Scharr derivatives, interpolated patch (all in registers) ----
     wave_sync();
-    stage16<18, 18>(I, H, W, ipx - 1, ipy - 1, s_reg, r);
+    stage16<18, 18>(I, pitch, ipx - 1, ipy - 1, s_reg, r);
     wave_sync();
     int tI[win], tX[win], tY[win];
     int a11 = 0, a12 = 0, a22 = 0;   // per-lane partial sums stay below 2^31
@@ -557,7 +545,7 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
         rx0 = iqx - KLT_MARGIN;
         ry0 = iqy - KLT_MARGIN;
         wave_sync();
-        stage16<24, 24>(J, H, W, rx0, ry0, s_reg, r);
+        stage16<24, 24>(J, pitch, rx0, ry0, s_reg, r);
         wave_sync();
         staged = true;
       }
@@ -604,7 +592,7 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
         rx0 = iex - KLT_MARGIN;
         ry0 = iey - KLT_MARGIN;
         wave_sync();
-        stage16<24, 24>(J, H, W, rx0, ry0, s_reg, r);
+        stage16<24, 24>(J, pitch, rx0, ry0, s_reg, r);
         wave_sync();
         staged = true;
       }
@@ -655,33 +643,41 @@ int vo_klt_num_levels(int H, int W, int win, int max_level) {
 size_t vo_pyramid_bytes(int H, int W, int n_levels) {
   size_t total = 0;
   int h = H, w = W;
-  for (int l = 1; l < n_levels; ++l) {
+  for (int l = 0; l < n_levels; ++l) {
+    total += pyr_level_bytes(h, w);
     h = (h + 1) / 2;
     w = (w + 1) / 2;
-    total += ((size_t)h * w + 255) & ~size_t(255);
   }
   return total ? total : 256;
 }
 
-// d_pyr receives levels 1 .. n_levels-1 back to back (each rounded up to 256 bytes)
+// d_pyr receives levels 0 .. n_levels-1 back to back, each with its reflected border (see pyr_t)
 int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_levels, uint8_t* d_pyr) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, d_img && d_pyr, "pyramid_build: null pointer");
   VO_REQUIRE(ctx, H > 0 && W > 0 && n_levels >= 1 && n_levels <= MAX_LEVELS, "pyramid_build: bad arguments");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const uint8_t* src = d_img;
-  int h = H, w = W;
-  uint8_t* dst = d_pyr;
+  {
+    vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
+    hipLaunchKernelGGL(pad_reflect_kernel, dim3(vo_cdiv(W + 2 * PYR_PAD, 64), vo_cdiv(H + 2 * PYR_PAD, 4)), dim3(256), 0,
+                       ctx->stream, d_img, H, W, d_pyr, pyr_pitch(W));
+  }
+  VO_TRY(vo_check_launch(ctx, "pad_reflect_kernel"));
+  const uint8_t* src = d_img;       // interior origin and pitch of the level above
+  int spitch = W, h = H, w = W;
+  uint8_t* dst = d_pyr + pyr_level_bytes(H, W);
   for (int l = 1; l < n_levels; ++l) {
     const int hd = (h + 1) / 2, wd = (w + 1) / 2;
+    const int dpitch = pyr_pitch(wd);
     {
       vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
-      hipLaunchKernelGGL(pyr_down_kernel, dim3(vo_cdiv(wd, 64), vo_cdiv(hd, 4)), dim3(256), 0, ctx->stream, src, h, w,
-                         dst, hd, wd);
+      hipLaunchKernelGGL(pyr_down_kernel, dim3(vo_cdiv(wd + 2 * PYR_PAD, 64), vo_cdiv(hd + 2 * PYR_PAD, 4)), dim3(256), 0,
+                         ctx->stream, src, spitch, h, w, dst, dpitch, hd, wd);
     }
     VO_TRY(vo_check_launch(ctx, "pyr_down_kernel"));
-    src = dst;
-    dst += ((size_t)hd * wd + 255) & ~size_t(255);
+    src = dst + (size_t)PYR_PAD * dpitch + PYR_PAD;
+    spitch = dpitch;
+    dst += pyr_level_bytes(hd, wd);
     h = hd;
     w = wd;
   }
@@ -696,24 +692,28 @@ int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_p
   if (N == 0) return VO_OK;
   VO_REQUIRE(ctx, d_prev && d_next && d_prev_xy && d_next_xy && d_status && d_err, "klt_track: null pointer");
   VO_REQUIRE(ctx, n_levels >= 1 && n_levels <= MAX_LEVELS, "klt_track: n_levels must be in 1..%d", MAX_LEVELS);
-  VO_REQUIRE(ctx, n_levels == 1 || (d_prev_pyr && d_next_pyr), "klt_track: pyramid buffers missing");
+  VO_REQUIRE(ctx, d_prev_pyr && d_next_pyr, "klt_track: pyramid buffers missing");
   VO_REQUIRE(ctx, win >= 3 && win <= MAX_WIN, "klt_track: window must be in 3..%d", MAX_WIN);
   VO_REQUIRE(ctx, H > 0 && W > 0, "klt_track: bad image size");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   pyr_t P;
   memset(&P, 0, sizeof(P));
   P.n_levels = n_levels;
-  P.prev[0] = d_prev;
-  P.next[0] = d_next;
-  P.H[0] = H;
-  P.W[0] = W;
-  size_t off = 0;
-  for (int l = 1; l < n_levels; ++l) {
-    P.H[l] = (P.H[l - 1] + 1) / 2;
-    P.W[l] = (P.W[l - 1] + 1) / 2;
-    P.prev[l] = d_prev_pyr + off;
-    P.next[l] = d_next_pyr + off;
-    off += ((size_t)P.H[l] * P.W[l] + 255) & ~size_t(255);
+  {
+    // every level, level 0 included, is read from the bordered copies vo_pyramid_build_dev made
+    size_t off = 0;
+    int h = H, w = W;
+    for (int l = 0; l < n_levels; ++l) {
+      P.H[l] = h;
+      P.W[l] = w;
+      P.pitch[l] = pyr_pitch(w);
+      const size_t origin = off + (size_t)PYR_PAD * P.pitch[l] + PYR_PAD;
+      P.prev[l] = d_prev_pyr + origin;
+      P.next[l] = d_next_pyr + origin;
+      off += pyr_level_bytes(h, w);
+      h = (h + 1) / 2;
+      w = (w + 1) / 2;
+    }
   }
   if (max_iter < 0) max_iter = 0;
   if (max_iter > 100) max_iter = 100;
@@ -792,7 +792,12 @@ int vo_pyr_down(vo_ctx* ctx, const uint8_t* img, int H, int W, uint8_t* out) {
   VO_TRY(vo_ensure(ctx, ctx->scratch[8], vo_pyramid_bytes(H, W, 2)));
   VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, img, px, hipMemcpyHostToDevice, ctx->stream));
   VO_TRY(vo_pyramid_build_dev(ctx, (const uint8_t*)ctx->img.p, H, W, 2, (uint8_t*)ctx->scratch[8].p));
-  VO_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->scratch[8].p, (size_t)hd * wd, hipMemcpyDeviceToHost, ctx->stream));
+  {
+    const uint8_t* l1 = (const uint8_t*)ctx->scratch[8].p + pyr_level_bytes(H, W);
+    const int pitch = pyr_pitch(wd);
+    VO_HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)wd, l1 + (size_t)PYR_PAD * pitch + PYR_PAD, (size_t)pitch, (size_t)wd,
+                                     (size_t)hd, hipMemcpyDeviceToHost, ctx->stream));
+  }
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return VO_OK;
 }
