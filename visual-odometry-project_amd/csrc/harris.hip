@@ -292,8 +292,14 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
                                                             unsigned long long* __restrict__ seg_keys_a1,
                                                             unsigned* __restrict__ seg_idx_a1,
                                                             uint4* __restrict__ seg_cnt,
-                                                            unsigned* __restrict__ hist) {
+                                                            unsigned* __restrict__ hist, nms_ctl* ctl) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // counters of this call (first kernel of the chain)
+    ctl->n_c = 0;
+    ctl->n_rem = 0;
+    ctl->overflow = 0;
+    ctl->n_sel = 0;
+  }
   const int r = R_T > 0 ? R_T : r_arg;
   const int RW = CX + 4 * r, RH = CY + 4 * r;   // score region (2r halo)
   const int LW = CX + 2 * r, LH = CY + 2 * r;   // region where L1 flags are needed
@@ -495,24 +501,17 @@ __device__ __forceinline__ unsigned suffix_sum_256(unsigned v, unsigned* s_w) {
   return suf;
 }
 
-__global__ __launch_bounds__(256) void nms_threshold_kernel(const unsigned* __restrict__ hist, nms_ctl* ctl, int N) {
+// The bound as IEEE bits (every thread of the 256-thread workgroup gets it); each compact
+// workgroup computes it for itself rather than waiting for a one-workgroup kernel.
+__device__ __forceinline__ unsigned long long nms_threshold_bits(const unsigned* __restrict__ hist, int N) {
   __shared__ unsigned s_w[4];
   __shared__ unsigned s_above;
   const int tid = threadIdx.x;
-  if (tid == 0) {   // counters of this call (the list is filled by the kernels that follow)
-    ctl->n_c = 0;
-    ctl->n_rem = 0;
-    ctl->overflow = 0;
-    ctl->n_sel = 0;
-  }
   // coarse level: thread t holds the count of fine bins [256 t, 256 t + 256)
   const unsigned v1 = hist[HIST_BINS + tid];
   const unsigned suf1 = suffix_sum_256(v1, s_w);
   const int n_ge = __syncthreads_count(suf1 >= (unsigned)N);   // suffix sums do not increase with t
-  if (n_ge == 0) {
-    if (tid == 0) ctl->t_bits = 1ull;   // fewer than N strict maxima: keep everything
-    return;
-  }
+  if (n_ge == 0) return 1ull;           // fewer than N strict maxima: keep everything
   const int cb = n_ge - 1;              // crossing coarse bin
   if (tid == cb) s_above = suf1 - v1;   // strict maxima in coarse bins above it
   __syncthreads();
@@ -520,10 +519,8 @@ __global__ __launch_bounds__(256) void nms_threshold_kernel(const unsigned* __re
   const unsigned v2 = hist[cb * 256 + tid];
   const unsigned suf2 = suffix_sum_256(v2, s_w);
   const int m_ge = __syncthreads_count(above + suf2 >= (unsigned)N);   // >= 1: bin 0 of cb reaches suf1(cb) >= N
-  if (tid == 0) {
-    const unsigned long long t = (unsigned long long)(cb * 256 + (m_ge - 1)) << HIST_SHIFT;
-    ctl->t_bits = t ? t : 1ull;
-  }
+  const unsigned long long t = (unsigned long long)(cb * 256 + (m_ge - 1)) << HIST_SHIFT;
+  return t ? t : 1ull;
 }
 
 // List entry format (idx_c): flat pixel index << 2 | flags.  bit 0: undecided (the sorted walk
@@ -533,7 +530,7 @@ constexpr unsigned ENT_UNDECIDED = 1u, ENT_CAND = 2u;
 
 // ---------------------------------------------------------------------------------
 // NMS stage 3 (one workgroup per tile): L1 >= T -> selected list; A1 >= T -> live candidates.
-// Also clears the histogram (its only reader has run) for the next call.
+// Also clears the other call parity's histogram (all its readers ran during the previous call).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long long* __restrict__ seg_keys_l1,
                                                          const unsigned* __restrict__ seg_idx_l1,
@@ -542,14 +539,17 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
                                                          uint4* __restrict__ seg_cnt, unsigned* __restrict__ seg_cand,
                                                          unsigned long long* __restrict__ keys_c,
                                                          unsigned* __restrict__ idx_c, unsigned* __restrict__ alive,
-                                                         nms_ctl* ctl, unsigned cap_c, unsigned* __restrict__ hist) {
+                                                         nms_ctl* ctl, unsigned cap_c,
+                                                         const unsigned* __restrict__ hist,
+                                                         unsigned* __restrict__ hist_other, int N) {
   __shared__ unsigned s_n, s_l1n, s_base;
+  static_assert(NT == 256, "nms_threshold_bits is written for 256 threads");
   const unsigned blk = blockIdx.x;
   const size_t seg0 = (size_t)blk * SEG;
   const uint4 cnt = seg_cnt[blk];
-  const unsigned long long t = ctl->t_bits;
   const int tid = threadIdx.x;
-  for (unsigned i = blk * NT + tid; i < (unsigned)HIST_TOTAL; i += gridDim.x * NT) hist[i] = 0;
+  for (unsigned i = blk * NT + tid; i < (unsigned)HIST_TOTAL; i += gridDim.x * NT) hist_other[i] = 0;
+  const unsigned long long t = nms_threshold_bits(hist, N);
   if (tid == 0) s_n = 0;
   __syncthreads();
   for (unsigned b0 = 0; b0 < cnt.x; b0 += NT) {
@@ -609,7 +609,8 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
 // own.  A tile leaves when none of its candidates is live; tiles blocked on a neighbour poll
 // for a bounded number of iterations, what is left goes to the second launch, and what that
 // leaves (FINAL) joins the list as undecided entries for the sorted walk.
-constexpr int ROUND_ITERS = 24;
+constexpr int ROUND_ITERS = 64;
+static_assert(CX * (CY / 8) == NT, "the column pass of the round kernel maps one strip to one thread");
 
 __device__ __forceinline__ unsigned load_state(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   const int LW = CX + 2 * r, LH = CY + 2 * r;
   unsigned* s_state = s_dyn;                     // LH x LW
   unsigned* s_rmax = s_state + LW * LH;          // LH x CX   row maxima
-  unsigned* s_m = s_rmax + LH * CX;              // CY x CX   window maxima
+  unsigned* s_m = s_rmax;                        // CY x CX   window maxima (written over the row maxima)
   __shared__ unsigned short s_cell[SEG];         // LDS cell of candidate i
   __shared__ unsigned short s_pass[SEG];         // candidates that top their window this iteration
   __shared__ unsigned short s_sel[SEG];          // candidates selected in this launch
@@ -706,9 +707,12 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
       }
     }
     __syncthreads();
-    for (int it = tid; it < CX * (CY / 8); it += NT) {
-      const int lx = it & (CX - 1), ys = (it / CX) * 8;
+    {
+      // one strip of eight window maxima per thread (CX * CY / 8 == NT); they overwrite the row
+      // maxima they were computed from, so every thread reads before any thread writes
+      const int lx = tid & (CX - 1), ys = (tid / CX) * 8;
       const unsigned* col = s_rmax + ys * CX + lx;
+      unsigned out[8];
       if (R_T > 0) {
         unsigned v[8 + 2 * R_T];
 #pragma unroll
@@ -718,15 +722,19 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
           unsigned m = v[o];
 #pragma unroll
           for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
-          s_m[(ys + o) * CX + lx] = m;
+          out[o] = m;
         }
       } else {
+#pragma unroll
         for (int o = 0; o < 8; ++o) {
           unsigned m = col[o * CX];
           for (int d = 1; d < WN; ++d) m = max(m, col[(o + d) * CX]);
-          s_m[(ys + o) * CX + lx] = m;
+          out[o] = m;
         }
       }
+      __syncthreads();
+#pragma unroll
+      for (int o = 0; o < 8; ++o) s_m[(ys + o) * CX + lx] = out[o];
     }
     __syncthreads();
     // ---- candidates whose word tops their window ----
@@ -1255,8 +1263,8 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   VO_TRY(vo_ensure(ctx, ctx->nms_idx_c, (size_t)cap_c * 4));
   VO_TRY(vo_ensure(ctx, ctx->nms_sel, (size_t)MAX_N * 4));
   if (!ctx->nms_hist.p) {
-    VO_TRY(vo_ensure(ctx, ctx->nms_hist, (size_t)HIST_TOTAL * 4));
-    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_hist.p, 0, (size_t)HIST_TOTAL * 4, ctx->stream));
+    VO_TRY(vo_ensure(ctx, ctx->nms_hist, (size_t)2 * HIST_TOTAL * 4));   // one histogram per call parity
+    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_hist.p, 0, (size_t)2 * HIST_TOTAL * 4, ctx->stream));
   }
   if (!ctx->nms_rank.p) {
     VO_TRY(vo_ensure(ctx, ctx->nms_rank, (size_t)RANK_MAX * 4));
@@ -1279,7 +1287,9 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   unsigned* cand = (unsigned*)ctx->nms_cand.p;
   uint4* segcnt = (uint4*)ctx->nms_segcnt.p;
   unsigned* alive = (unsigned*)ctx->nms_alive.p;
-  unsigned* hist = (unsigned*)ctx->nms_hist.p;
+  ctx->nms_parity ^= 1;
+  unsigned* hist = (unsigned*)ctx->nms_hist.p + (size_t)ctx->nms_parity * HIST_TOTAL;
+  unsigned* hist_other = (unsigned*)ctx->nms_hist.p + (size_t)(1 - ctx->nms_parity) * HIST_TOTAL;
   unsigned* rank = (unsigned*)ctx->nms_rank.p;
   hipStream_t st = ctx->stream;
   {
@@ -1296,36 +1306,25 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
     const size_t lds = candidates_lds_bytes(r);
     if (r == 5)
       hipLaunchKernelGGL(nms_candidates_kernel<5>, grid, dim3(NT), lds, st, d_scores, H, W, r, keys_l1, idx_l1,
-                         keys_a1, idx_a1, segcnt, hist);
+                         keys_a1, idx_a1, segcnt, hist, ctl);
     else
       hipLaunchKernelGGL(nms_candidates_kernel<0>, grid, dim3(NT), lds, st, d_scores, H, W, r, keys_l1, idx_l1,
-                         keys_a1, idx_a1, segcnt, hist);
+                         keys_a1, idx_a1, segcnt, hist, ctl);
   }
   VO_TRY(vo_check_launch(ctx, "nms_candidates_kernel"));
-  {
-    vo_prof_scope ps(ctx, VO_K_NMS_THRESHOLD);
-    hipLaunchKernelGGL(nms_threshold_kernel, dim3(1), dim3(256), 0, st, hist, ctl, N);
-  }
-  VO_TRY(vo_check_launch(ctx, "nms_threshold_kernel"));
   ctx->nms_alive_dirty = true;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_COMPACT);
     hipLaunchKernelGGL(nms_compact_kernel, dim3(nblk), dim3(NT), 0, st, keys_l1, idx_l1, keys_a1, idx_a1, segcnt,
-                       cand, keys_c, idx_c, alive, ctl, cap_c, hist);
+                       cand, keys_c, idx_c, alive, ctl, cap_c, hist, hist_other, N);
   }
   VO_TRY(vo_check_launch(ctx, "nms_compact_kernel"));
-  const size_t round_lds = ((size_t)(CX + 2 * r) * (CY + 2 * r) + (size_t)(CY + 2 * r) * CX + (size_t)CY * CX) * 4;
-  for (int round = 0; round < 2; ++round) {
+  const size_t round_lds = ((size_t)(CX + 2 * r) * (CY + 2 * r) + (size_t)(CY + 2 * r) * CX) * 4;
+  {
     vo_prof_scope ps(ctx, VO_K_NMS_ROUND);
     const dim3 g(nblk), b(NT);
-    if (r == 5 && round == 0)
-      hipLaunchKernelGGL((nms_round_kernel<5, false>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
-                         idx_c, ctl, cap_c, H, W, r, (int)grid.x);
-    else if (r == 5)
+    if (r == 5)
       hipLaunchKernelGGL((nms_round_kernel<5, true>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
-                         idx_c, ctl, cap_c, H, W, r, (int)grid.x);
-    else if (round == 0)
-      hipLaunchKernelGGL((nms_round_kernel<0, false>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
                          idx_c, ctl, cap_c, H, W, r, (int)grid.x);
     else
       hipLaunchKernelGGL((nms_round_kernel<0, true>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,

@@ -26,13 +26,16 @@
 struct vo_pipeline {
   vo_ctx* ctx = nullptr;
   vo_ctx* det = nullptr;            // second context (own stream + NMS workspace): detection runs beside tracking
-  hipEvent_t evDetDone = nullptr;   // recorded by the worker behind a step's detection branch
+  hipEvent_t evDet[2] = {nullptr, nullptr};   // keypoints ready; steps alternate, so the wait for the last step's
+                                              // event cannot catch this step's record
+  int ev_last = 0;                            // index of the event the latest detection records
+  hipEvent_t evDltDone = nullptr;             // the DLT queued behind a detection has read its inputs
   // detection worker: a mailbox the main thread posts (frame, buffers) to; it enqueues the branch
-  // on det->stream and records evDetDone
+  // on det->stream and records evDet[ev]
   std::thread worker;
   std::atomic<unsigned> job_posted{0}, job_done{0};
   std::atomic<bool> quit{false};
-  struct { int frame, slot, prev_set; bool with_dlt; } job = {0, 0, 0, false};
+  struct { int frame, slot, prev_set, ev; bool with_dlt; } job = {0, 0, 0, 0, false};
   int job_rc = 0;
   bool det_warm = false;
   vo_pipeline_config cfg;
@@ -359,7 +362,9 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
 #undef PA
   if (rc == VO_OK && (hipEventCreateWithFlags(&p->evA, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evB, hipEventDisableTiming) != hipSuccess ||
-                      hipEventCreateWithFlags(&p->evDetDone, hipEventDisableTiming) != hipSuccess))
+                      hipEventCreateWithFlags(&p->evDet[0], hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evDet[1], hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evDltDone, hipEventDisableTiming) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   if (rc != VO_OK) {
     vo_pipeline_destroy(p);
@@ -407,7 +412,9 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (q) (void)hipHostFree(q);
   if (p->evA) (void)hipEventDestroy(p->evA);
   if (p->evB) (void)hipEventDestroy(p->evB);
-  if (p->evDetDone) (void)hipEventDestroy(p->evDetDone);
+  for (int k = 0; k < 2; ++k)
+    if (p->evDet[k]) (void)hipEventDestroy(p->evDet[k]);
+  if (p->evDltDone) (void)hipEventDestroy(p->evDltDone);
   if (p->det) vo_destroy(p->det);
   delete p;
 }
@@ -434,20 +441,21 @@ int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
 
 // ---- launches of one step -----------------------------------------------------------------
 
-// detection branch: DLT of the previous step's tracks, then Harris response + NMS of `frame`
-static int enqueue_detection(vo_pipeline* p, int frame, int slot, int prev_set, bool with_dlt) {
+// detection branch: Harris response + NMS of `frame` (evDet[ev]: the next step's tracker may
+// start), then the DLT of the previous step's tracks (evDltDone: its inputs may be overwritten)
+static int enqueue_detection(vo_pipeline* p, int frame, int slot, int prev_set, bool with_dlt, int ev) {
   const vo_pipeline_config& c = p->cfg;
   vo_ctx* det = p->det;
-  int rc = VO_OK;
+  det->nms_kp_f32 = p->d_kp_f32[slot];   // the tracker's float copy of the keypoints
+  int rc = vo_harris_response_dev(det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
+  if (rc == VO_OK) rc = vo_nms_keypoints_dev(det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, p->d_kp[slot]);
+  if (rc == VO_OK && hipEventRecord(p->evDet[ev], det->stream) != hipSuccess) rc = VO_EHIP;
   // cameras are read from mapped host memory (set s is rewritten two steps later at the earliest),
   // the point count from the word the gather kernel of that step left in HBM
-  if (with_dlt)
+  if (rc == VO_OK && with_dlt)
     rc = vo_triangulate_dlt_ndev(det, p->d_prev_c[prev_set], p->d_next_c[prev_set], p->d_ntracked + 4 + prev_set,
                                  c.n_keypoints, p->m_C + 24 * prev_set, p->m_C + 24 * prev_set + 12, p->d_tri);
-  det->nms_kp_f32 = p->d_kp_f32[slot];   // the tracker's float copy of the keypoints
-  if (rc == VO_OK)
-    rc = vo_harris_response_dev(det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
-  if (rc == VO_OK) rc = vo_nms_keypoints_dev(det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, p->d_kp[slot]);
+  if (rc == VO_OK && hipEventRecord(p->evDltDone, det->stream) != hipSuccess) rc = VO_EHIP;
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(det));
   return VO_OK;
 }
@@ -464,6 +472,8 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
                           p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
   if (det_pos == 1) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
+  // the track set this gather fills was the input of the DLT queued behind the last detection
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDltDone, 0));
   {
     vo_prof_scope ps(ctx, VO_K_GATHER);
     hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->d_kp[a], p->d_next_f32,
@@ -502,9 +512,7 @@ static void worker_main(vo_pipeline* p) {
     }
     idle = 0;
     seen = posted;
-    int rc = enqueue_detection(p, p->job.frame, p->job.slot, p->job.prev_set, p->job.with_dlt);
-    if (rc == VO_OK && hipEventRecord(p->evDetDone, p->det->stream) != hipSuccess) rc = VO_EHIP;
-    p->job_rc = rc;
+    p->job_rc = enqueue_detection(p, p->job.frame, p->job.slot, p->job.prev_set, p->job.with_dlt, p->job.ev);
     p->job_done.store(seen, std::memory_order_release);
   }
 }
@@ -517,10 +525,12 @@ static void post_detection(vo_pipeline* p, int frame, int slot, int prev_set, bo
   p->job.slot = slot;
   p->job.prev_set = prev_set;
   p->job.with_dlt = with_dlt;
+  p->ev_last ^= 1;
+  p->job.ev = p->ev_last;
   p->job_posted.store(p->job_posted.load(std::memory_order_relaxed) + 1, std::memory_order_release);
 }
 
-// waits (host) until the worker has enqueued everything it was given, evDetDone included
+// waits (host) until the worker has enqueued everything it was given, evDet[] included
 static int worker_idle(vo_pipeline* p) {
   const unsigned posted = p->job_posted.load(std::memory_order_relaxed);
   while (p->job_done.load(std::memory_order_acquire) != posted) __builtin_ia32_pause();
@@ -534,7 +544,7 @@ static int worker_idle(vo_pipeline* p) {
 
 static int detect_join(vo_pipeline* p) {
   VO_TRY(worker_idle(p));
-  VO_HIP_TRY(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->evDetDone, 0));
+  VO_HIP_TRY(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->evDet[p->ev_last], 0));
   return VO_OK;
 }
 
@@ -568,7 +578,8 @@ static int flush_dlt(vo_pipeline* p) {
   const int rc = vo_triangulate_dlt_ndev(p->det, p->d_prev_c[s], p->d_next_c[s], p->d_ntracked + 4 + s,
                                          p->cfg.n_keypoints, p->m_C + 24 * s, p->m_C + 24 * s + 12, p->d_tri);
   if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->det));
-  VO_HIP_TRY(ctx, hipEventRecord(p->evDetDone, p->det->stream));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evDltDone, p->det->stream));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evDet[p->ev_last], p->det->stream));
   return VO_OK;
 }
 
@@ -606,10 +617,11 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
 
   // ---- all launches of the step: detection from the worker thread, tracking from this one ----
   VO_TRY(worker_idle(p));
-  VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDetDone, 0));   // keypoints of `prev` (the last step's detection)
+  const int ev_prev = p->ev_last;                      // recorded behind the last step's detection
   static const int det_pos = getenv("VO_DET_POS") ? atoi(getenv("VO_DET_POS")) : 0;
   if (det_pos == 0) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
+  VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[ev_prev], 0));   // keypoints of `prev`
   VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, det_pos));
   VO_TRY(launch_mirror(p, true));
   if (det_pos == 2) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);

@@ -47,6 +47,7 @@ struct vo_ctx {
   vo_buf nms_keys_c, nms_idx_c;                              // compacted candidates
   vo_buf nms_hist, nms_ctl, nms_sel, nms_cand, nms_alive, nms_segcnt, nms_rank;
   bool nms_alive_dirty = false;
+  int nms_parity = 0;            // NMS calls alternate between two histograms (the idle one is cleared meanwhile)
   float* nms_kp_f32 = nullptr;   // optional: the NMS also writes its keypoints as float pairs here (device)
   vo_buf scratch[16];
   vo_buf sift_arena;
