@@ -610,7 +610,7 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
 // for a bounded number of iterations, what is left goes to the second launch, and what that
 // leaves (FINAL) joins the list as undecided entries for the sorted walk.
 constexpr int ROUND_ITERS = 64;
-static_assert(CX * (CY / 8) == NT, "the column pass of the round kernel maps one strip to one thread");
+static_assert(CX * (CY / 8) == NT, "the row pass of the round kernel maps one strip to one thread");
 
 __device__ __forceinline__ unsigned load_state(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -630,9 +630,13 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   const int r = R_T > 0 ? R_T : r_arg;
   const int WN = 2 * r + 1;
   const int LW = CX + 2 * r, LH = CY + 2 * r;
-  unsigned* s_state = s_dyn;                     // LH x LW
-  unsigned* s_rmax = s_state + LW * LH;          // LH x CX   row maxima
-  unsigned* s_m = s_rmax;                        // CY x CX   window maxima (written over the row maxima)
+  // odd row pitches: a wave's lanes walk either along x (stride 1) or along y (stride = pitch),
+  // and both patterns then spread over all LDS banks
+  const int SP = LW | 1;                         // pitch of the state snapshot and of the column maxima
+  constexpr int PM = CX + 1;                     // pitch of the window maxima
+  unsigned* s_state = s_dyn;                     // LH x LW (pitch SP)
+  unsigned* s_v = s_state + SP * LH;             // CY x LW (pitch SP)  column maxima
+  unsigned* s_m = s_v;                           // CY x CX (pitch PM)  window maxima, written over the column maxima
   __shared__ unsigned short s_cell[SEG];         // LDS cell of candidate i
   __shared__ unsigned short s_pass[SEG];         // candidates that top their window this iteration
   __shared__ unsigned short s_sel[SEG];          // candidates selected in this launch
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   for (unsigned i = tid; i < n; i += NT) {
     const unsigned idx = seg_cand[seg0 + i];
     const int py = (int)(idx / (unsigned)W), px = (int)(idx - (unsigned)py * (unsigned)W);
-    s_cell[i] = (unsigned short)((py - y0 + r) * LW + (px - x0 + r));
+    s_cell[i] = (unsigned short)((py - y0 + r) * SP + (px - x0 + r));
   }
   if (tid == 0) {
     s_nsel = 0;
@@ -671,7 +675,8 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
         const int i = tid + k * NT;
-        if (i < LW * LH) s_state[i] = v[k];
+        const int ly = i / LW, lx = i - ly * LW;
+        if (i < LW * LH) s_state[ly * SP + lx] = v[k];
       }
     } else {
       for (int i = tid; i < LW * LH; i += NT) {
@@ -679,14 +684,41 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
         const int gy = y0 - r + ly, gx = x0 - r + lx;
         unsigned v = 0u;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = load_state(alive + (size_t)gy * W + gx);
-        s_state[i] = v;
+        s_state[ly * SP + lx] = v;
       }
     }
     __syncthreads();
-    // ---- window maximum of the state words, rows then columns ----
-    for (int it = tid; it < LH * (CX / 8); it += NT) {
-      const int ly = it / (CX / 8), xs = (it - ly * (CX / 8)) * 8;
-      const unsigned* row = s_state + ly * LW + xs;
+    // ---- window maximum of the state words: columns (lanes along x), then rows (lanes along y) ----
+    for (int it = tid; it < LW * (CY / 8); it += NT) {
+      const int st = it / LW, x = it - st * LW;
+      const int ys = st * 8;
+      const unsigned* col = s_state + ys * SP + x;
+      if (R_T > 0) {
+        unsigned v[8 + 2 * R_T];
+#pragma unroll
+        for (int k = 0; k < 8 + 2 * R_T; ++k) v[k] = col[k * SP];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          unsigned m = v[o];
+#pragma unroll
+          for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
+          s_v[(ys + o) * SP + x] = m;
+        }
+      } else {
+        for (int o = 0; o < 8; ++o) {
+          unsigned m = col[o * SP];
+          for (int d = 1; d < WN; ++d) m = max(m, col[(o + d) * SP]);
+          s_v[(ys + o) * SP + x] = m;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      // one strip of eight window maxima per thread (CY * CX / 8 == NT), lanes along y; they are
+      // written over the column maxima, so every thread reads before any thread writes
+      const int y = tid & (CY - 1), xs = (tid / CY) * 8;
+      const unsigned* row = s_v + y * SP + xs;
+      unsigned out[8];
       if (R_T > 0) {
         unsigned v[8 + 2 * R_T];
 #pragma unroll
@@ -696,45 +728,19 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
           unsigned m = v[o];
 #pragma unroll
           for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
-          s_rmax[ly * CX + xs + o] = m;
-        }
-      } else {
-        for (int o = 0; o < 8; ++o) {
-          unsigned m = row[o];
-          for (int d = 1; d < WN; ++d) m = max(m, row[o + d]);
-          s_rmax[ly * CX + xs + o] = m;
-        }
-      }
-    }
-    __syncthreads();
-    {
-      // one strip of eight window maxima per thread (CX * CY / 8 == NT); they overwrite the row
-      // maxima they were computed from, so every thread reads before any thread writes
-      const int lx = tid & (CX - 1), ys = (tid / CX) * 8;
-      const unsigned* col = s_rmax + ys * CX + lx;
-      unsigned out[8];
-      if (R_T > 0) {
-        unsigned v[8 + 2 * R_T];
-#pragma unroll
-        for (int k = 0; k < 8 + 2 * R_T; ++k) v[k] = col[k * CX];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          unsigned m = v[o];
-#pragma unroll
-          for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
           out[o] = m;
         }
       } else {
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-          unsigned m = col[o * CX];
-          for (int d = 1; d < WN; ++d) m = max(m, col[(o + d) * CX]);
+          unsigned m = row[o];
+          for (int d = 1; d < WN; ++d) m = max(m, row[o + d]);
           out[o] = m;
         }
       }
       __syncthreads();
 #pragma unroll
-      for (int o = 0; o < 8; ++o) s_m[(ys + o) * CX + lx] = out[o];
+      for (int o = 0; o < 8; ++o) s_m[y * PM + xs + o] = out[o];
     }
     __syncthreads();
     // ---- candidates whose word tops their window ----
@@ -749,8 +755,8 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
       const unsigned cp = s_state[cell];
       if (cp < 3u) continue;                                   // selected or dead
       ++live;
-      const int ly = cell / LW, lx = cell - ly * LW;
-      if (s_m[(ly - r) * CX + (lx - r)] != cp) continue;       // a live neighbour has a larger word
+      const int ly = cell / SP, lx = cell - ly * SP;
+      if (s_m[(ly - r) * PM + (lx - r)] != cp) continue;       // a live neighbour has a larger word
       s_pass[atomicAdd(&s_npass, 1u)] = (unsigned short)cell;
     }
     const int any_live = __syncthreads_or(live ? 1 : 0);
@@ -766,13 +772,13 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
       unsigned* c = s_state + cell;
       const unsigned cp = *c;
       if (cp < 3u) continue;                                   // killed by a tied winner meanwhile
-      const int ly = cell / LW, lx = cell - ly * LW;
+      const int ly = cell / SP, lx = cell - ly * SP;
       const int py = y0 - r + ly, px = x0 - r + lx;
       bool blocked = false, killed = false;
       for (int t = lane; t < WN * WN; t += 64) {
         const int j = t / WN - r, d = t - (t / WN) * WN - r;
         if (j == 0 && d == 0) continue;
-        const unsigned v = c[j * LW + d];
+        const unsigned v = c[j * SP + d];
         if (v == 1u) killed = true;                            // a selected pixel owns this window
         if (v == cp) {
           const double s = sc[(size_t)py * W + px];
@@ -793,7 +799,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
       for (int t = lane; t < WN * WN; t += 64) {
         const int j = t / WN - r, d = t - (t / WN) * WN - r;
         if (j == 0 && d == 0) continue;
-        unsigned* q = c + j * LW + d;
+        unsigned* q = c + j * SP + d;
         if (*q >= 3u) {                                        // live words only (always inside the image)
           *q = 0u;
           store_state(alive + (size_t)(py + j) * W + (px + d), 0u);
@@ -838,7 +844,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   for (unsigned k = tid; k < nsel + nrem; k += NT) {
     const bool und = k >= nsel;
     const int cell = und ? s_pass[k - nsel] : s_sel[k];
-    const int ly = cell / LW, lx = cell - ly * LW;
+    const int ly = cell / SP, lx = cell - ly * SP;
     const unsigned idx = (unsigned)(y0 - r + ly) * (unsigned)W + (unsigned)(x0 - r + lx);
     const unsigned pos = base + k;
     if (pos < cap_c) {
@@ -1319,7 +1325,7 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
                        cand, keys_c, idx_c, alive, ctl, cap_c, hist, hist_other, N);
   }
   VO_TRY(vo_check_launch(ctx, "nms_compact_kernel"));
-  const size_t round_lds = ((size_t)(CX + 2 * r) * (CY + 2 * r) + (size_t)(CY + 2 * r) * CX) * 4;
+  const size_t round_lds = (size_t)((CX + 2 * r) | 1) * ((CY + 2 * r) + CY) * 4;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_ROUND);
     const dim3 g(nblk), b(NT);
