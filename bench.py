@@ -38,14 +38,11 @@ def algorithmic_bytes(kernel_name, n_tracked):
     table = {
         "harris_response": px * 1 + px * 8,                   # image read once, fp64 map written once
         "nms_candidates": px * 8,                             # fp64 map read once
-        "nms_threshold": 65536 * 4 * 2,                       # histogram read + cleared
         "nms_compact": N_KP * 12,                             # the N selected strict maxima
         "nms_round": N_KP * 4 * 2,                            # state words of the picks (list traffic is not compulsory)
-        "nms_collect": 0,
         "nms_rank": N_KP * 12,
-        "nms_emit": N_KP * 16,                                # keypoints written
-        "nms_select": N_KP * 16,
-        "pyr_down": (px + px // 4) // 2,                      # per launch (2 launches): read level l, write level l+1
+        "nms_select": N_KP * 16,                              # keypoints written
+        "pyr_down": (2 * px + px // 4 + px // 4 + px // 16) // 3,   # per launch (3 launches): bordered copy of level 0, levels 1 and 2
         "klt_track": N_KP * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + N_KP * (8 + 8 + 1 + 4),
         "track_gather": N_KP * (8 + 1 + 4 + 16) + n_tracked * (16 + 16 + 24 + 4),
         "p3p_solve": HYP * (16 + 4 * 40 + 96 + 1),
@@ -53,6 +50,24 @@ def algorithmic_bytes(kernel_name, n_tracked):
         "dlt_triangulate": n_tracked * (16 + 16 + 24) + 192,
     }
     return table.get(kernel_name)
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this
+    same command, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes); None if the
+    file or the kernel is missing.  bench.py itself cannot run under the counters."""
+    names = {"klt_track": "klt_track16_kernel", "nms_round": "nms_round_kernel<5, true>",
+             "nms_candidates": "nms_candidates_kernel<5>", "harris_response": "harris_response_kernel<9>",
+             "p3p_solve": "p3p_solve_kernel<true>", "p3p_score": "p3p_score_kernel", "dlt_triangulate": "dlt_kernel",
+             "nms_compact": "nms_compact_kernel", "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel",
+             "track_gather": "gather_tracks_kernel"}
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            table = json.load(f)
+        return int(table[names[kernel_name]]["hbm_bytes_corrected"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(stream, frames=3):
@@ -199,7 +214,8 @@ def main():
         avg_us = dom_ms / max(dom_n, 1) * 1e3
         ab = algorithmic_bytes(dom_name, ntr)
         roof = {"bound": "hbm", "kernel": dom_name, "avg_launch_us": round(avg_us, 3), "launches": dom_n,
-                "algorithmic_bytes_per_launch": ab, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+                "algorithmic_bytes_per_launch": ab, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "traffic": pmc_traffic(dom_name)}
         if ab:
             ach = ab / (avg_us * 1e-6) / 1e9
             roof["achieved"] = round(ach, 2)
