@@ -128,8 +128,10 @@ int vo_patch_descriptors_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W,
  * next_xy N*2 float32, status N uint8, err N float32 (mean |patch diff| / 32).
  * Pyramid level l+1 is ((H+1)/2, (W+1)/2); the number of levels actually used is
  * vo_klt_num_levels (the builder stops when a level is not larger than the
- * window).  The _dev form takes level 0 (the image) and a buffer holding levels
- * 1..n-1 back to back, each rounded up to 256 bytes (vo_pyramid_bytes).        */
+ * window).  The _dev form takes the images and, for each, the buffer that
+ * vo_pyramid_build_dev filled (vo_pyramid_bytes): an opaque layout holding every
+ * level, level 0 included, with a reflect-101 border so the tracker's blocks are
+ * plain in-bounds reads.  The tracker reads the levels from those buffers only. */
 int vo_klt_num_levels(int H, int W, int win, int max_level);
 size_t vo_pyramid_bytes(int H, int W, int n_levels);
 int vo_pyr_down(vo_ctx* ctx, const uint8_t* img, int H, int W, uint8_t* out);
