@@ -1,5 +1,5 @@
 import csv, glob, sys
-f = sorted(glob.glob('gpurun_out/prof3/**/*kernel_trace.csv', recursive=True), key=lambda p: __import__('os').path.getmtime(p))[-1]
+f = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob('gpurun_out/prof3/**/*kernel_trace.csv', recursive=True), key=lambda p: __import__('os').path.getmtime(p))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]

@@ -67,7 +67,14 @@ struct vo_pipeline {
   // pinned host
   int32_t* h_ntracked = nullptr;
   int32_t* h_samples = nullptr;
-  uint32_t* h_raw = nullptr;         // 7 * hyp generator outputs for the device-side sampler
+  // look-ahead of the estimator's generator for the device-side sampler: h_raw[raw_pos ..
+  // raw_fill) are its next 32-bit outputs (raw_gen = its state behind raw_fill).  A step
+  // consumes 7 per sample of the sequential rule, so the tail serves the following steps and
+  // the top-up happens while the GPU works, not on the way to the launches.
+  uint32_t* h_raw = nullptr;
+  size_t raw_cap = 0, raw_pos = 0, raw_fill = 0;
+  vo_pcg64 raw_gen;
+  bool raw_valid = false;
   uint8_t* h_valid = nullptr;
   int32_t* h_counts = nullptr;
   double* h_pose = nullptr;          // 12
@@ -334,7 +341,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_masks, (size_t)Hyp * vo_cdiv(N, 64)));
   PA(pin_alloc(ctx, &p->h_ntracked, 4));
   PA(pin_alloc(ctx, &p->h_samples, (size_t)Hyp * 4));
-  PA(pin_alloc(ctx, &p->h_raw, (size_t)Hyp * 7));
+  p->raw_cap = (size_t)Hyp * 7 * 4;
+  PA(pin_alloc(ctx, &p->h_raw, p->raw_cap));
   PA(pin_alloc(ctx, &p->h_valid, (size_t)Hyp));
   PA(pin_alloc(ctx, &p->h_counts, (size_t)Hyp));
   PA(pin_alloc(ctx, &p->h_pose, 12));
@@ -435,6 +443,7 @@ int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img, const flo
 int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
   if (!p || !rng) return VO_EINVAL;
   p->rng = *rng;
+  p->raw_valid = false;
   p->seeded = true;
   return VO_OK;
 }
@@ -473,7 +482,7 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
                           p->d_next_f32, p->d_status, p->d_err));
   if (det_pos == 1) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
   // the track set this gather fills was the input of the DLT queued behind the last detection
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDltDone, 0));
+  if (hipEventQuery(p->evDltDone) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDltDone, 0));
   {
     vo_prof_scope ps(ctx, VO_K_GATHER);
     hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->d_kp[a], p->d_next_f32,
@@ -482,7 +491,7 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
                        p->d_ntracked, cs);
   }
   VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
-  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], p->d_ntracked, N, c.K, p->m_raw, c.hyp,
+  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], p->d_ntracked, N, c.K, p->m_raw + p->raw_pos, c.hyp,
                                    c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks,
                                    (uint32_t*)p->d_ntracked + 2));
   return VO_OK;
@@ -608,10 +617,18 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     if (p->dbg_last_return > 0) p->dbg_t[3] += t_entry - p->dbg_last_return;
   }
 
-  // Generator outputs for the device-side sampler: drawn from a copy, the real generator
-  // advances by what the sequential rule consumes (below).
-  vo_pcg64 g = p->rng;
-  vo_rng_raw32(&g, 7 * c.hyp, p->h_raw);
+  // Generator outputs for the device-side sampler (a look-ahead; the real generator advances
+  // by what the sequential rule consumes, below).  Normally they are already there.
+  const size_t need = (size_t)7 * c.hyp;
+  if (!p->raw_valid || p->raw_fill < p->raw_pos + need) {
+    if (!p->raw_valid) {
+      p->raw_gen = p->rng;
+      p->raw_pos = p->raw_fill = 0;
+      p->raw_valid = true;
+    }
+    vo_rng_raw32(&p->raw_gen, (int)(p->raw_pos + need - p->raw_fill), p->h_raw + p->raw_fill);
+    p->raw_fill = p->raw_pos + need;
+  }
   const unsigned seq_b0 = ++p->seq;
   p->h_seq[2] = seq_b0;                               // the mirror kernel publishes this value when it is done
 
@@ -621,7 +638,9 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   static const int det_pos = getenv("VO_DET_POS") ? atoi(getenv("VO_DET_POS")) : 0;
   if (det_pos == 0) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[ev_prev], 0));   // keypoints of `prev`
+  // keypoints of `prev`: usually long finished, and then no barrier goes into the queue
+  if (hipEventQuery(p->evDet[ev_prev]) != hipSuccess)
+    VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[ev_prev], 0));
   VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, det_pos));
   VO_TRY(launch_mirror(p, true));
   if (det_pos == 2) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
@@ -629,6 +648,11 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   unsigned seq_b = seq_b0;
 
   if (dbg) t_enq = now();
+  // while the GPU works: extend the look-ahead so the next step finds its outputs ready
+  if (p->raw_fill < p->raw_pos + 2 * need && p->raw_pos + 2 * need <= p->raw_cap) {
+    vo_rng_raw32(&p->raw_gen, (int)(p->raw_pos + 2 * need - p->raw_fill), p->h_raw + p->raw_fill);
+    p->raw_fill = p->raw_pos + 2 * need;
+  }
   VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
   if (dbg) t_res = now();
   const int n = ((volatile int32_t*)p->h_ntracked)[0];
@@ -646,9 +670,15 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     int total_consumed = 0, finished = 0, batches = 0, hyp_valid = 0;
     bool have_batch = !redo;
     int words = vo_cdiv(N, 64);
-    if (redo) g = p->rng;   // a draw may have been rejected (or n < 8): the batch is redone from sequential samples
+    // generator copy for batches drawn by the sequential sampler: the first batch again if a draw
+    // may have been rejected (or n < 8), later batches if the rule is not done after c.hyp samples
+    vo_pcg64 g = p->rng;
     while (!finished) {
       if (!have_batch) {
+        if (batches == 1 && !redo) {   // skip what the device-side batch consumed
+          std::vector<int32_t> skip((size_t)4 * c.hyp);
+          VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, skip.data()));
+        }
         VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, p->h_samples));
         seq_b = ++p->seq;
         p->h_seq[2] = seq_b;
@@ -682,6 +712,15 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     {
       std::vector<int32_t> tmp((size_t)4 * (total_consumed > 0 ? total_consumed : 1));
       VO_TRY(vo_rng_choice(&p->rng, n, 4, total_consumed, tmp.data()));
+    }
+    // the look-ahead moves with the generator: 7 outputs per consumed sample when every draw
+    // was accepted at once (no flag) and only the device-side batch was used
+    if (!redo && batches == 1) p->raw_pos += (size_t)7 * total_consumed;
+    else p->raw_valid = false;
+    if (p->raw_valid && p->raw_pos > p->raw_cap / 2) {   // make room (the solve kernel has finished reading)
+      memmove(p->h_raw, p->h_raw + p->raw_pos, (p->raw_fill - p->raw_pos) * sizeof(uint32_t));
+      p->raw_fill -= p->raw_pos;
+      p->raw_pos = 0;
     }
     out->n_inliers = best_count > 0 ? best_count : 0;
     out->best_index = best_idx;
