@@ -77,6 +77,142 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(const uint8_t* __restr
   dst[(size_t)yp * dpitch + xp] = src[(size_t)reflect101(yp - PYR_PAD, H) * W + reflect101(xp - PYR_PAD, W)];
 }
 
+// v = interior pixel (x, y) of a W x H level -> its place in the bordered buffer and every border
+// place that mirrors onto it (one reflection: needs min(W, H) > PYR_PAD)
+__device__ __forceinline__ void store_with_mirrors(uint8_t* __restrict__ dst, int pitch, int H, int W, int x, int y,
+                                                   uint8_t v) {
+  int xs[3], ys[3];
+  int nx = 1, ny = 1;
+  xs[0] = x + PYR_PAD;
+  ys[0] = y + PYR_PAD;
+  if (x >= 1 && x <= PYR_PAD) xs[nx++] = PYR_PAD - x;
+  if (x >= W - 1 - PYR_PAD && x <= W - 2) xs[nx++] = PYR_PAD + 2 * (W - 1) - x;
+  if (y >= 1 && y <= PYR_PAD) ys[ny++] = PYR_PAD - y;
+  if (y >= H - 1 - PYR_PAD && y <= H - 2) ys[ny++] = PYR_PAD + 2 * (H - 1) - y;
+  for (int j = 0; j < ny; ++j)
+    for (int i = 0; i < nx; ++i) dst[(size_t)ys[j] * pitch + xs[i]] = v;
+}
+
+// 5x5 [1 4 6 4 1]^2 tap at (2x, 2y) of an unbordered W x H image, reflect-101
+__device__ __forceinline__ int pyr_tap(const uint8_t* __restrict__ src, int pitch, int H, int W, int x, int y) {
+  int xs[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) xs[i] = reflect101(2 * x + i - 2, W);
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const uint8_t* row = src + (size_t)reflect101(2 * y + j - 2, H) * pitch;
+    const int r = row[xs[0]] + 4 * row[xs[1]] + 6 * row[xs[2]] + 4 * row[xs[3]] + row[xs[4]];
+    const int wj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+    sum += wj * r;
+  }
+  return (sum + 128) >> 8;
+}
+
+// Levels 0, 1 and 2 of the bordered pyramid in ONE launch (three dependent launches were
+// 22 us of the step's critical path).  No workgroup waits for another:
+//   * the first nB workgroups each produce a 16x16 tile of level 2 from a 35x35 patch of level 1
+//     that they compute for themselves in LDS (straight from the frame);
+//   * the others produce level 1 (one pixel per thread) and copy the 2x2 frame pixels under it
+//     into the bordered level 0.
+// Border pixels are written by the thread that owns the interior pixel they mirror.
+__global__ __launch_bounds__(256) void pyramid3_kernel(const uint8_t* __restrict__ src, int H0, int W0,
+                                                       uint8_t* __restrict__ d0, int p0, uint8_t* __restrict__ d1,
+                                                       int p1, int H1, int W1, uint8_t* __restrict__ d2, int p2,
+                                                       int H2, int W2, int nB, int tiles2_x, int blocks1_x) {
+  __shared__ uint8_t s_l0[73 * 76];   // frame patch under the level-1 patch
+  __shared__ uint8_t s_l1[35 * 36];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nB) {
+    const int tx = (int)blockIdx.x % tiles2_x, ty = (int)blockIdx.x / tiles2_x;
+    const int x2a = tx * 16, y2a = ty * 16;
+    // Level-1 patch entry (ly, lx) stands for level-1 coordinate (2 y2a - 2 + ly, 2 x2a - 2 + lx),
+    // reflected into level 1 where that falls outside.  For every level-2 pixel this tile stores
+    // the reflected coordinates stay inside [lo, hi], so the frame pixels under them are one
+    // contiguous patch (reflected at the frame's own edges), staged once.
+    const int ax = 2 * x2a - 2, ay = 2 * y2a - 2;
+    const int lox = max(ax, 0), hix = min(ax + 34, W1 - 1);
+    const int loy = max(ay, 0), hiy = min(ay + 34, H1 - 1);
+    const int fx0 = 2 * lox - 2, fy0 = 2 * loy - 2;             // frame coordinate of s_l0[0][0]
+    const int fw = 2 * (hix - lox) + 5, fh = 2 * (hiy - loy) + 5;
+    for (int i = tid; i < fw * fh; i += 256) {
+      const int ly = i / fw, lx = i - ly * fw;
+      int gx = fx0 + lx, gy = fy0 + ly;                         // at most 2 pixels outside: one reflection
+      gx = gx < 0 ? -gx : (gx >= W0 ? 2 * (W0 - 1) - gx : gx);
+      gy = gy < 0 ? -gy : (gy >= H0 ? 2 * (H0 - 1) - gy : gy);
+      s_l0[ly * 76 + lx] = src[(size_t)gy * W0 + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < 35 * 35; i += 256) {
+      const int ly = i / 35, lx = i - ly * 35;
+      int x1 = reflect101(ax + lx, W1), y1 = reflect101(ay + ly, H1);
+      x1 = min(max(x1, lox), hix);                              // (only entries no stored pixel uses are clamped)
+      y1 = min(max(y1, loy), hiy);
+      const uint8_t* q = s_l0 + (2 * (y1 - loy)) * 76 + 2 * (x1 - lox);
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const uint8_t* row = q + j * 76;
+        const int r = row[0] + 4 * row[1] + 6 * row[2] + 4 * row[3] + row[4];
+        const int wj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+        sum += wj * r;
+      }
+      s_l1[ly * 36 + lx] = (uint8_t)((sum + 128) >> 8);
+    }
+    __syncthreads();
+    const int lx = tid & 15, ly = tid >> 4;
+    const int x2 = x2a + lx, y2 = y2a + ly;
+    if (x2 < W2 && y2 < H2) {
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const uint8_t* row = s_l1 + (2 * ly + j) * 36 + 2 * lx;
+        const int r = row[0] + 4 * row[1] + 6 * row[2] + 4 * row[3] + row[4];
+        const int wj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+        sum += wj * r;
+      }
+      store_with_mirrors(d2, p2, H2, W2, x2, y2, (uint8_t)((sum + 128) >> 8));
+    }
+    return;
+  }
+  // level 1: a 32x8 tile per workgroup from a 67x19 frame patch staged once; the patch's centre
+  // is also what goes into the bordered level 0
+  const int blk = (int)blockIdx.x - nB;
+  const int x1a = (blk % blocks1_x) * 32, y1a = (blk / blocks1_x) * 8;
+  const int fx0 = 2 * x1a - 2, fy0 = 2 * y1a - 2;
+  for (int i = tid; i < 67 * 19; i += 256) {
+    const int ly = i / 67, lx = i - ly * 67;
+    int gx = fx0 + lx, gy = fy0 + ly;
+    gx = gx < 0 ? -gx : (gx >= W0 ? 2 * (W0 - 1) - gx : gx);     // at most 2 pixels outside (tiles that stick out
+    gy = gy < 0 ? -gy : (gy >= H0 ? 2 * (H0 - 1) - gy : gy);     //  further only feed pixels that are not stored)
+    gx = min(max(gx, 0), W0 - 1);
+    gy = min(max(gy, 0), H0 - 1);
+    s_l0[ly * 76 + lx] = src[(size_t)gy * W0 + gx];
+  }
+  __syncthreads();
+  const int lx = tid & 31, ly = tid >> 5;
+  const int x1 = x1a + lx, y1 = y1a + ly;
+  if (x1 >= W1 || y1 >= H1) return;
+  {
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const uint8_t* row = s_l0 + (2 * ly + j) * 76 + 2 * lx;
+      const int r = row[0] + 4 * row[1] + 6 * row[2] + 4 * row[3] + row[4];
+      const int wj = (j == 0 || j == 4) ? 1 : ((j == 2) ? 6 : 4);
+      sum += wj * r;
+    }
+    store_with_mirrors(d1, p1, H1, W1, x1, y1, (uint8_t)((sum + 128) >> 8));
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int x0 = 2 * x1 + dx, y0 = 2 * y1 + dy;
+      if (x0 < W0 && y0 < H0) store_with_mirrors(d0, p0, H0, W0, x0, y0, s_l0[(2 * ly + 2 + dy) * 76 + 2 * lx + 2 + dx]);
+    }
+}
+
 // Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic), result in
 // every lane.  Steps: within quads, within half rows, within rows of 16, then the two
 // row broadcasts that gfx9 provides for wave64.
@@ -657,16 +793,36 @@ int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_
   VO_REQUIRE(ctx, d_img && d_pyr, "pyramid_build: null pointer");
   VO_REQUIRE(ctx, H > 0 && W > 0 && n_levels >= 1 && n_levels <= MAX_LEVELS, "pyramid_build: bad arguments");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  {
+  const int h1 = (H + 1) / 2, w1 = (W + 1) / 2, h2 = (h1 + 1) / 2, w2 = (w1 + 1) / 2;
+  int first_plain = 1;              // first level the per-level kernel still has to make
+  const uint8_t* src = d_img;       // interior origin and pitch of the level above it
+  int spitch = W, h = H, w = W;
+  uint8_t* dst = d_pyr + pyr_level_bytes(H, W);
+  if (n_levels >= 3 && h2 > PYR_PAD && w2 > PYR_PAD) {
+    // levels 0..2 in one launch
+    uint8_t* d1 = dst;
+    uint8_t* d2 = d1 + pyr_level_bytes(h1, w1);
+    const int tiles2_x = vo_cdiv(w2, 16), nB = tiles2_x * vo_cdiv(h2, 16);
+    const int blocks1_x = vo_cdiv(w1, 32), nA = blocks1_x * vo_cdiv(h1, 8);
+    {
+      vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
+      hipLaunchKernelGGL(pyramid3_kernel, dim3(nB + nA), dim3(256), 0, ctx->stream, d_img, H, W, d_pyr, pyr_pitch(W), d1,
+                         pyr_pitch(w1), h1, w1, d2, pyr_pitch(w2), h2, w2, nB, tiles2_x, blocks1_x);
+    }
+    VO_TRY(vo_check_launch(ctx, "pyramid3_kernel"));
+    first_plain = 3;
+    src = d2 + (size_t)PYR_PAD * pyr_pitch(w2) + PYR_PAD;
+    spitch = pyr_pitch(w2);
+    dst = d2 + pyr_level_bytes(h2, w2);
+    h = h2;
+    w = w2;
+  } else {
     vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
     hipLaunchKernelGGL(pad_reflect_kernel, dim3(vo_cdiv(W + 2 * PYR_PAD, 64), vo_cdiv(H + 2 * PYR_PAD, 4)), dim3(256), 0,
                        ctx->stream, d_img, H, W, d_pyr, pyr_pitch(W));
   }
   VO_TRY(vo_check_launch(ctx, "pad_reflect_kernel"));
-  const uint8_t* src = d_img;       // interior origin and pitch of the level above
-  int spitch = W, h = H, w = W;
-  uint8_t* dst = d_pyr + pyr_level_bytes(H, W);
-  for (int l = 1; l < n_levels; ++l) {
+  for (int l = first_plain; l < n_levels; ++l) {
     const int hd = (h + 1) / 2, wd = (w + 1) / 2;
     const int dpitch = pyr_pitch(wd);
     {
