@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lookahead", action="store_true",
+                    help="submit frame k+1 before collecting frame k (vo_pipeline_submit / _collect)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,11 +144,21 @@ def main():
     stats = {"tracked": [], "inliers": [], "rot_err": [], "trans_err": [], "iters": [], "tri_err": []}
 
     def run(n, record=False):
+        # --lookahead: one frame of look-ahead, as a camera stream gives it: frame k+1 is submitted (all
+        # of its GPU work enqueued) before the pose of frame k is collected, so the host's share of a
+        # step overlaps the GPU's.  Default: the reference's order, one blocking call per frame.
         nonlocal pos
+        if args.lookahead:
+            pipe.submit(order[pos], order[pos + 1])
         for k in range(n):
             a, b = order[pos], order[pos + 1]
             pos += 1
-            r = pipe.step(a, b)
+            if args.lookahead:
+                if k + 1 < n:
+                    pipe.submit(order[pos], order[pos + 1])
+                r = pipe.collect()
+            else:
+                r = pipe.step(a, b)
             if world > 1:
                 s = k & 1
                 if comm_done[s] is not None:

@@ -276,6 +276,14 @@ int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img, const flo
 int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng);
 int vo_pipeline_prime(vo_pipeline* p, int idx);
 int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out);
+/* vo_pipeline_step in two halves, for a caller that has the next frame before it needs the
+ * last pose (a camera stream): submit enqueues all GPU work of the frame and returns;
+ * collect waits for it and runs the sequential RANSAC rule (main.py:248-268's
+ * estimate_pose).  At most two steps may be in flight, collected in submission order; with
+ * one step of look-ahead (submit k+1, then collect k) the host's share of a step overlaps
+ * the GPU's.  Results are identical to vo_pipeline_step.                              */
+int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx);
+int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out);
 /* vo_prof_read / vo_prof_reset over both of the pipeline's streams (detection runs on a
  * second stream beside tracking).                                                   */
 int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64_t* launches);

@@ -81,3 +81,46 @@ def test_pipeline_matches_oracle_composition(ctx, H, W, N, hyp, sampler, monkeyp
         assert np.abs(R - Tcw[:3, :3]).max() < 5e-3 and np.abs(t - Tcw[:3, 3]).max() < 0.1
         kp = ref["kp_next"]
     pipe.close()
+
+
+@pytest.mark.parametrize("sampler", ["device", "sequential"])
+def test_pipeline_lookahead_matches_step(ctx, sampler, monkeypatch):
+    """submit(k+1) before collect(k) (one frame of look-ahead) must give what step() gives frame by
+    frame: same counts, same RANSAC bookkeeping, same poses -- including the generator hand-over
+    between a collected step and the one already in flight."""
+    from vo import _native, synthetic
+    if sampler == "sequential":
+        monkeypatch.setenv("VO_SEQ_SAMPLER", "1")
+    else:
+        monkeypatch.delenv("VO_SEQ_SAMPLER", raising=False)
+    H, W, N, hyp, F = 240, 320, 300, 256, 5
+    stream = synthetic.Stream(F, H, W)
+    order = stream.order(12)
+
+    def make():
+        pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp,
+                                p3p_threshold=1.0, max_iterations=1000)
+        for i in range(F):
+            pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
+        pipe.prime(order[0])
+        return pipe
+
+    def fields(r):
+        return (r.n_tracked, r.n_inliers, r.best_index, r.hyp_valid, r.ransac_iterations, r.draws_consumed,
+                tuple(r.R), tuple(r.t))
+
+    pipe = make()
+    ref = [fields(pipe.step(a, b)) for a, b in zip(order[:-1], order[1:])]
+    pipe.close()
+    pipe = make()
+    got = []
+    pairs = list(zip(order[:-1], order[1:]))
+    pipe.submit(*pairs[0])
+    for k in range(len(pairs)):
+        if k + 1 < len(pairs):
+            pipe.submit(*pairs[k + 1])
+        got.append(fields(pipe.collect()))
+    last = pipe.fetch(got[-1][0])            # nothing in flight any more: fetch works again
+    assert last["prev_xy"].shape == (got[-1][0], 2)
+    pipe.close()
+    assert got == ref

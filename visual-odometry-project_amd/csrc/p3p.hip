@@ -168,6 +168,7 @@ template <bool RAW>
 __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
                                                        const int* __restrict__ samples,
                                                        const unsigned* __restrict__ raws,
+                                                       const unsigned* __restrict__ rawctl, unsigned raw_tag,
                                                        const int* __restrict__ d_n, unsigned* __restrict__ flag,
                                                        int Hyp, double fx,
                                                        double fy, double cx, double cy, double* __restrict__ Rout,
@@ -176,6 +177,28 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
   // then lane `sub` takes root `sub` through the triad alignment and the fourth-point test
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = gt >> 2, sub = gt & 3;
+  if (RAW && rawctl) {
+    // Where this step's outputs start in the host's look-ahead buffer is known once the previous
+    // step's consumption is: the host publishes {tag, position} in mapped memory, normally long
+    // before this kernel runs.  Bounded wait; on time-out the host redoes the batch.
+    __shared__ unsigned s_pos;
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      bool ok = true;
+      while (__hip_atomic_load(rawctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != raw_tag) {
+        if (++spins > 4000) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(64);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      s_pos = ok ? __hip_atomic_load(rawctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+      if (!ok) atomicOr(flag, 1u);
+    }
+    __syncthreads();
+    raws += s_pos;
+  }
   if (h >= Hyp) return;                 // whole quads leave together
   int sidx[4];
   if (RAW) {
@@ -405,8 +428,9 @@ __global__ __launch_bounds__(256) void reproj_kernel(const double* __restrict__ 
 // Pipeline-internal form of vo_p3p_hypotheses_dev: population size and generator outputs are
 // device-readable and need not be final when this is enqueued (see p3p_solve_kernel<true>).
 int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
-                              const double* K, const uint32_t* d_raws, int Hyp, double thr_sq, double* d_R,
-                              double* d_t, uint8_t* d_valid, int32_t* d_counts, uint64_t* d_masks, uint32_t* d_flag) {
+                              const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
+                              int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
+                              uint64_t* d_masks, uint32_t* d_flag) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, d_X && d_x && d_n && K && d_raws && d_R && d_t && d_valid && d_counts && d_flag,
              "p3p_hypotheses_raw: null pointer");
@@ -416,7 +440,8 @@ int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x,
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<true>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
-                       (const int*)nullptr, d_raws, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid);
+                       (const int*)nullptr, d_raws, d_rawctl, raw_tag, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t,
+                       d_valid);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   {
@@ -441,8 +466,8 @@ int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<false>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
-                       d_samples, (const unsigned*)nullptr, (const int*)nullptr, (unsigned*)nullptr, Hyp, fx, fy, cx,
-                       cy, d_R, d_t, d_valid);
+                       d_samples, (const unsigned*)nullptr, (const unsigned*)nullptr, 0u, (const int*)nullptr,
+                       (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   const int words = vo_cdiv(N, 64);

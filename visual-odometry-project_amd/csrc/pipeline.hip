@@ -26,6 +26,8 @@
 struct vo_pipeline {
   vo_ctx* ctx = nullptr;
   vo_ctx* det = nullptr;            // second context (own stream + NMS workspace): detection runs beside tracking
+  vo_ctx* redo = nullptr;           // third stream: hypothesis batches of the sequential sampler (rare) must not queue
+                                    // behind a step submitted later, whose solve kernel waits for this step's outcome
   hipEvent_t evDet[2] = {nullptr, nullptr};   // keypoints ready; steps alternate, so the wait for the last step's
                                               // event cannot catch this step's record
   int ev_last = 0;                            // index of the event the latest detection records
@@ -35,7 +37,8 @@ struct vo_pipeline {
   std::thread worker;
   std::atomic<unsigned> job_posted{0}, job_done{0};
   std::atomic<bool> quit{false};
-  struct { int frame, slot, prev_set, ev; bool with_dlt; } job = {0, 0, 0, 0, false};
+  struct job_t { int kind, frame, slot, ev; };   // kind 0: detection of `frame` into keypoint buffer `slot`; 1: DLT of track set `slot`
+  job_t jobs[8];
   int job_rc = 0;
   bool det_warm = false;
   vo_pipeline_config cfg;
@@ -56,16 +59,23 @@ struct vo_pipeline {
   uint8_t* d_status = nullptr;
   // compacted tracks, two sets: the deferred DLT of step k reads set k&1 while step k+1 fills the other
   double *d_prev_c[2] = {nullptr, nullptr}, *d_next_c[2] = {nullptr, nullptr}, *d_land_c[2] = {nullptr, nullptr};
-  double* d_tri = nullptr;
-  int cset = 0;                      // set written by the last step
-  bool dlt_pending = false;          // the last step's DLT has not been enqueued yet (the next step does it)
-  int32_t* d_ntracked = nullptr;
+  // Everything a step's hypotheses produce exists twice ("slot" = its track set, alternating):
+  // a step may be submitted while the previous one's results are still being read.
+  double* d_tri = nullptr;           // 2 x N x 3
+  int cset = 0;                      // set of the last submitted step
+  int32_t* d_ntracked = nullptr;     // 2 x 8: [0] tracked count, [1] mirror arrival counter, [2] sampler flag
   double *d_R = nullptr, *d_t = nullptr;
   uint8_t* d_valid = nullptr;
   int32_t* d_counts = nullptr;
   uint64_t* d_masks = nullptr;
+  // steps submitted and not yet collected (at most two), oldest first
+  struct flight_t { int prev_idx, next_idx, slot; unsigned seq; bool raw_published; };
+  flight_t flight[2];
+  int n_flight = 0;
+  bool dlt_unflushed = false;        // the last collected step's DLT job has not been posted
+  int cset_collected = 0;            // slot of the last collected step
   // pinned host
-  int32_t* h_ntracked = nullptr;
+  int32_t* h_ntracked = nullptr;     // 2 x 4
   int32_t* h_samples = nullptr;
   // look-ahead of the estimator's generator for the device-side sampler: h_raw[raw_pos ..
   // raw_fill) are its next 32-bit outputs (raw_gen = its state behind raw_fill).  A step
@@ -79,7 +89,8 @@ struct vo_pipeline {
   int32_t* h_counts = nullptr;
   double* h_pose = nullptr;          // 12
   double *h_R = nullptr, *h_t = nullptr;     // all hypotheses' poses, written by the GPU into mapped host memory
-  volatile unsigned* h_seq = nullptr;         // [0] tracking done, [1] hypotheses mirrored: sequence numbers the host spins on
+  volatile unsigned* h_seq = nullptr;         // per slot s: [4s+1] published by the mirror kernel, [4s+2] value it shall publish;
+                                              // [8+2s], [9+2s]: {tag, offset} of the slot's outputs in h_raw
   unsigned seq = 0;
   double* h_C = nullptr;             // 2 x 24 (C1, C2), alternating with the track sets
   // device aliases of the mapped host buffers
@@ -114,8 +125,7 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
                                                              double fy, double cx, double cy,
                                                              const double* __restrict__ T_wc,
                                                              double* __restrict__ prev_c, double* __restrict__ next_c,
-                                                             double* __restrict__ land_c, int32_t* __restrict__ n_out,
-                                                             int cs) {
+                                                             double* __restrict__ land_c, int32_t* __restrict__ n_out) {
   // All loads of up to four passes (4096 keypoints) go out before anything is consumed: one
   // round trip for the tracker's outputs, one for the depth look-ups that depend on them.
   constexpr int GE = 4;
@@ -182,7 +192,6 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
   if (tid == 0) {
     n_out[0] = s_base;
     n_out[2] = 0;           // "sampler needs the sequential path" flag of the solve kernel that follows
-    n_out[4 + cs] = s_base; // count of track set cs, for the DLT that runs during the next step
   }
 }
 
@@ -262,6 +271,12 @@ int spin_until(vo_ctx* ctx, volatile unsigned* word, unsigned value) {
   return *word == value ? VO_OK : vo_set_error(ctx, VO_EHIP, "pipeline: the GPU never published sequence %u", value);
 }
 
+double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
 void rigid_inverse(const double* T, double* Ti) {
   // T = [R t; 0 1] -> [R^T  -R^T t]
   for (int r = 0; r < 3; ++r)
@@ -299,7 +314,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   if (!p) return VO_ENOMEM;
   p->ctx = ctx;
   p->cfg = *cfg;
-  if (vo_create(ctx->device, nullptr, &p->det) != VO_OK) {
+  if (vo_create(ctx->device, nullptr, &p->det) != VO_OK || vo_create(ctx->device, nullptr, &p->redo) != VO_OK) {
+    if (p->det) vo_destroy(p->det);
     delete p;
     return vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the detection stream");
   }
@@ -332,22 +348,22 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     PA(dev_alloc(ctx, &p->d_next_c[k], (size_t)N * 2));
     PA(dev_alloc(ctx, &p->d_land_c[k], (size_t)N * 3));
   }
-  PA(dev_alloc(ctx, &p->d_tri, (size_t)N * 3));
-  PA(dev_alloc(ctx, &p->d_ntracked, 8));
-  PA(dev_alloc(ctx, &p->d_R, (size_t)Hyp * 9));
-  PA(dev_alloc(ctx, &p->d_t, (size_t)Hyp * 3));
-  PA(dev_alloc(ctx, &p->d_valid, (size_t)Hyp));
-  PA(dev_alloc(ctx, &p->d_counts, (size_t)Hyp));
-  PA(dev_alloc(ctx, &p->d_masks, (size_t)Hyp * vo_cdiv(N, 64)));
-  PA(pin_alloc(ctx, &p->h_ntracked, 4));
+  PA(dev_alloc(ctx, &p->d_tri, (size_t)2 * N * 3));
+  PA(dev_alloc(ctx, &p->d_ntracked, 16));
+  PA(dev_alloc(ctx, &p->d_R, (size_t)2 * Hyp * 9));
+  PA(dev_alloc(ctx, &p->d_t, (size_t)2 * Hyp * 3));
+  PA(dev_alloc(ctx, &p->d_valid, (size_t)2 * Hyp));
+  PA(dev_alloc(ctx, &p->d_counts, (size_t)2 * Hyp));
+  PA(dev_alloc(ctx, &p->d_masks, (size_t)2 * Hyp * vo_cdiv(N, 64)));
+  PA(pin_alloc(ctx, &p->h_ntracked, 8));
   PA(pin_alloc(ctx, &p->h_samples, (size_t)Hyp * 4));
-  p->raw_cap = (size_t)Hyp * 7 * 4;
+  p->raw_cap = (size_t)Hyp * 7 * 16;
   PA(pin_alloc(ctx, &p->h_raw, p->raw_cap));
-  PA(pin_alloc(ctx, &p->h_valid, (size_t)Hyp));
-  PA(pin_alloc(ctx, &p->h_counts, (size_t)Hyp));
+  PA(pin_alloc(ctx, &p->h_valid, (size_t)2 * Hyp));
+  PA(pin_alloc(ctx, &p->h_counts, (size_t)2 * Hyp));
   PA(pin_alloc(ctx, &p->h_pose, 12));
-  PA(pin_alloc(ctx, &p->h_R, (size_t)Hyp * 9));
-  PA(pin_alloc(ctx, &p->h_t, (size_t)Hyp * 3));
+  PA(pin_alloc(ctx, &p->h_R, (size_t)2 * Hyp * 9));
+  PA(pin_alloc(ctx, &p->h_t, (size_t)2 * Hyp * 3));
   {
     unsigned* q = nullptr;
     PA(pin_alloc(ctx, &q, 16));
@@ -378,7 +394,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     vo_pipeline_destroy(p);
     return rc;
   }
-  if (hipMemset(p->d_ntracked, 0, 32) != hipSuccess) {
+  if (hipMemset(p->d_ntracked, 0, 64) != hipSuccess) {
     vo_pipeline_destroy(p);
     return vo_set_error(ctx, VO_EHIP, "pipeline: hipMemset failed");
   }
@@ -424,6 +440,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (p->evDet[k]) (void)hipEventDestroy(p->evDet[k]);
   if (p->evDltDone) (void)hipEventDestroy(p->evDltDone);
   if (p->det) vo_destroy(p->det);
+  if (p->redo) vo_destroy(p->redo);
   delete p;
 }
 
@@ -449,30 +466,43 @@ int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
 }
 
 // ---- launches of one step -----------------------------------------------------------------
+// slot-indexed views (slot = track set of the step)
+static inline double* sl_R(vo_pipeline* p, int s) { return p->d_R + (size_t)s * p->cfg.hyp * 9; }
+static inline double* sl_t(vo_pipeline* p, int s) { return p->d_t + (size_t)s * p->cfg.hyp * 3; }
+static inline uint8_t* sl_valid(vo_pipeline* p, int s) { return p->d_valid + (size_t)s * p->cfg.hyp; }
+static inline int32_t* sl_counts(vo_pipeline* p, int s) { return p->d_counts + (size_t)s * p->cfg.hyp; }
+static inline uint64_t* sl_masks(vo_pipeline* p, int s) {
+  return p->d_masks + (size_t)s * p->cfg.hyp * vo_cdiv(p->cfg.n_keypoints, 64);
+}
+static inline int32_t* sl_nt(vo_pipeline* p, int s) { return p->d_ntracked + 8 * s; }
+static inline double* sl_tri(vo_pipeline* p, int s) { return p->d_tri + (size_t)s * p->cfg.n_keypoints * 3; }
 
-// detection branch: Harris response + NMS of `frame` (evDet[ev]: the next step's tracker may
-// start), then the DLT of the previous step's tracks (evDltDone: its inputs may be overwritten)
-static int enqueue_detection(vo_pipeline* p, int frame, int slot, int prev_set, bool with_dlt, int ev) {
+// detection of `frame` into keypoint buffer `slot`; evDet[ev]: the next step's tracker may start
+static int enqueue_detection(vo_pipeline* p, int frame, int slot, int ev) {
   const vo_pipeline_config& c = p->cfg;
   vo_ctx* det = p->det;
   det->nms_kp_f32 = p->d_kp_f32[slot];   // the tracker's float copy of the keypoints
   int rc = vo_harris_response_dev(det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
   if (rc == VO_OK) rc = vo_nms_keypoints_dev(det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, p->d_kp[slot]);
   if (rc == VO_OK && hipEventRecord(p->evDet[ev], det->stream) != hipSuccess) rc = VO_EHIP;
-  // cameras are read from mapped host memory (set s is rewritten two steps later at the earliest),
-  // the point count from the word the gather kernel of that step left in HBM
-  if (rc == VO_OK && with_dlt)
-    rc = vo_triangulate_dlt_ndev(det, p->d_prev_c[prev_set], p->d_next_c[prev_set], p->d_ntracked + 4 + prev_set,
-                                 c.n_keypoints, p->m_C + 24 * prev_set, p->m_C + 24 * prev_set + 12, p->d_tri);
+  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(det));
+  return VO_OK;
+}
+
+// DLT of track set `s`; evDltDone: the set may be overwritten.  Cameras are read from mapped
+// host memory (set s is rewritten two steps later at the earliest), the point count from the
+// word the gather kernel of that step left in HBM.
+static int enqueue_dlt(vo_pipeline* p, int s) {
+  vo_ctx* det = p->det;
+  int rc = vo_triangulate_dlt_ndev(det, p->d_prev_c[s], p->d_next_c[s], sl_nt(p, s), p->cfg.n_keypoints, p->m_C + 24 * s,
+                                   p->m_C + 24 * s + 12, sl_tri(p, s));
   if (rc == VO_OK && hipEventRecord(p->evDltDone, det->stream) != hipSuccess) rc = VO_EHIP;
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(det));
   return VO_OK;
 }
 
-// tracking branch up to the mirror kernel (main stream)
-static void post_detection(vo_pipeline* p, int frame, int slot, int prev_set, bool with_dlt);
-
-static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, int b, int cs, int det_pos) {
+// tracking branch (main stream): KLT -> gather -> hypotheses
+static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, int b, int cs, unsigned raw_tag) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
   const int N = c.n_keypoints;
@@ -480,29 +510,30 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
   VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
                           p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
-  if (det_pos == 1) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
-  // the track set this gather fills was the input of the DLT queued behind the last detection
+  // the track set this gather fills was the input of the DLT of two steps ago
   if (hipEventQuery(p->evDltDone) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDltDone, 0));
   {
     vo_prof_scope ps(ctx, VO_K_GATHER);
     hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->d_kp[a], p->d_next_f32,
                        p->d_status, p->d_err, N, (float)c.klt_err_threshold, p->d_depth[prev_idx], c.H, c.W, fx, fy, cx,
                        cy, p->d_T_wc + (size_t)prev_idx * 16, p->d_prev_c[cs], p->d_next_c[cs], p->d_land_c[cs],
-                       p->d_ntracked, cs);
+                       sl_nt(p, cs));
   }
   VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
-  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], p->d_ntracked, N, c.K, p->m_raw + p->raw_pos, c.hyp,
-                                   c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks,
-                                   (uint32_t*)p->d_ntracked + 2));
+  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], sl_nt(p, cs), N, c.K, p->m_raw,
+                                   (const uint32_t*)(p->m_seq + 8 + 2 * cs), raw_tag, c.hyp, c.p3p_thr_sq, sl_R(p, cs),
+                                   sl_t(p, cs), sl_valid(p, cs), sl_counts(p, cs), sl_masks(p, cs),
+                                   (uint32_t*)sl_nt(p, cs) + 2));
   return VO_OK;
 }
 
-static int launch_mirror(vo_pipeline* p, bool with_count) {
+static int launch_mirror(vo_pipeline* p, int s, bool with_count, hipStream_t st) {
   const vo_pipeline_config& c = p->cfg;
-  hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, p->ctx->stream, p->d_valid, p->d_counts, p->d_R,
-                     p->d_t, c.hyp, p->m_valid, p->m_counts, p->m_R, p->m_t, p->m_seq + 1, p->m_seq + 2,
-                     (unsigned*)p->d_ntracked + 1, with_count ? (const int32_t*)p->d_ntracked : (const int32_t*)nullptr,
-                     p->m_ntracked);
+  const size_t h = (size_t)s * c.hyp;
+  hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, st, sl_valid(p, s), sl_counts(p, s),
+                     sl_R(p, s), sl_t(p, s), c.hyp, p->m_valid + h, p->m_counts + h, p->m_R + h * 9, p->m_t + h * 3,
+                     p->m_seq + 4 * s + 1, p->m_seq + 4 * s + 2, (unsigned*)sl_nt(p, s) + 1,
+                     with_count ? (const int32_t*)sl_nt(p, s) : (const int32_t*)nullptr, p->m_ntracked + 4 * s);
   return vo_check_launch(p->ctx, "mirror_hypotheses_kernel");
 }
 
@@ -520,26 +551,31 @@ static void worker_main(vo_pipeline* p) {
       continue;
     }
     idle = 0;
-    seen = posted;
-    p->job_rc = enqueue_detection(p, p->job.frame, p->job.slot, p->job.prev_set, p->job.with_dlt, p->job.ev);
+    const vo_pipeline::job_t j = p->jobs[seen & 7];
+    const int rc = j.kind == 0 ? enqueue_detection(p, j.frame, j.slot, j.ev) : enqueue_dlt(p, j.slot);
+    if (rc != VO_OK) p->job_rc = rc;
+    ++seen;
     p->job_done.store(seen, std::memory_order_release);
   }
 }
 
-// hands the detection branch of a step to the worker
-static void post_detection(vo_pipeline* p, int frame, int slot, int prev_set, bool with_dlt) {
+static void post_job(vo_pipeline* p, int kind, int frame, int slot, int ev) {
   p->det->prof_on = p->ctx->prof_on;
   p->det->prof_kernel = p->ctx->prof_kernel;
-  p->job.frame = frame;
-  p->job.slot = slot;
-  p->job.prev_set = prev_set;
-  p->job.with_dlt = with_dlt;
-  p->ev_last ^= 1;
-  p->job.ev = p->ev_last;
-  p->job_posted.store(p->job_posted.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+  const unsigned n = p->job_posted.load(std::memory_order_relaxed);
+  while (n - p->job_done.load(std::memory_order_acquire) >= 8) __builtin_ia32_pause();   // ring full (never in practice)
+  p->jobs[n & 7] = {kind, frame, slot, ev};
+  p->job_posted.store(n + 1, std::memory_order_release);
 }
 
-// waits (host) until the worker has enqueued everything it was given, evDet[] included
+// hands the detection of `frame` to the worker; returns the index of the event it will record
+static int post_detection(vo_pipeline* p, int frame, int slot) {
+  p->ev_last ^= 1;
+  post_job(p, 0, frame, slot, p->ev_last);
+  return p->ev_last;
+}
+
+// waits (host) until the worker has enqueued everything it was given, its event records included
 static int worker_idle(vo_pipeline* p) {
   const unsigned posted = p->job_posted.load(std::memory_order_relaxed);
   while (p->job_done.load(std::memory_order_acquire) != posted) __builtin_ia32_pause();
@@ -557,111 +593,137 @@ static int detect_join(vo_pipeline* p) {
   return VO_OK;
 }
 
+// the DLT of the last collected step (posted lazily: fetch / export / the next collect need it)
+static int flush_dlt(vo_pipeline* p) {
+  if (!p->dlt_unflushed) return VO_OK;
+  p->dlt_unflushed = false;
+  post_job(p, 1, 0, p->cset_collected, 0);
+  return VO_OK;
+}
+
 int vo_pipeline_prime(vo_pipeline* p, int idx) {
   if (!p) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
   VO_REQUIRE(ctx, idx >= 0 && idx < p->cfg.n_frames, "pipeline_prime: bad frame index");
   VO_REQUIRE(ctx, p->seeded, "pipeline_prime: call vo_pipeline_seed first");
+  VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_prime: %d submitted step(s) not collected", p->n_flight);
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   p->cur = 0;
-  p->dlt_pending = false;
+  p->dlt_unflushed = false;
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[idx], p->cfg.H, p->cfg.W, p->n_levels, p->d_pyr[0]));
   VO_TRY(worker_idle(p));
-  post_detection(p, idx, 0, 0, false);
+  post_detection(p, idx, 0);
   VO_TRY(detect_join(p));
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   p->prev_frame = idx;
   return VO_OK;
 }
 
-// The DLT of the last step normally runs at the start of the next one (it is not on the path to
-// the next pose); fetch / export, which read its result, run it now.
-static int flush_dlt(vo_pipeline* p) {
-  if (!p->dlt_pending) return VO_OK;
-  vo_ctx* ctx = p->ctx;
-  p->dlt_pending = false;
-  VO_TRY(worker_idle(p));
-  p->det->prof_on = ctx->prof_on;
-  p->det->prof_kernel = ctx->prof_kernel;
-  const int s = p->cset;
-  const int rc = vo_triangulate_dlt_ndev(p->det, p->d_prev_c[s], p->d_next_c[s], p->d_ntracked + 4 + s,
-                                         p->cfg.n_keypoints, p->m_C + 24 * s, p->m_C + 24 * s + 12, p->d_tri);
-  if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->det));
-  VO_HIP_TRY(ctx, hipEventRecord(p->evDltDone, p->det->stream));
-  VO_HIP_TRY(ctx, hipEventRecord(p->evDet[p->ev_last], p->det->stream));
-  return VO_OK;
-}
-
-int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out) {
-  if (!p || !out) return VO_EINVAL;
-  vo_ctx* ctx = p->ctx;
-  const vo_pipeline_config& c = p->cfg;
-  VO_REQUIRE(ctx, next_idx >= 0 && next_idx < c.n_frames, "pipeline_step: bad frame index");
-  VO_REQUIRE(ctx, prev_idx == p->prev_frame, "pipeline_step: prev frame %d is not the frame last processed (%d)",
-             prev_idx, p->prev_frame);
-  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int N = c.n_keypoints, a = p->cur, b = 1 - p->cur;
-  const int cs = 1 - p->cset;                       // track set this step fills
-  const bool seq_sampler = getenv("VO_SEQ_SAMPLER") != nullptr;   // test hook: always take the sequential path
-  memset(out, 0, sizeof(*out));
-  out->best_index = -1;
-  static const bool dbg = getenv("VO_DEBUG_TIMING") != nullptr;
-  auto now = []() {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
-  };
-  double t_entry = 0, t_enq = 0, t_res = 0;
-  if (dbg) {
-    t_entry = now();
-    if (p->dbg_last_return > 0) p->dbg_t[3] += t_entry - p->dbg_last_return;
+// makes h_raw[raw_pos .. raw_pos + need) valid and tells slot s's solve kernel where it starts
+static void publish_raws(vo_pipeline* p, int s, unsigned tag) {
+  const size_t need = (size_t)7 * p->cfg.hyp;
+  if (!p->raw_valid || p->raw_pos + 2 * need > p->raw_cap) {
+    // (re)start the look-ahead at the generator's present position.  Kernels of earlier steps are
+    // past their reads (their results have been collected), so the buffer may be rewritten.
+    p->raw_gen = p->rng;
+    p->raw_pos = p->raw_fill = 0;
+    p->raw_valid = true;
   }
-
-  // Generator outputs for the device-side sampler (a look-ahead; the real generator advances
-  // by what the sequential rule consumes, below).  Normally they are already there.
-  const size_t need = (size_t)7 * c.hyp;
-  if (!p->raw_valid || p->raw_fill < p->raw_pos + need) {
-    if (!p->raw_valid) {
-      p->raw_gen = p->rng;
-      p->raw_pos = p->raw_fill = 0;
-      p->raw_valid = true;
-    }
+  if (p->raw_fill < p->raw_pos + need) {
     vo_rng_raw32(&p->raw_gen, (int)(p->raw_pos + need - p->raw_fill), p->h_raw + p->raw_fill);
     p->raw_fill = p->raw_pos + need;
   }
-  const unsigned seq_b0 = ++p->seq;
-  p->h_seq[2] = seq_b0;                               // the mirror kernel publishes this value when it is done
+  p->h_seq[9 + 2 * s] = (unsigned)p->raw_pos;
+  std::atomic_thread_fence(std::memory_order_release);
+  p->h_seq[8 + 2 * s] = tag;
+}
+
+int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  const vo_pipeline_config& c = p->cfg;
+  VO_REQUIRE(ctx, next_idx >= 0 && next_idx < c.n_frames, "pipeline_submit: bad frame index");
+  VO_REQUIRE(ctx, prev_idx == p->prev_frame, "pipeline_submit: prev frame %d is not the frame last submitted (%d)",
+             prev_idx, p->prev_frame);
+  VO_REQUIRE(ctx, p->n_flight < 2, "pipeline_submit: two steps are already in flight, collect one first");
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int a = p->cur, b = 1 - p->cur;
+  const int cs = 1 - p->cset;                          // slot (track set) this step fills
+  static const bool dbg = getenv("VO_DEBUG_TIMING") != nullptr;
+  double t_entry = 0;
+  if (dbg) {
+    t_entry = now_us();
+    if (p->dbg_last_return > 0) p->dbg_t[3] += t_entry - p->dbg_last_return;
+  }
+  const unsigned seq = ++p->seq;
+  p->h_seq[4 * cs + 2] = seq;                          // the mirror kernel publishes this value when it is done
+  // where the step's generator outputs start is known once every earlier step has been
+  // collected; otherwise the collect of the step before publishes it (the solve kernel waits)
+  const bool publish_now = p->n_flight == 0;
+  if (publish_now) publish_raws(p, cs, seq);
 
   // ---- all launches of the step: detection from the worker thread, tracking from this one ----
+  VO_TRY(flush_dlt(p));                                // reads the track set this step's gather will overwrite
   VO_TRY(worker_idle(p));
   const int ev_prev = p->ev_last;                      // recorded behind the last step's detection
-  static const int det_pos = getenv("VO_DET_POS") ? atoi(getenv("VO_DET_POS")) : 0;
-  if (det_pos == 0) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
+  post_detection(p, next_idx, b);
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
   // keypoints of `prev`: usually long finished, and then no barrier goes into the queue
   if (hipEventQuery(p->evDet[ev_prev]) != hipSuccess)
     VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[ev_prev], 0));
-  VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, det_pos));
-  VO_TRY(launch_mirror(p, true));
-  if (det_pos == 2) post_detection(p, next_idx, b, 1 - cs, p->dlt_pending);
-  p->dlt_pending = false;
-  unsigned seq_b = seq_b0;
+  VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, seq));
+  VO_TRY(launch_mirror(p, cs, true, ctx->stream));
 
-  if (dbg) t_enq = now();
-  // while the GPU works: extend the look-ahead so the next step finds its outputs ready
-  if (p->raw_fill < p->raw_pos + 2 * need && p->raw_pos + 2 * need <= p->raw_cap) {
+  vo_pipeline::flight_t& f = p->flight[p->n_flight++];
+  f.prev_idx = prev_idx;
+  f.next_idx = next_idx;
+  f.slot = cs;
+  f.seq = seq;
+  f.raw_published = publish_now;
+  p->cset = cs;
+  p->cur = b;
+  p->prev_frame = next_idx;
+  if (dbg) p->dbg_t[0] += now_us() - t_entry;
+  return VO_OK;
+}
+
+int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
+  if (!p || !out) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  const vo_pipeline_config& c = p->cfg;
+  VO_REQUIRE(ctx, p->n_flight > 0, "pipeline_collect: nothing submitted");
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const vo_pipeline::flight_t f = p->flight[0];
+  const int N = c.n_keypoints, cs = f.slot;
+  const size_t need = (size_t)7 * c.hyp;
+  const bool seq_sampler = getenv("VO_SEQ_SAMPLER") != nullptr;   // test hook: always take the sequential path
+  static const bool dbg = getenv("VO_DEBUG_TIMING") != nullptr;
+  memset(out, 0, sizeof(*out));
+  out->best_index = -1;
+  VO_TRY(flush_dlt(p));                                // (of the step collected before this one)
+  const double t_wait = dbg ? now_us() : 0;
+
+  // while the GPU works: extend the look-ahead so the next steps find their outputs ready
+  if (p->raw_valid && f.raw_published && p->raw_fill < p->raw_pos + 2 * need && p->raw_pos + 2 * need <= p->raw_cap) {
     vo_rng_raw32(&p->raw_gen, (int)(p->raw_pos + 2 * need - p->raw_fill), p->h_raw + p->raw_fill);
     p->raw_fill = p->raw_pos + 2 * need;
   }
-  VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
-  if (dbg) t_res = now();
-  const int n = ((volatile int32_t*)p->h_ntracked)[0];
-  const bool redo = ((volatile int32_t*)p->h_ntracked)[2] != 0 || seq_sampler;
+  unsigned seq_b = f.seq;
+  VO_TRY(spin_until(ctx, p->h_seq + 4 * cs + 1, seq_b));
+  const double t_res = dbg ? now_us() : 0;
+  const int32_t* h_nt = p->h_ntracked + 4 * cs;
+  const int n = ((volatile const int32_t*)h_nt)[0];
+  const bool redo = ((volatile const int32_t*)h_nt)[2] != 0 || seq_sampler;
+  const uint8_t* h_valid = p->h_valid + (size_t)cs * c.hyp;
+  const int32_t* h_counts = p->h_counts + (size_t)cs * c.hyp;
+  const double* h_R = p->h_R + (size_t)cs * c.hyp * 9;
+  const double* h_t = p->h_t + (size_t)cs * c.hyp * 3;
   out->n_tracked = n;
   p->last_ntracked = n;
   p->last_best = -1;
   p->last_words = vo_cdiv(N, 64);
-  p->cset = cs;
+  p->cset_collected = cs;
+  bool raw_ok = true;                                  // the look-ahead is still aligned with the generator
 
   if (n >= 4) {
     // ---- sequential RANSAC rule replayed on the host over the bulk (valid, count) ----
@@ -681,25 +743,32 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
         }
         VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, p->h_samples));
         seq_b = ++p->seq;
-        p->h_seq[2] = seq_b;
-        VO_TRY(vo_p3p_hypotheses_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], n, c.K, p->m_samples, c.hyp, c.p3p_thr_sq,
-                                     p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks));
-        VO_TRY(launch_mirror(p, false));
-        VO_TRY(spin_until(ctx, p->h_seq + 1, seq_b));
+        p->h_seq[4 * cs + 2] = seq_b;
+        // On its own stream: the inputs are complete (this step's results were seen), every buffer
+        // belongs to this step's slot, and the main stream may already hold the next step, whose
+        // solve kernel waits for what this collect publishes.
+        {
+          const int rc = vo_p3p_hypotheses_dev(p->redo, p->d_land_c[cs], p->d_next_c[cs], n, c.K, p->m_samples, c.hyp,
+                                               c.p3p_thr_sq, sl_R(p, cs), sl_t(p, cs), sl_valid(p, cs), sl_counts(p, cs),
+                                               sl_masks(p, cs));
+          if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->redo));
+        }
+        VO_TRY(launch_mirror(p, cs, false, p->redo->stream));
+        VO_TRY(spin_until(ctx, p->h_seq + 4 * cs + 1, seq_b));
         words = vo_cdiv(n, 64);
       }
       have_batch = false;
       int consumed = 0;
       const int32_t before = best_idx;
-      VO_TRY(vo_ransac_replay(&p->rs, p->h_valid, p->h_counts, c.hyp, n, &n_done, &best_count, &best_idx,
-                              batches * c.hyp, &consumed, &finished));
-      for (int i = 0; i < c.hyp; ++i) hyp_valid += p->h_valid[i] ? 1 : 0;
+      VO_TRY(vo_ransac_replay(&p->rs, h_valid, h_counts, c.hyp, n, &n_done, &best_count, &best_idx, batches * c.hyp,
+                              &consumed, &finished));
+      for (int i = 0; i < c.hyp; ++i) hyp_valid += h_valid[i] ? 1 : 0;
       total_consumed += consumed;
       if (best_idx != before) {
         // the winner so far lives in this batch: take its pose before the buffers are reused
         const int local = best_idx - batches * c.hyp;
-        memcpy(out->R, p->h_R + (size_t)local * 9, 72);
-        memcpy(out->t, p->h_t + (size_t)local * 3, 24);
+        memcpy(out->R, h_R + (size_t)local * 9, 72);
+        memcpy(out->t, h_t + (size_t)local * 3, 24);
         p->last_best = local;
         p->last_words = words;
       } else if (batches > 0) {
@@ -715,13 +784,8 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     }
     // the look-ahead moves with the generator: 7 outputs per consumed sample when every draw
     // was accepted at once (no flag) and only the device-side batch was used
-    if (!redo && batches == 1) p->raw_pos += (size_t)7 * total_consumed;
-    else p->raw_valid = false;
-    if (p->raw_valid && p->raw_pos > p->raw_cap / 2) {   // make room (the solve kernel has finished reading)
-      memmove(p->h_raw, p->h_raw + p->raw_pos, (p->raw_fill - p->raw_pos) * sizeof(uint32_t));
-      p->raw_fill -= p->raw_pos;
-      p->raw_pos = 0;
-    }
+    if (!redo && batches == 1 && f.raw_published) p->raw_pos += (size_t)7 * total_consumed;
+    else raw_ok = false;
     out->n_inliers = best_count > 0 ? best_count : 0;
     out->best_index = best_idx;
     out->ransac_iterations = n_done;
@@ -732,7 +796,7 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
     if (best_idx >= 0) {
       double Tcw[16], Rt[12];
       double* hC = p->h_C + 24 * cs;
-      rigid_inverse(&p->T_wc[(size_t)prev_idx * 16], Tcw);
+      rigid_inverse(&p->T_wc[(size_t)f.prev_idx * 16], Tcw);
       k_times_rt(c.K, Tcw, hC);
       for (int r = 0; r < 3; ++r) {
         Rt[4 * r] = out->R[3 * r];
@@ -741,15 +805,21 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
         Rt[4 * r + 3] = out->t[r];
       }
       k_times_rt(c.K, Rt, hC + 12);
-      p->dlt_pending = true;
+      p->dlt_unflushed = true;
     }
   }
-  p->cur = b;
-  p->prev_frame = next_idx;
+  if (!raw_ok) p->raw_valid = false;
+
+  // this step is done; the one submitted after it learns where its generator outputs start
+  p->flight[0] = p->flight[1];
+  --p->n_flight;
+  if (p->n_flight > 0 && !p->flight[0].raw_published) {
+    publish_raws(p, p->flight[0].slot, p->flight[0].seq);
+    p->flight[0].raw_published = true;
+  }
   if (dbg) {
-    const double t_ret = now();
-    p->dbg_t[0] += t_enq - t_entry;
-    p->dbg_t[1] += t_res - t_enq;
+    const double t_ret = now_us();
+    p->dbg_t[1] += t_res - t_wait;
     p->dbg_t[2] += t_ret - t_res;
     p->dbg_last_return = t_ret;
     ++p->dbg_steps;
@@ -757,12 +827,21 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   return VO_OK;
 }
 
+int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out) {
+  if (!p || !out) return VO_EINVAL;
+  VO_REQUIRE(p->ctx, p->n_flight == 0, "pipeline_step: %d submitted step(s) not collected", p->n_flight);
+  VO_TRY(vo_pipeline_submit(p, prev_idx, next_idx));
+  return vo_pipeline_collect(p, out);
+}
+
 int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record) {
   if (!p || !r || !d_record) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
   VO_REQUIRE(ctx, cap >= 0, "pipeline_export_state: bad capacity");
+  // the triangulated landmarks of the last collected step: its DLT runs on the detection stream
   VO_TRY(flush_dlt(p));
-  VO_TRY(detect_join(p));
+  VO_TRY(worker_idle(p));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDltDone, 0));
   pose17 h;
   for (int row = 0; row < 3; ++row) {
     for (int c = 0; c < 3; ++c) h.v[4 * row + c] = r->R[3 * row + c];
@@ -773,8 +852,8 @@ int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int ca
   const int n = r->best_index >= 0 ? (r->n_tracked < cap ? r->n_tracked : cap) : 0;
   h.v[16] = (double)n;
   const int threads = n * 3 > 17 ? n * 3 : 17;
-  hipLaunchKernelGGL(export_state_kernel, dim3(vo_cdiv(threads, 256)), dim3(256), 0, ctx->stream, h, p->d_tri, n, cap,
-                     d_record);
+  hipLaunchKernelGGL(export_state_kernel, dim3(vo_cdiv(threads, 256)), dim3(256), 0, ctx->stream, h,
+                     sl_tri(p, p->cset_collected), n, cap, d_record);
   return vo_check_launch(ctx, "export_state_kernel");
 }
 
@@ -804,21 +883,23 @@ int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* 
   if (!p) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
   hipStream_t st = ctx->stream;
+  VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_fetch: %d submitted step(s) not collected", p->n_flight);
   const int n = p->last_ntracked, N = p->cfg.n_keypoints;
-  const int cs = p->cset;
+  const int cs = p->cset_collected;
   VO_TRY(flush_dlt(p));
   VO_TRY(detect_join(p));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(st, p->evDltDone, 0));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   if (kp_next) VO_HIP_TRY(ctx, hipMemcpy(kp_next, p->d_kp[p->cur], (size_t)N * 16, hipMemcpyDeviceToHost));
   if (n > 0) {
     if (prev_xy) VO_HIP_TRY(ctx, hipMemcpy(prev_xy, p->d_prev_c[cs], (size_t)n * 16, hipMemcpyDeviceToHost));
     if (next_xy) VO_HIP_TRY(ctx, hipMemcpy(next_xy, p->d_next_c[cs], (size_t)n * 16, hipMemcpyDeviceToHost));
     if (landmarks) VO_HIP_TRY(ctx, hipMemcpy(landmarks, p->d_land_c[cs], (size_t)n * 24, hipMemcpyDeviceToHost));
-    if (triangulated) VO_HIP_TRY(ctx, hipMemcpy(triangulated, p->d_tri, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (triangulated) VO_HIP_TRY(ctx, hipMemcpy(triangulated, sl_tri(p, cs), (size_t)n * 24, hipMemcpyDeviceToHost));
     if (inliers) {
       VO_REQUIRE(ctx, p->last_best >= 0, "pipeline_fetch: no inlier mask for the last step");
       std::vector<uint64_t> row(p->last_words);
-      VO_HIP_TRY(ctx, hipMemcpy(row.data(), p->d_masks + (size_t)p->last_best * p->last_words,
+      VO_HIP_TRY(ctx, hipMemcpy(row.data(), sl_masks(p, cs) + (size_t)p->last_best * p->last_words,
                                 (size_t)p->last_words * 8, hipMemcpyDeviceToHost));
       for (int i = 0; i < n; ++i) inliers[i] = (uint8_t)((row[i >> 6] >> (i & 63)) & 1ull);
     }

@@ -100,9 +100,12 @@ static inline int vo_cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---- internal entry points shared between translation units (not part of the C ABI) ----
 // P3P hypotheses whose sample indices are derived on the device from raw generator outputs
 // and a device-resident population size (p3p.hip).
+// d_rawctl (optional, mapped host memory): {tag, offset}; the kernel waits (bounded) until the tag
+// equals raw_tag and reads its outputs from d_raws + offset.
 int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
-                              const double* K, const uint32_t* d_raws, int Hyp, double thr_sq, double* d_R,
-                              double* d_t, uint8_t* d_valid, int32_t* d_counts, uint64_t* d_masks, uint32_t* d_flag);
+                              const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
+                              int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
+                              uint64_t* d_masks, uint32_t* d_flag);
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
 void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
 // DLT with a device-resident point count (dlt.hip)

@@ -123,6 +123,8 @@ _SIGS = {
     "vo_pipeline_seed": (_i, [_vp, _vp]),
     "vo_pipeline_prime": (_i, [_vp, _i]),
     "vo_pipeline_step": (_i, [_vp, _i, _i, _vp]),
+    "vo_pipeline_submit": (_i, [_vp, _i, _i]),
+    "vo_pipeline_collect": (_i, [_vp, _vp]),
     "vo_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vo_pipeline_export_state_dev": (_i, [_vp, _vp, _i, _vp]),
     "vo_pipeline_prof_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_int64)]),
@@ -484,6 +486,16 @@ class Pipeline:
     def step(self, prev_idx, next_idx):
         r = StepResult()
         self.ctx._chk(self.ctx._lib.vo_pipeline_step(self._h, int(prev_idx), int(next_idx), C.byref(r)))
+        return r
+
+    def submit(self, prev_idx, next_idx):
+        """First half of step(): enqueue the frame's GPU work and return (at most two in flight)."""
+        self.ctx._chk(self.ctx._lib.vo_pipeline_submit(self._h, int(prev_idx), int(next_idx)))
+
+    def collect(self):
+        """Second half of step(): wait for the oldest submitted frame, replay the RANSAC rule."""
+        r = StepResult()
+        self.ctx._chk(self.ctx._lib.vo_pipeline_collect(self._h, C.byref(r)))
         return r
 
     def prof_read(self, kernel_id):
