@@ -610,7 +610,8 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
 // for a bounded number of iterations, what is left goes to the second launch, and what that
 // leaves (FINAL) joins the list as undecided entries for the sorted walk.
 constexpr int ROUND_ITERS = 64;
-static_assert(CX * (CY / 8) == NT, "the row pass of the round kernel maps one strip to one thread");
+constexpr int RT = 512;           // threads of a round workgroup
+static_assert((CX * CY) % RT == 0 && RT % CY == 0, "the row pass of the round kernel maps one strip to one thread");
 
 __device__ __forceinline__ unsigned load_state(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -620,7 +621,7 @@ __device__ __forceinline__ void store_state(unsigned* p, unsigned v) {
 }
 
 template <int R_T, bool FINAL>
-__global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict__ sc, unsigned* alive,
+__global__ __launch_bounds__(RT) void nms_round_kernel(const double* __restrict__ sc, unsigned* alive,
                                                        uint4* __restrict__ seg_cnt,
                                                        const unsigned* __restrict__ seg_cand,
                                                        unsigned long long* __restrict__ keys_c,
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   if (n == 0 || seg_cnt[blk].w == 0) return;
   const int x0 = (int)(blk % (unsigned)tiles_x) * CX, y0 = (int)(blk / (unsigned)tiles_x) * CY;
   const size_t seg0 = (size_t)blk * SEG;
-  for (unsigned i = tid; i < n; i += NT) {
+  for (unsigned i = tid; i < n; i += RT) {
     const unsigned idx = seg_cand[seg0 + i];
     const int py = (int)(idx / (unsigned)W), px = (int)(idx - (unsigned)py * (unsigned)W);
     s_cell[i] = (unsigned short)((py - y0 + r) * SP + (px - x0 + r));
@@ -662,11 +663,11 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     // ---- fresh copy of the tile's part of the state map ----
     if (!reload) {
     } else if (R_T > 0) {
-      constexpr int PER = ((CX + 2 * R_T) * (CY + 2 * R_T) + NT - 1) / NT;
+      constexpr int PER = ((CX + 2 * R_T) * (CY + 2 * R_T) + RT - 1) / RT;
       unsigned v[PER];
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
-        const int i = tid + k * NT;
+        const int i = tid + k * RT;
         const int ly = i / LW, lx = i - ly * LW;
         const int gy = y0 - r + ly, gx = x0 - r + lx;
         const bool in = i < LW * LH && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -674,12 +675,12 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
       }
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
-        const int i = tid + k * NT;
+        const int i = tid + k * RT;
         const int ly = i / LW, lx = i - ly * LW;
         if (i < LW * LH) s_state[ly * SP + lx] = v[k];
       }
     } else {
-      for (int i = tid; i < LW * LH; i += NT) {
+      for (int i = tid; i < LW * LH; i += RT) {
         const int ly = i / LW, lx = i - ly * LW;
         const int gy = y0 - r + ly, gx = x0 - r + lx;
         unsigned v = 0u;
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     }
     __syncthreads();
     // ---- window maximum of the state words: columns (lanes along x), then rows (lanes along y) ----
-    for (int it = tid; it < LW * (CY / 8); it += NT) {
+    for (int it = tid; it < LW * (CY / 8); it += RT) {
       const int st = it / LW, x = it - st * LW;
       const int ys = st * 8;
       const unsigned* col = s_state + ys * SP + x;
@@ -714,17 +715,18 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     }
     __syncthreads();
     {
-      // one strip of eight window maxima per thread (CY * CX / 8 == NT), lanes along y; they are
+      // one strip of RS window maxima per thread (CY * CX / RS == RT), lanes along y; they are
       // written over the column maxima, so every thread reads before any thread writes
-      const int y = tid & (CY - 1), xs = (tid / CY) * 8;
+      constexpr int RS = CX * CY / RT;
+      const int y = tid & (CY - 1), xs = (tid / CY) * RS;
       const unsigned* row = s_v + y * SP + xs;
-      unsigned out[8];
+      unsigned out[RS];
       if (R_T > 0) {
-        unsigned v[8 + 2 * R_T];
+        unsigned v[RS + 2 * R_T];
 #pragma unroll
-        for (int k = 0; k < 8 + 2 * R_T; ++k) v[k] = row[k];
+        for (int k = 0; k < RS + 2 * R_T; ++k) v[k] = row[k];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        for (int o = 0; o < RS; ++o) {
           unsigned m = v[o];
 #pragma unroll
           for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
         }
       } else {
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
+        for (int o = 0; o < RS; ++o) {
           unsigned m = row[o];
           for (int d = 1; d < WN; ++d) m = max(m, row[o + d]);
           out[o] = m;
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
       }
       __syncthreads();
 #pragma unroll
-      for (int o = 0; o < 8; ++o) s_m[y * PM + xs + o] = out[o];
+      for (int o = 0; o < RS; ++o) s_m[y * PM + xs + o] = out[o];
     }
     __syncthreads();
     // ---- candidates whose word tops their window ----
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     }
     __syncthreads();
     unsigned live = 0;
-    for (unsigned i = tid; i < n; i += NT) {
+    for (unsigned i = tid; i < n; i += RT) {
       const int cell = s_cell[i];
       const unsigned cp = s_state[cell];
       if (cp < 3u) continue;                                   // selected or dead
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
     // two tied neighbours exactly one proceeds).  The winner is selected and kills the live
     // words of its window, in LDS and in the global map.
     const int lane = tid & 63;
-    for (unsigned k = tid >> 6; k < npass; k += NT / 64) {
+    for (unsigned k = tid >> 6; k < npass; k += RT / 64) {
       const int cell = s_pass[k];
       unsigned* c = s_state + cell;
       const unsigned cp = *c;
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   {
     if (tid == 0) s_npass = 0;
     __syncthreads();
-    for (unsigned b0 = 0; b0 < n; b0 += NT) {
+    for (unsigned b0 = 0; b0 < n; b0 += RT) {
       const unsigned i = b0 + tid;
       const bool live = i < n && s_state[s_cell[i]] >= 3u;
       const unsigned slot = wave_slot(live, &s_npass);
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const double* __restrict_
   }
   __syncthreads();
   const unsigned base = s_npass;
-  for (unsigned k = tid; k < nsel + nrem; k += NT) {
+  for (unsigned k = tid; k < nsel + nrem; k += RT) {
     const bool und = k >= nsel;
     const int cell = und ? s_pass[k - nsel] : s_sel[k];
     const int ly = cell / SP, lx = cell - ly * SP;
@@ -1328,7 +1330,7 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   const size_t round_lds = (size_t)((CX + 2 * r) | 1) * ((CY + 2 * r) + CY) * 4;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_ROUND);
-    const dim3 g(nblk), b(NT);
+    const dim3 g(nblk), b(RT);
     if (r == 5)
       hipLaunchKernelGGL((nms_round_kernel<5, true>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
                          idx_c, ctl, cap_c, H, W, r, (int)grid.x);

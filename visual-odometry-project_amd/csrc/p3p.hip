@@ -185,15 +185,16 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
     if (threadIdx.x == 0) {
       int spins = 0;
       bool ok = true;
-      while (__hip_atomic_load(rawctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != raw_tag) {
+      const unsigned long long* ctl = reinterpret_cast<const unsigned long long*>(rawctl);   // tag | offset << 32
+      unsigned long long w;
+      while ((unsigned)(w = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != raw_tag) {
         if (++spins > 4000) {
           ok = false;
           break;
         }
         __builtin_amdgcn_s_sleep(64);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-      s_pos = ok ? __hip_atomic_load(rawctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+      s_pos = ok ? (unsigned)(w >> 32) : 0u;
       if (!ok) atomicOr(flag, 1u);
     }
     __syncthreads();

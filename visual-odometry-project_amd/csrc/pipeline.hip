@@ -31,7 +31,7 @@ struct vo_pipeline {
   hipEvent_t evDet[2] = {nullptr, nullptr};   // keypoints ready; steps alternate, so the wait for the last step's
                                               // event cannot catch this step's record
   int ev_last = 0;                            // index of the event the latest detection records
-  hipEvent_t evDltDone = nullptr;             // the DLT queued behind a detection has read its inputs
+  hipEvent_t evDlt[2] = {nullptr, nullptr};   // the DLT of track set s has run (its inputs may be overwritten, its output read)
   // detection worker: a mailbox the main thread posts (frame, buffers) to; it enqueues the branch
   // on det->stream and records evDet[ev]
   std::thread worker;
@@ -388,7 +388,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
                       hipEventCreateWithFlags(&p->evB, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evDet[0], hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evDet[1], hipEventDisableTiming) != hipSuccess ||
-                      hipEventCreateWithFlags(&p->evDltDone, hipEventDisableTiming) != hipSuccess))
+                      hipEventCreateWithFlags(&p->evDlt[0], hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evDlt[1], hipEventDisableTiming) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   if (rc != VO_OK) {
     vo_pipeline_destroy(p);
@@ -438,7 +439,8 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   if (p->evB) (void)hipEventDestroy(p->evB);
   for (int k = 0; k < 2; ++k)
     if (p->evDet[k]) (void)hipEventDestroy(p->evDet[k]);
-  if (p->evDltDone) (void)hipEventDestroy(p->evDltDone);
+  for (int k = 0; k < 2; ++k)
+    if (p->evDlt[k]) (void)hipEventDestroy(p->evDlt[k]);
   if (p->det) vo_destroy(p->det);
   if (p->redo) vo_destroy(p->redo);
   delete p;
@@ -489,14 +491,14 @@ static int enqueue_detection(vo_pipeline* p, int frame, int slot, int ev) {
   return VO_OK;
 }
 
-// DLT of track set `s`; evDltDone: the set may be overwritten.  Cameras are read from mapped
+// DLT of track set `s`; evDlt[s]: the set may be overwritten.  Cameras are read from mapped
 // host memory (set s is rewritten two steps later at the earliest), the point count from the
 // word the gather kernel of that step left in HBM.
 static int enqueue_dlt(vo_pipeline* p, int s) {
   vo_ctx* det = p->det;
   int rc = vo_triangulate_dlt_ndev(det, p->d_prev_c[s], p->d_next_c[s], sl_nt(p, s), p->cfg.n_keypoints, p->m_C + 24 * s,
                                    p->m_C + 24 * s + 12, sl_tri(p, s));
-  if (rc == VO_OK && hipEventRecord(p->evDltDone, det->stream) != hipSuccess) rc = VO_EHIP;
+  if (rc == VO_OK && hipEventRecord(p->evDlt[s], det->stream) != hipSuccess) rc = VO_EHIP;
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(det));
   return VO_OK;
 }
@@ -511,7 +513,7 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
                           p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
   // the track set this gather fills was the input of the DLT of two steps ago
-  if (hipEventQuery(p->evDltDone) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDltDone, 0));
+  if (hipEventQuery(p->evDlt[cs]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDlt[cs], 0));
   {
     vo_prof_scope ps(ctx, VO_K_GATHER);
     hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->d_kp[a], p->d_next_f32,
@@ -633,9 +635,9 @@ static void publish_raws(vo_pipeline* p, int s, unsigned tag) {
     vo_rng_raw32(&p->raw_gen, (int)(p->raw_pos + need - p->raw_fill), p->h_raw + p->raw_fill);
     p->raw_fill = p->raw_pos + need;
   }
-  p->h_seq[9 + 2 * s] = (unsigned)p->raw_pos;
-  std::atomic_thread_fence(std::memory_order_release);
-  p->h_seq[8 + 2 * s] = tag;
+  // {tag, offset} as one 8-byte word: the kernel reads it with a single load
+  __atomic_store_n(reinterpret_cast<volatile unsigned long long*>(p->h_seq + 8 + 2 * s),
+                   (unsigned long long)tag | ((unsigned long long)p->raw_pos << 32), __ATOMIC_RELEASE);
 }
 
 int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
@@ -663,10 +665,10 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   if (publish_now) publish_raws(p, cs, seq);
 
   // ---- all launches of the step: detection from the worker thread, tracking from this one ----
-  VO_TRY(flush_dlt(p));                                // reads the track set this step's gather will overwrite
-  VO_TRY(worker_idle(p));
+  VO_TRY(worker_idle(p));                              // (everything posted earlier has recorded its events)
   const int ev_prev = p->ev_last;                      // recorded behind the last step's detection
   post_detection(p, next_idx, b);
+  VO_TRY(flush_dlt(p));                                // the last collected step's DLT, behind this detection
   VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
   // keypoints of `prev`: usually long finished, and then no barrier goes into the queue
   if (hipEventQuery(p->evDet[ev_prev]) != hipSuccess)
@@ -841,7 +843,7 @@ int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int ca
   // the triangulated landmarks of the last collected step: its DLT runs on the detection stream
   VO_TRY(flush_dlt(p));
   VO_TRY(worker_idle(p));
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDltDone, 0));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDlt[p->cset_collected], 0));
   pose17 h;
   for (int row = 0; row < 3; ++row) {
     for (int c = 0; c < 3; ++c) h.v[4 * row + c] = r->R[3 * row + c];
@@ -888,7 +890,7 @@ int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* 
   const int cs = p->cset_collected;
   VO_TRY(flush_dlt(p));
   VO_TRY(detect_join(p));
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(st, p->evDltDone, 0));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(st, p->evDlt[cs], 0));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   if (kp_next) VO_HIP_TRY(ctx, hipMemcpy(kp_next, p->d_kp[p->cur], (size_t)N * 16, hipMemcpyDeviceToHost));
   if (n > 0) {
