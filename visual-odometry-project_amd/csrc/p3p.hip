@@ -172,7 +172,10 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
                                                        const int* __restrict__ d_n, unsigned* __restrict__ flag,
                                                        int Hyp, double fx,
                                                        double fy, double cx, double cy, double* __restrict__ Rout,
-                                                       double* __restrict__ tout, uint8_t* __restrict__ valid) {
+                                                       double* __restrict__ tout, uint8_t* __restrict__ valid,
+                                                       double* __restrict__ Rhost, double* __restrict__ thost) {
+  // Rhost / thost (optional, mapped host memory): the poses are also written there, so the host
+  // finds the winner's without a copy kernel moving all of them.
   // four lanes (a DPP quad) per hypothesis: the set-up and the quartic are computed by all four,
   // then lane `sub` takes root `sub` through the triad alignment and the fourth-point test
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,6 +362,10 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
       for (int k = 0; k < 9; ++k) Rout[9 * h + k] = bestR[k];
       for (int k = 0; k < 3; ++k) tout[3 * h + k] = bestt[k];
       valid[h] = 1;
+      if (Rhost) {
+        for (int k = 0; k < 9; ++k) Rhost[9 * h + k] = bestR[k];
+        for (int k = 0; k < 3; ++k) thost[3 * h + k] = bestt[k];
+      }
     }
   }
 }
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256) void reproj_kernel(const double* __restrict__ 
 int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
                               const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
                               int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
-                              uint64_t* d_masks, uint32_t* d_flag) {
+                              uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, d_X && d_x && d_n && K && d_raws && d_R && d_t && d_valid && d_counts && d_flag,
              "p3p_hypotheses_raw: null pointer");
@@ -442,7 +449,7 @@ int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x,
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<true>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
                        (const int*)nullptr, d_raws, d_rawctl, raw_tag, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t,
-                       d_valid);
+                       d_valid, m_R, m_t);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   {
@@ -468,7 +475,7 @@ int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<false>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
                        d_samples, (const unsigned*)nullptr, (const unsigned*)nullptr, 0u, (const int*)nullptr,
-                       (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid);
+                       (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid, (double*)nullptr, (double*)nullptr);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   const int words = vo_cdiv(N, 64);

@@ -218,8 +218,10 @@ __global__ __launch_bounds__(256) void mirror_hypotheses_kernel(const uint8_t* _
     h_valid[k] = valid[k];
     h_counts[k] = counts[k];
   }
-  for (int k = i; k < hyp * 9; k += stride) h_R[k] = R[k];
-  for (int k = i; k < hyp * 3; k += stride) h_t[k] = t[k];
+  if (h_R) {   // (the device-side-sampler path has the solve kernel write the poses to the host itself)
+    for (int k = i; k < hyp * 9; k += stride) h_R[k] = R[k];
+    for (int k = i; k < hyp * 3; k += stride) h_t[k] = t[k];
+  }
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -504,7 +506,8 @@ static int enqueue_dlt(vo_pipeline* p, int s) {
 }
 
 // tracking branch (main stream): KLT -> gather -> hypotheses
-static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, int b, int cs, unsigned raw_tag) {
+static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, int b, int cs, unsigned raw_tag,
+                            bool raw_known) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
   const int N = c.n_keypoints;
@@ -522,18 +525,25 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
                        sl_nt(p, cs));
   }
   VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
-  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], sl_nt(p, cs), N, c.K, p->m_raw,
-                                   (const uint32_t*)(p->m_seq + 8 + 2 * cs), raw_tag, c.hyp, c.p3p_thr_sq, sl_R(p, cs),
+  // where the generator outputs start: known now (passed by value), or published later by the
+  // collect of the step before (the kernel polls the mapped word)
+  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], sl_nt(p, cs), N, c.K,
+                                   raw_known ? p->m_raw + p->raw_pos : p->m_raw,
+                                   raw_known ? (const uint32_t*)nullptr : (const uint32_t*)(p->m_seq + 8 + 2 * cs),
+                                   raw_tag, c.hyp, c.p3p_thr_sq, sl_R(p, cs),
                                    sl_t(p, cs), sl_valid(p, cs), sl_counts(p, cs), sl_masks(p, cs),
-                                   (uint32_t*)sl_nt(p, cs) + 2));
+                                   (uint32_t*)sl_nt(p, cs) + 2, p->m_R + (size_t)cs * c.hyp * 9,
+                                   p->m_t + (size_t)cs * c.hyp * 3));
   return VO_OK;
 }
 
 static int launch_mirror(vo_pipeline* p, int s, bool with_count, hipStream_t st) {
   const vo_pipeline_config& c = p->cfg;
   const size_t h = (size_t)s * c.hyp;
-  hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(16), dim3(256), 0, st, sl_valid(p, s), sl_counts(p, s),
-                     sl_R(p, s), sl_t(p, s), c.hyp, p->m_valid + h, p->m_counts + h, p->m_R + h * 9, p->m_t + h * 3,
+  // with_count: the step's own launch (poses already on the host) -> (valid, count) only, 2 workgroups
+  hipLaunchKernelGGL(mirror_hypotheses_kernel, dim3(with_count ? 2 : 16), dim3(256), 0, st, sl_valid(p, s), sl_counts(p, s),
+                     sl_R(p, s), sl_t(p, s), c.hyp, p->m_valid + h, p->m_counts + h,
+                     with_count ? (double*)nullptr : p->m_R + h * 9, with_count ? (double*)nullptr : p->m_t + h * 3,
                      p->m_seq + 4 * s + 1, p->m_seq + 4 * s + 2, (unsigned*)sl_nt(p, s) + 1,
                      with_count ? (const int32_t*)sl_nt(p, s) : (const int32_t*)nullptr, p->m_ntracked + 4 * s);
   return vo_check_launch(p->ctx, "mirror_hypotheses_kernel");
@@ -673,7 +683,7 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   // keypoints of `prev`: usually long finished, and then no barrier goes into the queue
   if (hipEventQuery(p->evDet[ev_prev]) != hipSuccess)
     VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[ev_prev], 0));
-  VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, seq));
+  VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, seq, publish_now));
   VO_TRY(launch_mirror(p, cs, true, ctx->stream));
 
   vo_pipeline::flight_t& f = p->flight[p->n_flight++];

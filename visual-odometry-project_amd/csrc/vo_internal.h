@@ -105,7 +105,8 @@ static inline int vo_cdiv(int a, int b) { return (a + b - 1) / b; }
 int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
                               const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
                               int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
-                              uint64_t* d_masks, uint32_t* d_flag);
+                              uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t);
+// m_R / m_t (optional, mapped host memory): every pose is also written there.
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
 void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
 // DLT with a device-resident point count (dlt.hip)
