@@ -549,13 +549,30 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
   const uint4 cnt = seg_cnt[blk];
   const int tid = threadIdx.x;
   for (unsigned i = blk * NT + tid; i < (unsigned)HIST_TOTAL; i += gridDim.x * NT) hist_other[i] = 0;
+  // the tile's segment entries are requested before the bound is computed (its two dependent
+  // histogram reads then overlap these loads instead of preceding one round trip per chunk)
+  constexpr int CH = SEG / NT;
+  unsigned long long ka[CH];
+  unsigned ia[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const unsigned i = (unsigned)k * NT + tid;
+    const bool in = i < cnt.y;
+    ka[k] = in ? seg_keys_a1[seg0 + i] : 0ull;
+    ia[k] = in ? seg_idx_a1[seg0 + i] : 0u;
+  }
+  unsigned long long kl = tid < cnt.x ? seg_keys_l1[seg0 + tid] : 0ull;
+  unsigned il = tid < cnt.x ? seg_idx_l1[seg0 + tid] : 0u;
   const unsigned long long t = nms_threshold_bits(hist, N);
   if (tid == 0) s_n = 0;
   __syncthreads();
   for (unsigned b0 = 0; b0 < cnt.x; b0 += NT) {
     const unsigned i = b0 + tid;
-    const unsigned long long key = i < cnt.x ? seg_keys_l1[seg0 + i] : 0ull;
-    const bool keep = i < cnt.x && key >= t;
+    if (b0 > 0) {   // tiles with more than NT strict maxima (r = 0 ...): later chunks are fetched here
+      kl = i < cnt.x ? seg_keys_l1[seg0 + i] : 0ull;
+      il = i < cnt.x ? seg_idx_l1[seg0 + i] : 0u;
+    }
+    const bool keep = i < cnt.x && kl >= t;
     if (tid == 0) s_l1n = 0;
     __syncthreads();
     const unsigned slot = wave_slot(keep, &s_l1n);
@@ -565,23 +582,22 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
     if (keep) {
       const unsigned pos = s_base + slot;
       if (pos < cap_c) {
-        keys_c[pos] = key;
-        idx_c[pos] = seg_idx_l1[seg0 + i] << 2;
+        keys_c[pos] = kl;
+        idx_c[pos] = il << 2;
       } else {
         ctl->overflow = 1;
       }
     }
     __syncthreads();
   }
-  for (unsigned b0 = 0; b0 < cnt.y; b0 += NT) {
-    const unsigned i = b0 + tid;
-    const unsigned long long key = i < cnt.y ? seg_keys_a1[seg0 + i] : 0ull;
-    const bool keep = i < cnt.y && key >= t;
-    const unsigned slot = wave_slot(keep, &s_n);
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    if ((unsigned)k * NT >= cnt.y) break;                 // uniform
+    const bool keep = (unsigned)k * NT + tid < cnt.y && ka[k] >= t;
+    const unsigned slot = wave_slot(keep, &s_n);          // (chunks in order, waves race within a chunk: any order is fine)
     if (keep) {
-      const unsigned idx = seg_idx_a1[seg0 + i];
-      seg_cand[seg0 + slot] = idx;
-      alive[idx] = live_code(key);
+      seg_cand[seg0 + slot] = ia[k];
+      alive[ia[k]] = live_code(ka[k]);
     }
   }
   __syncthreads();

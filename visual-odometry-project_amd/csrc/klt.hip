@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(const uint8_t* __restr
 // v = interior pixel (x, y) of a W x H level -> its place in the bordered buffer and every border
 // place that mirrors onto it (one reflection: needs min(W, H) > PYR_PAD)
 __device__ __forceinline__ void store_with_mirrors(uint8_t* __restrict__ dst, int pitch, int H, int W, int x, int y,
-                                                   uint8_t v) {
+                                                   uint8_t v, bool skip_own = false) {
   int xs[3], ys[3];
   int nx = 1, ny = 1;
   xs[0] = x + PYR_PAD;
@@ -90,7 +90,7 @@ __device__ __forceinline__ void store_with_mirrors(uint8_t* __restrict__ dst, in
   if (y >= 1 && y <= PYR_PAD) ys[ny++] = PYR_PAD - y;
   if (y >= H - 1 - PYR_PAD && y <= H - 2) ys[ny++] = PYR_PAD + 2 * (H - 1) - y;
   for (int j = 0; j < ny; ++j)
-    for (int i = 0; i < nx; ++i) dst[(size_t)ys[j] * pitch + xs[i]] = v;
+    for (int i = (j == 0 && skip_own) ? 1 : 0; i < nx; ++i) dst[(size_t)ys[j] * pitch + xs[i]] = v;
 }
 
 // 5x5 [1 4 6 4 1]^2 tap at (2x, 2y) of an unbordered W x H image, reflect-101
@@ -205,12 +205,16 @@ __global__ __launch_bounds__(256) void pyramid3_kernel(const uint8_t* __restrict
     store_with_mirrors(d1, p1, H1, W1, x1, y1, (uint8_t)((sum + 128) >> 8));
   }
 #pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int x0 = 2 * x1 + dx, y0 = 2 * y1 + dy;
-      if (x0 < W0 && y0 < H0) store_with_mirrors(d0, p0, H0, W0, x0, y0, s_l0[(2 * ly + 2 + dy) * 76 + 2 * lx + 2 + dx]);
-    }
+  for (int dy = 0; dy < 2; ++dy) {
+    const int x0 = 2 * x1, y0 = 2 * y1 + dy;
+    if (y0 >= H0) continue;
+    const uint8_t v0 = s_l0[(2 * ly + 2 + dy) * 76 + 2 * lx + 2], v1 = s_l0[(2 * ly + 2 + dy) * 76 + 2 * lx + 3];
+    uint8_t* own = d0 + (size_t)(y0 + PYR_PAD) * p0 + (x0 + PYR_PAD);       // even offset: one 16-bit store for the pair
+    if (x0 + 1 < W0) *reinterpret_cast<unsigned short*>(own) = (unsigned short)(v0 | (v1 << 8));
+    else *own = v0;
+    store_with_mirrors(d0, p0, H0, W0, x0, y0, v0, true);                    // border copies only
+    if (x0 + 1 < W0) store_with_mirrors(d0, p0, H0, W0, x0 + 1, y0, v1, true);
+  }
 }
 
 // Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic), result in
