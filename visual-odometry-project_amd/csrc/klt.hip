@@ -135,12 +135,27 @@ __global__ __launch_bounds__(256) void pyramid3_kernel(const uint8_t* __restrict
     const int loy = max(ay, 0), hiy = min(ay + 34, H1 - 1);
     const int fx0 = 2 * lox - 2, fy0 = 2 * loy - 2;             // frame coordinate of s_l0[0][0]
     const int fw = 2 * (hix - lox) + 5, fh = 2 * (hiy - loy) + 5;
-    for (int i = tid; i < fw * fh; i += 256) {
-      const int ly = i / fw, lx = i - ly * fw;
-      int gx = fx0 + lx, gy = fy0 + ly;                         // at most 2 pixels outside: one reflection
-      gx = gx < 0 ? -gx : (gx >= W0 ? 2 * (W0 - 1) - gx : gx);
-      gy = gy < 0 ? -gy : (gy >= H0 ? 2 * (H0 - 1) - gy : gy);
-      s_l0[ly * 76 + lx] = src[(size_t)gy * W0 + gx];
+    {
+      // all loads of the patch go out before the first byte is stored (one round trip, not 21)
+      constexpr int PER = (73 * 73 + 255) / 256;
+      uint8_t v[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * 256;
+        const int ly = i / fw, lx = i - ly * fw;
+        int gx = fx0 + lx, gy = fy0 + ly;                       // at most 2 pixels outside: one reflection
+        gx = gx < 0 ? -gx : (gx >= W0 ? 2 * (W0 - 1) - gx : gx);
+        gy = gy < 0 ? -gy : (gy >= H0 ? 2 * (H0 - 1) - gy : gy);
+        gx = min(max(gx, 0), W0 - 1);
+        gy = min(max(gy, 0), H0 - 1);                           // (entries past fw * fh: any valid address)
+        v[k] = src[(size_t)gy * W0 + gx];
+      }
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * 256;
+        const int ly = i / fw, lx = i - ly * fw;
+        if (i < fw * fh) s_l0[ly * 76 + lx] = v[k];
+      }
     }
     __syncthreads();
     for (int i = tid; i < 35 * 35; i += 256) {
@@ -180,14 +195,26 @@ __global__ __launch_bounds__(256) void pyramid3_kernel(const uint8_t* __restrict
   const int blk = (int)blockIdx.x - nB;
   const int x1a = (blk % blocks1_x) * 32, y1a = (blk / blocks1_x) * 8;
   const int fx0 = 2 * x1a - 2, fy0 = 2 * y1a - 2;
-  for (int i = tid; i < 67 * 19; i += 256) {
-    const int ly = i / 67, lx = i - ly * 67;
-    int gx = fx0 + lx, gy = fy0 + ly;
-    gx = gx < 0 ? -gx : (gx >= W0 ? 2 * (W0 - 1) - gx : gx);     // at most 2 pixels outside (tiles that stick out
-    gy = gy < 0 ? -gy : (gy >= H0 ? 2 * (H0 - 1) - gy : gy);     //  further only feed pixels that are not stored)
-    gx = min(max(gx, 0), W0 - 1);
-    gy = min(max(gy, 0), H0 - 1);
-    s_l0[ly * 76 + lx] = src[(size_t)gy * W0 + gx];
+  {
+    constexpr int PER = (67 * 19 + 255) / 256;
+    uint8_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * 256;
+      const int ly = i / 67, lx = i - ly * 67;
+      int gx = fx0 + lx, gy = fy0 + ly;
+      gx = gx < 0 ? -gx : (gx >= W0 ? 2 * (W0 - 1) - gx : gx);     // at most 2 pixels outside (tiles that stick out
+      gy = gy < 0 ? -gy : (gy >= H0 ? 2 * (H0 - 1) - gy : gy);     //  further only feed pixels that are not stored)
+      gx = min(max(gx, 0), W0 - 1);
+      gy = min(max(gy, 0), H0 - 1);
+      v[k] = src[(size_t)gy * W0 + gx];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * 256;
+      const int ly = i / 67, lx = i - ly * 67;
+      if (i < 67 * 19) s_l0[ly * 76 + lx] = v[k];
+    }
   }
   __syncthreads();
   const int lx = tid & 31, ly = tid >> 5;
