@@ -28,32 +28,52 @@
 #include <string.h>
 
 static double cubic_positive_root(double A, double B, double C) {
-  /* a real root in (0, bound] of m^3 + A m^2 + B m + C, given C < 0: Newton steps
-   * kept inside a sign-change bracket, bisection otherwise (fixed operation
-   * order, +,-,*,/ only, so every implementation converges to the same bits) */
-  double bound = fabs(A);
-  if (fabs(B) > bound) bound = fabs(B);
-  if (fabs(C) > bound) bound = fabs(C);
-  double xl = 0.0, xh = 1.0 + bound;
-  double rts = 0.5 * (xl + xh);
+  /* a real root in (0, U] of m^3 + A m^2 + B m + C, given C < 0.  U bounds every positive root:
+   * beyond it each of |A| m^2, |B| m, |C| is below m^3 / 3.  L bounds them from below:
+   * -C = m (m^2 + A m + B) <= m (U^2 + |A| U + |B|).  Newton steps kept inside the sign-change
+   * bracket [L, U]; otherwise the bracket is split at its geometric mean while it spans more
+   * than two octaves, at its midpoint after that (fixed operation order; + - * / sqrt and
+   * exponent arithmetic only, so every implementation converges to the same bits) */
+  double U = 3.0 * fabs(A);
+  const double sb = sqrt(3.0 * fabs(B));
+  if (sb > U) U = sb;
+  int e;
+  (void)frexp(3.0 * fabs(C), &e);                          /* 3|C| < 2^e */
+  const int e3 = (e >= 0) ? (e + 2) / 3 : -((-e) / 3);     /* ceil(e / 3) */
+  const double cb = ldexp(1.0, e3);
+  if (cb > U) U = cb;
+  double xl = fabs(C) / ((U + fabs(A)) * U + fabs(B));
+  double xh = 1.0625 * U;
+  {
+    const double fl = ((xl + A) * xl + B) * xl + C;
+    if (fl == 0.0) return xl;
+    if (!(fl < 0.0)) xl = 0.0;                             /* rounding spoiled the lower bound */
+  }
+  double rts = (xl > 0.0 && xh > 4.0 * xl) ? sqrt(xl * xh) : 0.5 * (xl + xh);
   double dxold = xh - xl, dx = dxold;
   double f = ((rts + A) * rts + B) * rts + C;
   double df = (3.0 * rts + 2.0 * A) * rts + B;
-  for (int it = 0; it < 128; ++it) {
+  for (int it = 0; it < 100; ++it) {
     if (f == 0.0) break;
     if (f < 0.0) xl = rts;
     else xh = rts;
-    double prev = rts;
+    const double prev = rts;
     if ((((rts - xh) * df - f) * ((rts - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
       dxold = dx;
-      dx = 0.5 * (xh - xl);
-      rts = xl + dx;
+      if (xl > 0.0 && xh > 4.0 * xl) {
+        rts = sqrt(xl * xh);
+        dx = rts - xl;
+      } else {
+        dx = 0.5 * (xh - xl);
+        rts = xl + dx;
+      }
     } else {
       dxold = dx;
       dx = f / df;
       rts = rts - dx;
     }
-    if (rts == prev) break;
+    if (rts == prev || fabs(dx) <= 1.4551915228366852e-11 * fabs(rts)) break;   /* 2^-36: the quartic's
+                                                       roots are Newton-polished afterwards */
     f = ((rts + A) * rts + B) * rts + C;
     df = (3.0 * rts + 2.0 * A) * rts + B;
   }

@@ -26,31 +26,48 @@ struct pose_t {
 };
 
 __device__ __forceinline__ double cubic_root_bracketed(double A, double B, double C) {
-  // real root in (0, 1 + max|coef|] of m^3 + A m^2 + B m + C for C < 0:
-  // Newton inside a sign-change bracket, bisection when Newton leaves it or stalls
-  double bound = fabs(A);
-  if (fabs(B) > bound) bound = fabs(B);
-  if (fabs(C) > bound) bound = fabs(C);
-  double xl = 0.0, xh = 1.0 + bound;
-  double rts = 0.5 * (xl + xh);
+  // same operations in the same order as oracle/csrc/p3p.c:cubic_positive_root -- a real root in
+  // (0, U] of m^3 + A m^2 + B m + C for C < 0, Newton inside the bracket [L, U], geometric-mean
+  // then midpoint bisection when Newton leaves it or stalls
+  double U = 3.0 * fabs(A);
+  const double sb = sqrt(3.0 * fabs(B));
+  if (sb > U) U = sb;
+  int e;
+  (void)frexp(3.0 * fabs(C), &e);                          // 3|C| < 2^e
+  const int e3 = (e >= 0) ? (e + 2) / 3 : -((-e) / 3);     // ceil(e / 3)
+  const double cb = ldexp(1.0, e3);
+  if (cb > U) U = cb;
+  double xl = fabs(C) / ((U + fabs(A)) * U + fabs(B));
+  double xh = 1.0625 * U;
+  {
+    const double fl = ((xl + A) * xl + B) * xl + C;
+    if (fl == 0.0) return xl;
+    if (!(fl < 0.0)) xl = 0.0;                             // rounding spoiled the lower bound
+  }
+  double rts = (xl > 0.0 && xh > 4.0 * xl) ? sqrt(xl * xh) : 0.5 * (xl + xh);
   double dxold = xh - xl, dx = dxold;
   double f = ((rts + A) * rts + B) * rts + C;
   double df = (3.0 * rts + 2.0 * A) * rts + B;
-  for (int it = 0; it < 128; ++it) {
+  for (int it = 0; it < 100; ++it) {
     if (f == 0.0) break;
     if (f < 0.0) xl = rts;
     else xh = rts;
     const double prev = rts;
     if ((((rts - xh) * df - f) * ((rts - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
       dxold = dx;
-      dx = 0.5 * (xh - xl);
-      rts = xl + dx;
+      if (xl > 0.0 && xh > 4.0 * xl) {
+        rts = sqrt(xl * xh);
+        dx = rts - xl;
+      } else {
+        dx = 0.5 * (xh - xl);
+        rts = xl + dx;
+      }
     } else {
       dxold = dx;
       dx = f / df;
       rts = rts - dx;
     }
-    if (rts == prev) break;
+    if (rts == prev || fabs(dx) <= 1.4551915228366852e-11 * fabs(rts)) break;   // 2^-36 (roots are polished later)
     f = ((rts + A) * rts + B) * rts + C;
     df = (3.0 * rts + 2.0 * A) * rts + B;
   }
