@@ -27,13 +27,17 @@
 #include <stdint.h>
 #include <string.h>
 
+static double cubic_eval(double A, double B, double C, double x) { return ((x + A) * x + B) * x + C; }
+
 static double cubic_positive_root(double A, double B, double C) {
   /* a real root in (0, U] of m^3 + A m^2 + B m + C, given C < 0.  U bounds every positive root:
    * beyond it each of |A| m^2, |B| m, |C| is below m^3 / 3.  L bounds them from below:
-   * -C = m (m^2 + A m + B) <= m (U^2 + |A| U + |B|).  Newton steps kept inside the sign-change
-   * bracket [L, U]; otherwise the bracket is split at its geometric mean while it spans more
-   * than two octaves, at its midpoint after that (fixed operation order; + - * / sqrt and
-   * exponent arithmetic only, so every implementation converges to the same bits) */
+   * -C = m (m^2 + A m + B) <= m (U^2 + |A| U + |B|).  The sign-change bracket [L, U] is cut in
+   * four per round -- at geometric points while it spans more than four octaves, evenly after
+   * that -- keeping the leftmost sign change, down to a relative width of 2^-36; one Newton
+   * step finishes.  No data-dependent branches on anything but signs, and the three cut points of
+   * a round are independent (the GPU evaluates them in three lanes).  Fixed operation order;
+   * + - * / sqrt and exponent arithmetic only, so every implementation gets the same bits. */
   double U = 3.0 * fabs(A);
   const double sb = sqrt(3.0 * fabs(B));
   if (sb > U) U = sb;
@@ -44,40 +48,37 @@ static double cubic_positive_root(double A, double B, double C) {
   if (cb > U) U = cb;
   double xl = fabs(C) / ((U + fabs(A)) * U + fabs(B));
   double xh = 1.0625 * U;
-  {
-    const double fl = ((xl + A) * xl + B) * xl + C;
-    if (fl == 0.0) return xl;
-    if (!(fl < 0.0)) xl = 0.0;                             /* rounding spoiled the lower bound */
-  }
-  double rts = (xl > 0.0 && xh > 4.0 * xl) ? sqrt(xl * xh) : 0.5 * (xl + xh);
-  double dxold = xh - xl, dx = dxold;
-  double f = ((rts + A) * rts + B) * rts + C;
-  double df = (3.0 * rts + 2.0 * A) * rts + B;
-  for (int it = 0; it < 100; ++it) {
-    if (f == 0.0) break;
-    if (f < 0.0) xl = rts;
-    else xh = rts;
-    const double prev = rts;
-    if ((((rts - xh) * df - f) * ((rts - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
-      dxold = dx;
-      if (xl > 0.0 && xh > 4.0 * xl) {
-        rts = sqrt(xl * xh);
-        dx = rts - xl;
-      } else {
-        dx = 0.5 * (xh - xl);
-        rts = xl + dx;
-      }
+  if (!(cubic_eval(A, B, C, xl) < 0.0)) xl = 0.0;          /* rounding spoiled the lower bound */
+  for (int it = 0; it < 64; ++it) {
+    if (!(xh - xl > 1.4551915228366852e-11 * xh)) break;   /* 2^-36 */
+    double p1, p2, p3;
+    if (xl > 0.0 && xh > 16.0 * xl) {
+      const double r2 = sqrt(xh / xl);
+      const double r1 = sqrt(r2);
+      p1 = xl * r1;
+      p2 = xl * r2;
+      p3 = p2 * r1;
     } else {
-      dxold = dx;
-      dx = f / df;
-      rts = rts - dx;
+      const double w = 0.25 * (xh - xl);
+      p1 = xl + w;
+      p2 = xl + 2.0 * w;
+      p3 = xl + 3.0 * w;
     }
-    if (rts == prev || fabs(dx) <= 1.4551915228366852e-11 * fabs(rts)) break;   /* 2^-36: the quartic's
-                                                       roots are Newton-polished afterwards */
-    f = ((rts + A) * rts + B) * rts + C;
-    df = (3.0 * rts + 2.0 * A) * rts + B;
+    const int s1 = cubic_eval(A, B, C, p1) >= 0.0;
+    const int s2 = cubic_eval(A, B, C, p2) >= 0.0;
+    const int s3 = cubic_eval(A, B, C, p3) >= 0.0;
+    if (s1) xh = p1;
+    else if (s2) { xl = p1; xh = p2; }
+    else if (s3) { xl = p2; xh = p3; }
+    else xl = p3;
   }
-  return rts;
+  double m = 0.5 * (xl + xh);
+  {
+    const double f = cubic_eval(A, B, C, m);
+    const double df = (3.0 * m + 2.0 * A) * m + B;
+    if (df != 0.0) m = m - f / df;
+  }
+  return m;
 }
 
 static int quadratic_real(double b, double c, double* r) {

@@ -25,10 +25,19 @@ struct pose_t {
   double t[3];
 };
 
-__device__ __forceinline__ double cubic_root_bracketed(double A, double B, double C) {
-  // same operations in the same order as oracle/csrc/p3p.c:cubic_positive_root -- a real root in
-  // (0, U] of m^3 + A m^2 + B m + C for C < 0, Newton inside the bracket [L, U], geometric-mean
-  // then midpoint bisection when Newton leaves it or stalls
+__device__ __forceinline__ double cubic_eval(double A, double B, double C, double x) { return ((x + A) * x + B) * x + C; }
+
+// value of lane k (0..3) of the caller's quad, in all four lanes
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, true);   // quad_perm [K,K,K,K]
+}
+
+// Same operations in the same order as oracle/csrc/p3p.c:cubic_positive_root (a real root in (0, U]
+// of m^3 + A m^2 + B m + C for C < 0: the bracket [L, U] cut in four per round down to 2^-36, then
+// one Newton step).  Called by all four lanes of a hypothesis with equal arguments: lanes 1..3
+// evaluate the three cut points of a round, the signs travel by DPP.
+__device__ __forceinline__ double cubic_root_bracketed(double A, double B, double C, int sub) {
   double U = 3.0 * fabs(A);
   const double sb = sqrt(3.0 * fabs(B));
   if (sb > U) U = sb;
@@ -39,39 +48,37 @@ __device__ __forceinline__ double cubic_root_bracketed(double A, double B, doubl
   if (cb > U) U = cb;
   double xl = fabs(C) / ((U + fabs(A)) * U + fabs(B));
   double xh = 1.0625 * U;
-  {
-    const double fl = ((xl + A) * xl + B) * xl + C;
-    if (fl == 0.0) return xl;
-    if (!(fl < 0.0)) xl = 0.0;                             // rounding spoiled the lower bound
-  }
-  double rts = (xl > 0.0 && xh > 4.0 * xl) ? sqrt(xl * xh) : 0.5 * (xl + xh);
-  double dxold = xh - xl, dx = dxold;
-  double f = ((rts + A) * rts + B) * rts + C;
-  double df = (3.0 * rts + 2.0 * A) * rts + B;
-  for (int it = 0; it < 100; ++it) {
-    if (f == 0.0) break;
-    if (f < 0.0) xl = rts;
-    else xh = rts;
-    const double prev = rts;
-    if ((((rts - xh) * df - f) * ((rts - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
-      dxold = dx;
-      if (xl > 0.0 && xh > 4.0 * xl) {
-        rts = sqrt(xl * xh);
-        dx = rts - xl;
-      } else {
-        dx = 0.5 * (xh - xl);
-        rts = xl + dx;
-      }
+  if (!(cubic_eval(A, B, C, xl) < 0.0)) xl = 0.0;          // rounding spoiled the lower bound
+  for (int it = 0; it < 64; ++it) {
+    if (!(xh - xl > 1.4551915228366852e-11 * xh)) break;   // 2^-36 (uniform over the quad)
+    double p1, p2, p3;
+    if (xl > 0.0 && xh > 16.0 * xl) {
+      const double r2 = sqrt(xh / xl);
+      const double r1 = sqrt(r2);
+      p1 = xl * r1;
+      p2 = xl * r2;
+      p3 = p2 * r1;
     } else {
-      dxold = dx;
-      dx = f / df;
-      rts = rts - dx;
+      const double w = 0.25 * (xh - xl);
+      p1 = xl + w;
+      p2 = xl + 2.0 * w;
+      p3 = xl + 3.0 * w;
     }
-    if (rts == prev || fabs(dx) <= 1.4551915228366852e-11 * fabs(rts)) break;   // 2^-36 (roots are polished later)
-    f = ((rts + A) * rts + B) * rts + C;
-    df = (3.0 * rts + 2.0 * A) * rts + B;
+    const double pm = sub == 1 ? p1 : (sub == 2 ? p2 : p3);   // (lane 0 duplicates lane 3)
+    const int sm = cubic_eval(A, B, C, pm) >= 0.0 ? 1 : 0;
+    const int s1 = quad_bcast<1>(sm), s2 = quad_bcast<2>(sm), s3 = quad_bcast<3>(sm);
+    if (s1) xh = p1;
+    else if (s2) { xl = p1; xh = p2; }
+    else if (s3) { xl = p2; xh = p3; }
+    else xl = p3;
   }
-  return rts;
+  double m = 0.5 * (xl + xh);
+  {
+    const double f = cubic_eval(A, B, C, m);
+    const double df = (3.0 * m + 2.0 * A) * m + B;
+    if (df != 0.0) m = m - f / df;
+  }
+  return m;
 }
 
 __device__ __forceinline__ int quad_roots(double b, double c, double* r) {
@@ -84,14 +91,15 @@ __device__ __forceinline__ int quad_roots(double b, double c, double* r) {
   return 2;
 }
 
-__device__ int quartic_roots(double c0, double c1, double c2, double c3, double c4, double* roots) {
+// quad-cooperative: lane `sub` polishes (and returns in roots[sub]) only the root it will use
+__device__ int quartic_roots(double c0, double c1, double c2, double c3, double c4, double* roots, int sub) {
   if (c4 == 0.0) return 0;
   const double a3 = c3 / c4, a2 = c2 / c4, a1 = c1 / c4, a0 = c0 / c4;
   const double a3sq = a3 * a3;
   const double p = a2 - 0.375 * a3sq;
   const double q = a1 - 0.5 * a2 * a3 + 0.125 * a3sq * a3;
   const double r = a0 - 0.25 * a1 * a3 + 0.0625 * a2 * a3sq - (3.0 / 256.0) * a3sq * a3sq;
-  double y[4];
+  double y[4] = {0.0, 0.0, 0.0, 0.0};
   int n = 0;
   if (q == 0.0) {
     double z[2];
@@ -104,7 +112,7 @@ __device__ int quartic_roots(double c0, double c1, double c2, double c3, double 
       }
     }
   } else {
-    const double m = cubic_root_bracketed(p, 0.25 * p * p - r, -0.125 * q * q);
+    const double m = cubic_root_bracketed(p, 0.25 * p * p - r, -0.125 * q * q, sub);
     if (!(m > 0.0)) return 0;
     const double s = sqrt(2.0 * m);
     const double h = 0.5 * p + m;
@@ -113,15 +121,21 @@ __device__ int quartic_roots(double c0, double c1, double c2, double c3, double 
     n += quad_roots(-s, h + g, y + n);
   }
   const double shift = 0.25 * a3;
-  for (int i = 0; i < n; ++i) {
-    double x = y[i] - shift;
-    for (int it = 0; it < 3; ++it) {
-      const double f = (((x + a3) * x + a2) * x + a1) * x + a0;
-      const double df = ((4.0 * x + 3.0 * a3) * x + 2.0 * a2) * x + a1;
-      if (df == 0.0) break;
-      x = x - f / df;
+  {
+    double ys = y[0];
+    if (sub == 1) ys = y[1];
+    if (sub == 2) ys = y[2];
+    if (sub == 3) ys = y[3];
+    double x = ys - shift;
+    if (sub < n) {
+      for (int it = 0; it < 3; ++it) {
+        const double f = (((x + a3) * x + a2) * x + a1) * x + a0;
+        const double df = ((4.0 * x + 3.0 * a3) * x + 2.0 * a2) * x + a1;
+        if (df == 0.0) break;
+        x = x - f / df;
+      }
     }
-    roots[i] = x;
+    roots[0] = roots[1] = roots[2] = roots[3] = x;   // (each lane reads its own entry)
   }
   return n;
 }
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
     const double q1 = 2.0 * n1 * n0 - tc * nd1 + (w1 * dd0 + w0 * dd1);
     const double q0 = n0 * n0 - tc * nd0 + w0 * dd0;
     double roots[4];
-    const int nr = quartic_roots(q0, q1, q2, q3, q4, roots);
+    const int nr = quartic_roots(q0, q1, q2, q3, q4, roots, sub);
     do {
       if (sub >= nr) break;
       double v = roots[0];
