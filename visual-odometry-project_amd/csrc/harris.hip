@@ -627,6 +627,7 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
 // leaves (FINAL) joins the list as undecided entries for the sorted walk.
 constexpr int ROUND_ITERS = 64;
 constexpr int RT = 512;           // threads of a round workgroup
+constexpr int LIVE_SPARSE = 32;   // at most this many live candidates: no dense pass, each looks around itself
 static_assert((CX * CY) % RT == 0 && RT % CY == 0, "the row pass of the round kernel maps one strip to one thread");
 
 __device__ __forceinline__ unsigned load_state(const unsigned* p) {
@@ -655,9 +656,10 @@ __global__ __launch_bounds__(RT) void nms_round_kernel(const double* __restrict_
   unsigned* s_v = s_state + SP * LH;             // CY x LW (pitch SP)  column maxima
   unsigned* s_m = s_v;                           // CY x CX (pitch PM)  window maxima, written over the column maxima
   __shared__ unsigned short s_cell[SEG];         // LDS cell of candidate i
-  __shared__ unsigned short s_pass[SEG];         // candidates that top their window this iteration
+  __shared__ unsigned short s_pass[SEG];         // live candidates of this iteration
   __shared__ unsigned short s_sel[SEG];          // candidates selected in this launch
-  __shared__ unsigned s_npass, s_nsel, s_prog;
+  __shared__ unsigned short s_pass2[SEG];        // ... after the dense filter
+  __shared__ unsigned s_npass, s_npass2, s_nsel, s_prog;
   const unsigned blk = blockIdx.x;
   const unsigned n = seg_cnt[blk].z;
   const int tid = threadIdx.x;
@@ -705,88 +707,98 @@ __global__ __launch_bounds__(RT) void nms_round_kernel(const double* __restrict_
       }
     }
     __syncthreads();
-    // ---- window maximum of the state words: columns (lanes along x), then rows (lanes along y) ----
-    for (int it = tid; it < LW * (CY / 8); it += RT) {
-      const int st = it / LW, x = it - st * LW;
-      const int ys = st * 8;
-      const unsigned* col = s_state + ys * SP + x;
-      if (R_T > 0) {
-        unsigned v[8 + 2 * R_T];
-#pragma unroll
-        for (int k = 0; k < 8 + 2 * R_T; ++k) v[k] = col[k * SP];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          unsigned m = v[o];
-#pragma unroll
-          for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
-          s_v[(ys + o) * SP + x] = m;
-        }
-      } else {
-        for (int o = 0; o < 8; ++o) {
-          unsigned m = col[o * SP];
-          for (int d = 1; d < WN; ++d) m = max(m, col[(o + d) * SP]);
-          s_v[(ys + o) * SP + x] = m;
-        }
-      }
-    }
-    __syncthreads();
-    {
-      // one strip of RS window maxima per thread (CY * CX / RS == RT), lanes along y; they are
-      // written over the column maxima, so every thread reads before any thread writes
-      constexpr int RS = CX * CY / RT;
-      const int y = tid & (CY - 1), xs = (tid / CY) * RS;
-      const unsigned* row = s_v + y * SP + xs;
-      unsigned out[RS];
-      if (R_T > 0) {
-        unsigned v[RS + 2 * R_T];
-#pragma unroll
-        for (int k = 0; k < RS + 2 * R_T; ++k) v[k] = row[k];
-#pragma unroll
-        for (int o = 0; o < RS; ++o) {
-          unsigned m = v[o];
-#pragma unroll
-          for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
-          out[o] = m;
-        }
-      } else {
-#pragma unroll
-        for (int o = 0; o < RS; ++o) {
-          unsigned m = row[o];
-          for (int d = 1; d < WN; ++d) m = max(m, row[o + d]);
-          out[o] = m;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int o = 0; o < RS; ++o) s_m[y * PM + xs + o] = out[o];
-    }
-    __syncthreads();
-    // ---- candidates whose word tops their window ----
+    // ---- the tile's live candidates ----
     if (tid == 0) {
       s_npass = 0;
+      s_npass2 = 0;
       s_prog = 0;
     }
     __syncthreads();
-    unsigned live = 0;
     for (unsigned i = tid; i < n; i += RT) {
       const int cell = s_cell[i];
-      const unsigned cp = s_state[cell];
-      if (cp < 3u) continue;                                   // selected or dead
-      ++live;
-      const int ly = cell / SP, lx = cell - ly * SP;
-      if (s_m[(ly - r) * PM + (lx - r)] != cp) continue;       // a live neighbour has a larger word
-      s_pass[atomicAdd(&s_npass, 1u)] = (unsigned short)cell;
+      if (s_state[cell] >= 3u) s_pass[atomicAdd(&s_npass, 1u)] = (unsigned short)cell;
     }
-    const int any_live = __syncthreads_or(live ? 1 : 0);
-    if (!any_live) break;                                      // nothing left to decide in this tile
-    const unsigned npass = s_npass;
+    __syncthreads();
+    const unsigned nlive = s_npass;
+    if (nlive == 0) break;                                     // nothing left to decide in this tile
+    // Many live candidates: one dense pass finds those whose word tops their window, and only
+    // they get a wave.  Few (most tiles, and the late iterations of the busy ones): every live
+    // candidate gets a wave and looks for a larger live word in its window itself.
+    const unsigned short* list = s_pass;
+    unsigned npass = nlive;
+    if (nlive > (unsigned)LIVE_SPARSE) {
+      // ---- window maximum of the state words: columns (lanes along x), then rows (lanes along y) ----
+      for (int it = tid; it < LW * (CY / 8); it += RT) {
+        const int st = it / LW, x = it - st * LW;
+        const int ys = st * 8;
+        const unsigned* col = s_state + ys * SP + x;
+        if (R_T > 0) {
+          unsigned v[8 + 2 * R_T];
+#pragma unroll
+          for (int k = 0; k < 8 + 2 * R_T; ++k) v[k] = col[k * SP];
+#pragma unroll
+          for (int o = 0; o < 8; ++o) {
+            unsigned m = v[o];
+#pragma unroll
+            for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
+            s_v[(ys + o) * SP + x] = m;
+          }
+        } else {
+          for (int o = 0; o < 8; ++o) {
+            unsigned m = col[o * SP];
+            for (int d = 1; d < WN; ++d) m = max(m, col[(o + d) * SP]);
+            s_v[(ys + o) * SP + x] = m;
+          }
+        }
+      }
+      __syncthreads();
+      {
+        // one strip of RS window maxima per thread (CY * CX / RS == RT), lanes along y; they are
+        // written over the column maxima, so every thread reads before any thread writes
+        constexpr int RS = CX * CY / RT;
+        const int y = tid & (CY - 1), xs = (tid / CY) * RS;
+        const unsigned* row = s_v + y * SP + xs;
+        unsigned out[RS];
+        if (R_T > 0) {
+          unsigned v[RS + 2 * R_T];
+#pragma unroll
+          for (int k = 0; k < RS + 2 * R_T; ++k) v[k] = row[k];
+#pragma unroll
+          for (int o = 0; o < RS; ++o) {
+            unsigned m = v[o];
+#pragma unroll
+            for (int d = 1; d <= 2 * R_T; ++d) m = max(m, v[o + d]);
+            out[o] = m;
+          }
+        } else {
+#pragma unroll
+          for (int o = 0; o < RS; ++o) {
+            unsigned m = row[o];
+            for (int d = 1; d < WN; ++d) m = max(m, row[o + d]);
+            out[o] = m;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < RS; ++o) s_m[y * PM + xs + o] = out[o];
+      }
+      __syncthreads();
+      for (unsigned k = tid; k < nlive; k += RT) {
+        const int cell = s_pass[k];
+        const int ly = cell / SP, lx = cell - ly * SP;
+        if (s_m[(ly - r) * PM + (lx - r)] == s_state[cell]) s_pass2[atomicAdd(&s_npass2, 1u)] = (unsigned short)cell;
+      }
+      __syncthreads();
+      list = s_pass2;
+      npass = s_npass2;
+    }
     // ---- one wave per passing candidate: lanes share the window ----
     // Equal words are settled by the full score, then the flat index (a total order, so of
     // two tied neighbours exactly one proceeds).  The winner is selected and kills the live
     // words of its window, in LDS and in the global map.
     const int lane = tid & 63;
     for (unsigned k = tid >> 6; k < npass; k += RT / 64) {
-      const int cell = s_pass[k];
+      const int cell = list[k];
       unsigned* c = s_state + cell;
       const unsigned cp = *c;
       if (cp < 3u) continue;                                   // killed by a tied winner meanwhile
@@ -798,6 +810,7 @@ __global__ __launch_bounds__(RT) void nms_round_kernel(const double* __restrict_
         if (j == 0 && d == 0) continue;
         const unsigned v = c[j * SP + d];
         if (v == 1u) killed = true;                            // a selected pixel owns this window
+        if (v >= 3u && v > cp) blocked = true;                 // a live neighbour has a larger word
         if (v == cp) {
           const double s = sc[(size_t)py * W + px];
           const double q = sc[(size_t)(py + j) * W + (px + d)];
