@@ -105,8 +105,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lookahead", action="store_true",
-                    help="submit frame k+1 before collecting frame k (vo_pipeline_submit / _collect)")
+    ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
+                    help="one blocking vo_pipeline_step per frame instead of submitting frame k+1 before "
+                         "collecting frame k (vo_pipeline_submit / _collect)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,9 +145,11 @@ def main():
     stats = {"tracked": [], "inliers": [], "rot_err": [], "trans_err": [], "iters": [], "tri_err": []}
 
     def run(n, record=False):
-        # --lookahead: one frame of look-ahead, as a camera stream gives it: frame k+1 is submitted (all
-        # of its GPU work enqueued) before the pose of frame k is collected, so the host's share of a
-        # step overlaps the GPU's.  Default: the reference's order, one blocking call per frame.
+        # Default: one frame of look-ahead, as a camera stream gives it -- frame k+1 is submitted (all of
+        # its GPU work enqueued) before the pose of frame k is collected, so the host's share of a step
+        # (launches, sequential RANSAC replay) overlaps the GPU's.  Every frame is processed in full
+        # and the results are those of the blocking call (tests/test_gpu_pipeline.py).
+        # --no-lookahead: the reference's order, one blocking vo_pipeline_step per frame.
         nonlocal pos
         if args.lookahead:
             pipe.submit(order[pos], order[pos + 1])
@@ -251,6 +254,7 @@ def main():
             "config": {"workload": "cfg-2: 1376x1241 KITTI-shaped synthetic stream, Harris+NMS 2000 kp -> KLT 3-level "
                                    "15x15 -> P3P-RANSAC 1000 hyps -> DLT; one independent sequence per GPU",
                        "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP,
+                       "frame_lookahead": 1 if args.lookahead else 0,
                        "parallelism": "sequence-sharded x%d%s" % (world, ", RCCL all-gather of {pose, landmarks} per frame" if world > 1 else "")},
             "roofline": roof,
             "per_kernel_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(per_kernel.items())},

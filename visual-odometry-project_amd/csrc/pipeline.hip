@@ -26,7 +26,8 @@
 struct vo_pipeline {
   vo_ctx* ctx = nullptr;
   vo_ctx* det = nullptr;            // second context (own stream + NMS workspace): detection runs beside tracking
-  vo_ctx* redo = nullptr;           // third stream: hypothesis batches of the sequential sampler (rare) must not queue
+  vo_ctx* tri = nullptr;            // stream of the DLT (independent of the detection it used to queue behind)
+  vo_ctx* redo = nullptr;           // another stream: hypothesis batches of the sequential sampler (rare) must not queue
                                     // behind a step submitted later, whose solve kernel waits for this step's outcome
   hipEvent_t evDet[2] = {nullptr, nullptr};   // keypoints ready; steps alternate, so the wait for the last step's
                                               // event cannot catch this step's record
@@ -316,8 +317,10 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   if (!p) return VO_ENOMEM;
   p->ctx = ctx;
   p->cfg = *cfg;
-  if (vo_create(ctx->device, nullptr, &p->det) != VO_OK || vo_create(ctx->device, nullptr, &p->redo) != VO_OK) {
+  if (vo_create(ctx->device, nullptr, &p->det) != VO_OK || vo_create(ctx->device, nullptr, &p->redo) != VO_OK ||
+      vo_create(ctx->device, nullptr, &p->tri) != VO_OK) {
     if (p->det) vo_destroy(p->det);
+    if (p->redo) vo_destroy(p->redo);
     delete p;
     return vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the detection stream");
   }
@@ -445,6 +448,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (p->evDlt[k]) (void)hipEventDestroy(p->evDlt[k]);
   if (p->det) vo_destroy(p->det);
   if (p->redo) vo_destroy(p->redo);
+  if (p->tri) vo_destroy(p->tri);
   delete p;
 }
 
@@ -497,7 +501,8 @@ static int enqueue_detection(vo_pipeline* p, int frame, int slot, int ev) {
 // host memory (set s is rewritten two steps later at the earliest), the point count from the
 // word the gather kernel of that step left in HBM.
 static int enqueue_dlt(vo_pipeline* p, int s) {
-  vo_ctx* det = p->det;
+  vo_ctx* det = p->tri;   // (own stream: the tracks are complete -- the host has collected the step -- and nothing
+                          //  on the detection stream depends on it)
   int rc = vo_triangulate_dlt_ndev(det, p->d_prev_c[s], p->d_next_c[s], sl_nt(p, s), p->cfg.n_keypoints, p->m_C + 24 * s,
                                    p->m_C + 24 * s + 12, sl_tri(p, s));
   if (rc == VO_OK && hipEventRecord(p->evDlt[s], det->stream) != hipSuccess) rc = VO_EHIP;
@@ -572,8 +577,8 @@ static void worker_main(vo_pipeline* p) {
 }
 
 static void post_job(vo_pipeline* p, int kind, int frame, int slot, int ev) {
-  p->det->prof_on = p->ctx->prof_on;
-  p->det->prof_kernel = p->ctx->prof_kernel;
+  p->det->prof_on = p->tri->prof_on = p->ctx->prof_on;
+  p->det->prof_kernel = p->tri->prof_kernel = p->ctx->prof_kernel;
   const unsigned n = p->job_posted.load(std::memory_order_relaxed);
   while (n - p->job_done.load(std::memory_order_acquire) >= 8) __builtin_ia32_pause();   // ring full (never in practice)
   p->jobs[n & 7] = {kind, frame, slot, ev};
@@ -878,8 +883,12 @@ int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64
   VO_TRY(vo_prof_read(p->ctx, kernel_id, &a, &na));
   int rc = vo_prof_read(p->det, kernel_id, &b, &nb);
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->det));
-  if (total_ms) *total_ms = a + b;
-  if (launches) *launches = na + nb;
+  double c = 0;
+  int64_t nc = 0;
+  rc = vo_prof_read(p->tri, kernel_id, &c, &nc);
+  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->tri));
+  if (total_ms) *total_ms = a + b + c;
+  if (launches) *launches = na + nb + nc;
   return VO_OK;
 }
 
@@ -887,6 +896,7 @@ int vo_pipeline_prof_reset(vo_pipeline* p) {
   if (!p) return VO_EINVAL;
   VO_TRY(worker_idle(p));
   VO_TRY(vo_prof_reset(p->ctx));
+  VO_TRY(vo_prof_reset(p->tri));
   return vo_prof_reset(p->det);
 }
 
