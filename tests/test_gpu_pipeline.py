@@ -124,3 +124,43 @@ def test_pipeline_lookahead_matches_step(ctx, sampler, monkeypatch):
     assert last["prev_xy"].shape == (got[-1][0], 2)
     pipe.close()
     assert got == ref
+
+
+def test_pipeline_stress_configuration_properties(ctx):
+    """BASELINE.json configs[4] (3840x2160, 8000 keypoints, 4-level pyramid, 4000 hypotheses): far
+    beyond what the oracle finishes in seconds, so checked through properties that do not depend
+    on size -- the greedy NMS rule (keypoints in decreasing score order, no two within r, none
+    better left unsuppressed), tracked points near the frame, and the recovered pose against the
+    stream's analytic ground truth."""
+    from vo import _native, synthetic
+    H, W, N, hyp, F, r = 2160, 3840, 8000, 4000, 3, 5
+    stream = synthetic.Stream(F, H, W)
+    pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, klt_win=15, klt_max_level=3, hyp=hyp,
+                            p3p_threshold=1.0, max_iterations=1000)
+    for i in range(F):
+        pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
+    pipe.prime(0)
+    for a, b in ((0, 1), (1, 2)):
+        res = pipe.step(a, b)
+        got = pipe.fetch(res.n_tracked)
+        # pose
+        Tcw = np.linalg.inv(stream.T_world_cam(b))
+        R, t = np.array(res.R).reshape(3, 3), np.array(res.t)
+        assert res.n_tracked > 0.8 * N and res.n_inliers > 0.3 * res.n_tracked
+        assert np.abs(R - Tcw[:3, :3]).max() < 5e-3 and np.abs(t - Tcw[:3, 3]).max() < 0.1
+        # (OpenCV's rule keeps a track while its window's corner is within one window of the frame)
+        assert (got["next_xy"] > -15).all() and (got["next_xy"][:, 0] < W + 15).all() and (got["next_xy"][:, 1] < H + 15).all()
+        # NMS of frame b
+        kp = got["kp_next"].astype(np.int64)
+        sc = ctx.harris_response(stream.image(b), 9, 0.09)
+        s = sc[kp[:, 1], kp[:, 0]]
+        assert (s > 0).all() and (np.diff(s) <= 0).all(), "keypoints are not in decreasing score order"
+        occupied = np.zeros((H, W), bool)
+        for (x, y) in kp:                                   # no pick inside an earlier pick's window
+            assert not occupied[y, x]
+            occupied[max(y - r, 0):y + r + 1, max(x - r, 0):x + r + 1] = True
+        # nothing better than the last pick is left outside every window (the greedy rule took the
+        # best remaining pixel each time)
+        left = np.where(occupied, 0.0, sc)
+        assert left.max() <= s[-1]
+    pipe.close()
