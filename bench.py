@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 
 H, W, N_KP, HYP, WIN, MAX_LEVEL = 1241, 1376, 2000, 1000, 15, 2
 N_FRAMES = 8
+PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -205,6 +206,9 @@ def main():
 
     # timed region: exactly K steps, events only around the dominant kernel
     pipe.prof_reset()
+    # (every PROF_EVERY-th launch is bracketed: an event pair costs the stream ~5 us, and bracketing
+    #  all of them made the step 4 % slower than it is)
+    ctx.prof_set_sampling(PROF_EVERY)
     ctx.prof_enable(dom_id)
     fence()
     t0 = time.perf_counter()
@@ -213,6 +217,7 @@ def main():
     dt = time.perf_counter() - t0
     dom_ms, dom_n = pipe.prof_read(dom_id)
     ctx.prof_disable()
+    ctx.prof_set_sampling(1)
 
     # untimed: accuracy against the analytic ground truth of the stream
     run(16, record=True)
@@ -231,7 +236,7 @@ def main():
         roof = {"bound": "hbm", "kernel": dom_name, "avg_launch_us": round(avg_us, 3), "launches": dom_n,
                 "algorithmic_bytes_per_launch": ab, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "traffic": pmc_traffic(dom_name)}
-        if ab:
+        if ab and avg_us > 0:
             ach = ab / (avg_us * 1e-6) / 1e9
             roof["achieved"] = round(ach, 2)
             roof["frac"] = round(ach / HBM_PEAK_GBS, 5)

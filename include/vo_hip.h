@@ -88,6 +88,9 @@ enum {
   VO_K_COUNT = 32
 };
 int vo_prof_enable(vo_ctx* ctx, int kernel_id);
+/* bracket only every n-th launch of a profiled kernel (default 1): the event pair itself costs
+ * the stream a few microseconds, vo_prof_read then reports the sampled launches           */
+int vo_prof_set_sampling(vo_ctx* ctx, int every);
 int vo_prof_disable(vo_ctx* ctx);
 int vo_prof_read(vo_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
 int vo_prof_reset(vo_ctx* ctx);

@@ -579,6 +579,7 @@ static void worker_main(vo_pipeline* p) {
 static void post_job(vo_pipeline* p, int kind, int frame, int slot, int ev) {
   p->det->prof_on = p->tri->prof_on = p->ctx->prof_on;
   p->det->prof_kernel = p->tri->prof_kernel = p->ctx->prof_kernel;
+  p->det->prof_every = p->tri->prof_every = p->ctx->prof_every;
   const unsigned n = p->job_posted.load(std::memory_order_relaxed);
   while (n - p->job_done.load(std::memory_order_acquire) >= 8) __builtin_ia32_pause();   // ring full (never in practice)
   p->jobs[n & 7] = {kind, frame, slot, ev};

@@ -161,6 +161,12 @@ int vo_prof_enable(vo_ctx* ctx, int kernel_id) {
   return VO_OK;
 }
 
+int vo_prof_set_sampling(vo_ctx* ctx, int every) {
+  if (!ctx || every < 1) return VO_EINVAL;
+  ctx->prof_every = every;
+  return VO_OK;
+}
+
 int vo_prof_disable(vo_ctx* ctx) {
   if (!ctx) return VO_EINVAL;
   ctx->prof_on = false;
@@ -211,6 +217,7 @@ static hipEvent_t take_event(vo_ctx* c) {
 
 vo_prof_scope::vo_prof_scope(vo_ctx* ctx, int kernel) : c(ctx), k(kernel) {
   if (!c->prof_on || (c->prof_kernel >= 0 && c->prof_kernel != k)) return;
+  if (c->prof_every > 1 && (c->prof_seen[k]++ % (unsigned)c->prof_every) != 0) return;
   a = take_event(c);
   b = take_event(c);
   if (!a || !b) {

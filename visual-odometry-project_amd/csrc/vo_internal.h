@@ -36,6 +36,8 @@ struct vo_ctx {
   // profiling
   bool prof_on = false;
   int prof_kernel = -1;
+  int prof_every = 1;                 // bracket every n-th launch of a profiled kernel only (events perturb the stream)
+  unsigned prof_seen[VO_K_COUNT] = {0};
   vo_prof_slot prof[VO_K_COUNT];
   std::vector<hipEvent_t> ev_free;
   typedef vo_prof_pair pending_ev;

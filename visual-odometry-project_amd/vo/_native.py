@@ -86,6 +86,7 @@ _SIGS = {
     "vo_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
     "vo_dev_download": (_i, [_vp, _vp, _vp, _sz]),
     "vo_prof_enable": (_i, [_vp, _i]),
+    "vo_prof_set_sampling": (_i, [_vp, _i]),
     "vo_prof_disable": (_i, [_vp]),
     "vo_prof_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_int64)]),
     "vo_prof_reset": (_i, [_vp]),
@@ -223,6 +224,9 @@ class Context:
 
     def prof_enable(self, kernel_id=-1):
         self._chk(self._lib.vo_prof_enable(self._h, int(kernel_id)))
+
+    def prof_set_sampling(self, every):
+        self._chk(self._lib.vo_prof_set_sampling(self._h, int(every)))
 
     def prof_disable(self):
         self._chk(self._lib.vo_prof_disable(self._h))
