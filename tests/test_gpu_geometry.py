@@ -92,7 +92,8 @@ def test_pyr_down_bit_exact(ctx, shape):
 
 
 @pytest.mark.parametrize("dx,dy,win,lvl", [(1.3, -0.7, 17, 2), (5.6, 3.2, 17, 2), (-9.5, 6.25, 15, 2),
-                                           (2.0, 1.0, 21, 3), (0.4, 0.2, 9, 0)])
+                                           (2.0, 1.0, 21, 3), (0.4, 0.2, 9, 0), (1.3, -0.7, 15, 2),
+                                           (1.3, -0.7, 21, 2), (-0.37, 0.81, 17, 3)])
 def test_klt_matches_oracle_and_flow(ctx, dx, dy, win, lvl):
     prev, nxt = shift_image(240, 320, 5, dx, dy)
     rng = np.random.default_rng(2)

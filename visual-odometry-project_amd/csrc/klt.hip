@@ -24,9 +24,9 @@ constexpr int MAX_WIN = 31;
 constexpr int W_BITS = 14;
 
 // Every level (level 0 included) is kept with PYR_PAD pixels of reflect-101 border on all
-// sides, so the tracker's blocks -- which reach at most 19 pixels past an edge for windows up
-// to 15 -- are plain in-bounds reads.  prev/next point at the interior origin of each level.
-constexpr int PYR_PAD = 24;
+// sides, so the row tracker's blocks -- which reach at most WIN + 4 pixels past an edge, WIN <= 21
+// -- are plain in-bounds reads.  prev/next point at the interior origin of each level.
+constexpr int PYR_PAD = 32;
 
 struct pyr_t {
   const uint8_t* prev[MAX_LEVELS];
@@ -501,7 +501,8 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
 }
 
 // ---------------------------------------------------------------------------------
-// 15x15 windows: one DPP row of 16 lanes per keypoint, four keypoints per wavefront
+// Windows of 15, 17 and 21: one lane per window row -- 16 lanes (a DPP row, four keypoints per
+// wave) for 15x15, 32 lanes (two keypoints per wave) for the larger ones
 // ---------------------------------------------------------------------------------
 // The kernel above spends most of its issue slots on work that is uniform per keypoint
 // (window position, bilinear weights, the 2x2 solve, the reduction tree), replicated over the
@@ -517,8 +518,16 @@ typedef short v2i16 __attribute__((ext_vector_type(2)));
 typedef unsigned u32_any __attribute__((aligned(1)));
 typedef unsigned short u16_any __attribute__((aligned(1)));
 
-constexpr int K16_PITCH = 24;                   // LDS bytes per staged row
-constexpr int K16_SLICE = K16_PITCH * 24;       // LDS bytes per keypoint (24 rows)
+// geometry of the row kernel for a WIN x WIN window
+template <int WIN>
+struct klt_rows {
+  static constexpr int n1 = WIN + 1, n3 = WIN + 3;          // derivative rows / rows of the template block
+  static constexpr int RS = n1 + 2 * KLT_MARGIN;            // side of the staged search region
+  static constexpr int PITCH = (RS + 7) & ~7;               // LDS bytes per staged row
+  static constexpr int SLICE = PITCH * RS;                  // LDS bytes per keypoint
+  static constexpr int WA = (n3 + 3) / 4, WB = (n1 + 3) / 4;   // words per template-block row / search row
+  static_assert(WIN + 5 <= PYR_PAD, "the staged blocks must stay inside the pyramid's border");
+};
 
 __device__ __forceinline__ int row_sum_i32(int v) {   // sum over the 16 lanes of a row, in all of them
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
@@ -527,10 +536,22 @@ __device__ __forceinline__ int row_sum_i32(int v) {   // sum over the 16 lanes o
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
   return v;
 }
+// sum over the LPK (16 or 32) lanes of a keypoint, in all of them
+template <int LPK>
+__device__ __forceinline__ int kp_sum_i32(int v) {
+  v = row_sum_i32(v);
+  if (LPK == 32) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);   // row_bcast15: rows 1, 3 += rows 0, 2
+    const int lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    v = (threadIdx.x & 32) ? hi : lo;
+  }
+  return v;
+}
 // exact sum of per-lane 32-bit partials (two 16-bit limbs), as a double (|sum| < 2^53)
-__device__ __forceinline__ double row_sum_exact(int v) {
-  const int lo = row_sum_i32(v & 0xffff);
-  const int hi = row_sum_i32(v >> 16);
+template <int LPK>
+__device__ __forceinline__ double kp_sum_exact(int v) {
+  const int lo = kp_sum_i32<LPK>(v & 0xffff);
+  const int hi = kp_sum_i32<LPK>(v >> 16);
   return (double)hi * 65536.0 + (double)lo;
 }
 
@@ -548,15 +569,31 @@ __device__ __forceinline__ int sdot2(unsigned a, unsigned b, int c) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2i16, a), __builtin_bit_cast(v2i16, b), c, false);
 }
 
+// NB (16, 18 or 22) bytes from a byte-aligned LDS address into words.  The pieces behind the first
+// 16 bytes are volatile on purpose: left to itself the compiler pairs the tails of two rows into one
+// ds_read2_b32, which ignores the low address bits and returns the wrong bytes for a misaligned base.
+template <int NB>
+__device__ __forceinline__ void load_row_bytes(const uint8_t* p, unsigned* w) {
+  __builtin_memcpy(w, p, 16);
+  if (NB >= 20) {
+    w[4] = *reinterpret_cast<const volatile u32_any*>(p + 16);
+    w[5] = NB >= 22 ? (unsigned)*reinterpret_cast<const volatile u16_any*>(p + 20) : 0u;
+  } else {
+    w[4] = NB >= 18 ? (unsigned)*reinterpret_cast<const volatile u16_any*>(p + 16) : 0u;
+    w[5] = 0u;
+  }
+}
+
 // rows [0, NR) x bytes [0, NC) of the image block whose top-left pixel is (x0, y0) -> s, pitch
-// K16_PITCH.  NC is 18 or 24; lane r takes rows r and r + 16.  The block may hang over the
-// image by up to 19 pixels: the level is stored with PYR_PAD pixels of reflected border.
-template <int NC, int NR>
+// PITCH; lane r takes rows r, r + LPK, ...  The block may hang over the image by up to WIN + 4
+// pixels: the level is stored with PYR_PAD pixels of reflected border.
+template <int NC, int NR, int LPK, int PITCH>
 __device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pitch, int x0, int y0, uint8_t* s, int r) {
-  unsigned v[2][6];
+  constexpr int PASSES = (NR + LPK - 1) / LPK;
+  unsigned v[PASSES][(NC + 3) / 4];
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int row = r + 16 * pass;
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int row = r + LPK * pass;
     const bool on = row < NR;
     const uint8_t* src = img + (ptrdiff_t)(y0 + (on ? row : 0)) * pitch + x0;
 #pragma unroll
@@ -564,28 +601,33 @@ __device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pit
     if (NC & 2) v[pass][NC / 4] = *(const u16_any*)(src + (NC & ~3));
   }
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int row = r + 16 * pass;
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int row = r + LPK * pass;
     if (row < NR) {
-      unsigned* d = reinterpret_cast<unsigned*>(s + row * K16_PITCH);
+      unsigned* d = reinterpret_cast<unsigned*>(s + row * PITCH);
 #pragma unroll
       for (int k = 0; k < (NC + 3) / 4; ++k) d[k] = v[pass][k];
     }
   }
 }
 
+template <int WIN, int LPK>
 __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, int max_iter,
                                                          double eps2, float min_eig_thr, float* __restrict__ next_xy,
                                                          uint8_t* __restrict__ status, float* __restrict__ err) {
-  __shared__ __align__(16) uint8_t smem[4 * K16_SLICE];
-  constexpr int win = 15, ww = 225, RS = 24;
+  typedef klt_rows<WIN> G;
+  constexpr int win = WIN, ww = WIN * WIN, RS = G::RS, n1 = G::n1, n3 = G::n3, K16_PITCH = G::PITCH;
+  constexpr int KPW = 64 / LPK;                        // keypoints per wave
+  static_assert(n1 <= LPK, "one lane per derivative row");
+  __shared__ __align__(16) uint8_t smem[KPW * G::SLICE + 16];
   const int lane = threadIdx.x;
-  const int i = blockIdx.x * 4 + (lane >> 4);
-  if (i >= N) return;                                  // a whole row of lanes leaves together
-  const int r = lane & 15;                             // window row of this lane (row 15 only feeds row 14's derivatives)
-  uint8_t* s_reg = smem + (lane >> 4) * K16_SLICE;
+  const int i = blockIdx.x * KPW + lane / LPK;
+  if (i >= N) return;                                  // all lanes of a keypoint leave together
+  const int r = lane & (LPK - 1);                      // window row of this lane (row WIN only feeds row WIN-1's derivatives)
+  uint8_t* s_reg = smem + (lane / LPK) * G::SLICE;
   const int live = r < win ? 1 : 0;
   const int rr = r < win ? r : win - 1;                // row whose pixels this lane reads in the search loop
+  const int rd = r < n1 ? r : n1 - 1;                  // derivative row of this lane (lanes past it idle along)
 
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -622,37 +664,38 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
     }
     int w00, w01, w10, w11;
     bilinear_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
-    unsigned wa = (unsigned)w00 | ((unsigned)w01 << 16), wb = (unsigned)w10 | ((unsigned)w11 << 16);
+    // (w11 = 2^14 - w00 - w01 - w10 can come out as -1: the packed weights are signed 16-bit halves)
+    unsigned wa = ((unsigned)w00 & 0xffffu) | ((unsigned)w01 << 16), wb = ((unsigned)w10 & 0xffffu) | ((unsigned)w11 << 16);
 
     // ---- template: image block, Scharr derivatives, interpolated patch (all in registers) ----
     wave_sync();
-    stage16<18, 18>(I, pitch, ipx - 1, ipy - 1, s_reg, r);
+    stage16<n3, n3, LPK, K16_PITCH>(I, pitch, ipx - 1, ipy - 1, s_reg, r);
     wave_sync();
     int tI[win], tX[win], tY[win];
     int a11 = 0, a12 = 0, a22 = 0;   // per-lane partial sums stay below 2^31
     {
-      unsigned A0[5], A1[5], A2[5];   // block rows r, r+1, r+2 (18 bytes each): the rows around derivative row r
+      unsigned A0[G::WA], A1[G::WA], A2[G::WA];   // block rows r, r+1, r+2 (n3 bytes each): the rows around derivative row r
       {
-        const unsigned* q0 = reinterpret_cast<const unsigned*>(s_reg + r * K16_PITCH);
+        const unsigned* q0 = reinterpret_cast<const unsigned*>(s_reg + rd * K16_PITCH);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < G::WA; ++k) {
           A0[k] = q0[k];
           A1[k] = q0[k + K16_PITCH / 4];
           A2[k] = q0[k + 2 * (K16_PITCH / 4)];
         }
       }
-      int cs[18], cd[18];             // per column: 3 (a0 + a2) + 10 a1, a2 - a0
+      int cs[n3], cd[n3];             // per column: 3 (a0 + a2) + 10 a1, a2 - a0
 #pragma unroll
-      for (int c = 0; c < 18; ++c) {
+      for (int c = 0; c < n3; ++c) {
         const int b0 = byte_at(A0, c), b1 = byte_at(A1, c), b2 = byte_at(A2, c);
         cs[c] = (b0 + b2) * 3 + b1 * 10;
         cd[c] = b2 - b0;
       }
-      const int gy = ipy + r;
+      const int gy = ipy + rd;
       const bool row_in = gy >= 0 && gy < H;
-      unsigned der[16], dern[16];     // (dx & 0xffff) | dy << 16 of derivative rows r and r + 1
+      unsigned der[n1], dern[n1];     // (dx & 0xffff) | dy << 16 of derivative rows r and r + 1
 #pragma unroll
-      for (int x = 0; x < 16; ++x) {
+      for (int x = 0; x < n1; ++x) {
         const int gx = ipx + x;
         int dx = cs[x + 2] - cs[x];
         int dy = (cd[x + 2] + cd[x]) * 3 + cd[x + 1] * 10;
@@ -663,11 +706,12 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
         der[x] = ((unsigned)dx & 0xffffu) | ((unsigned)dy << 16);
       }
 #pragma unroll
-      for (int x = 0; x < 16; ++x)
-        dern[x] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)der[x], 0x101, 0xF, 0xF, true);   // row_shl:1: lane r reads r + 1
+      for (int x = 0; x < n1; ++x)   // lane r reads lane r + 1: row_shl:1 inside a DPP row, wave_shl:1 across the two rows of a keypoint
+        dern[x] = LPK == 16 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)der[x], 0x101, 0xF, 0xF, true)
+                            : (unsigned)__builtin_amdgcn_update_dpp(0, (int)der[x], 0x130, 0xF, 0xF, true);
 #pragma unroll
       for (int x = 0; x < win; ++x) {
-        const int ival = udot2(pair_at(A1, x + 1), wa, udot2(pair_at(A2, x + 1), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        const int ival = sdot2(pair_at(A1, x + 1), wa, sdot2(pair_at(A2, x + 1), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
         const unsigned dxa = __builtin_amdgcn_perm(der[x + 1], der[x], 0x05040100u);
         const unsigned dya = __builtin_amdgcn_perm(der[x + 1], der[x], 0x07060302u);
         const unsigned dxb = __builtin_amdgcn_perm(dern[x + 1], dern[x], 0x05040100u);
@@ -682,9 +726,9 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
         a22 += iy * iy;
       }
     }
-    const float A11 = (float)row_sum_exact(a11) * FLT_SCALE;
-    const float A12 = (float)row_sum_exact(a12) * FLT_SCALE;
-    const float A22 = (float)row_sum_exact(a22) * FLT_SCALE;
+    const float A11 = (float)kp_sum_exact<LPK>(a11) * FLT_SCALE;
+    const float A12 = (float)kp_sum_exact<LPK>(a12) * FLT_SCALE;
+    const float A22 = (float)kp_sum_exact<LPK>(a22) * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * ww);
     if (minEig < min_eig_thr || D < 1.1920929e-07f) {
@@ -706,30 +750,30 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
         break;
       }
       bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
-      wa = (unsigned)w00 | ((unsigned)w01 << 16);
-      wb = (unsigned)w10 | ((unsigned)w11 << 16);
-      if (!staged || iqx < rx0 || iqy < ry0 || iqx + 16 > rx0 + RS || iqy + 16 > ry0 + RS) {
+      wa = ((unsigned)w00 & 0xffffu) | ((unsigned)w01 << 16);
+      wb = ((unsigned)w10 & 0xffffu) | ((unsigned)w11 << 16);
+      if (!staged || iqx < rx0 || iqy < ry0 || iqx + n1 > rx0 + RS || iqy + n1 > ry0 + RS) {
         rx0 = iqx - KLT_MARGIN;
         ry0 = iqy - KLT_MARGIN;
         wave_sync();
-        stage16<24, 24>(J, pitch, rx0, ry0, s_reg, r);
+        stage16<RS, RS, LPK, K16_PITCH>(J, pitch, rx0, ry0, s_reg, r);
         wave_sync();
         staged = true;
       }
       const uint8_t* base = s_reg + (iqy - ry0 + rr) * K16_PITCH + (iqx - rx0);
-      unsigned B0[4], B1[4];
-      __builtin_memcpy(B0, base, 16);
-      __builtin_memcpy(B1, base + K16_PITCH, 16);
+      unsigned B0[6], B1[6];
+      load_row_bytes<n1>(base, B0);
+      load_row_bytes<n1>(base + K16_PITCH, B1);
       int b1 = 0, b2 = 0;
 #pragma unroll
       for (int x = 0; x < win; ++x) {
-        const int jv = udot2(pair_at(B0, x), wa, udot2(pair_at(B1, x), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        const int jv = sdot2(pair_at(B0, x), wa, sdot2(pair_at(B1, x), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
         const int diff = jv - tI[x];
         b1 += diff * tX[x];
         b2 += diff * tY[x];
       }
-      const float fb1 = (float)row_sum_exact(b1) * FLT_SCALE;
-      const float fb2 = (float)row_sum_exact(b2) * FLT_SCALE;
+      const float fb1 = (float)kp_sum_exact<LPK>(b1) * FLT_SCALE;
+      const float fb2 = (float)kp_sum_exact<LPK>(b2) * FLT_SCALE;
       const float ddx = (A12 * fb2 - A22 * fb1) * D;
       const float ddy = (A12 * fb1 - A11 * fb2) * D;
       qx += ddx;
@@ -753,28 +797,28 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
         continue;
       }
       bilinear_weights(ex - (float)iex, ey - (float)iey, w00, w01, w10, w11);
-      wa = (unsigned)w00 | ((unsigned)w01 << 16);
-      wb = (unsigned)w10 | ((unsigned)w11 << 16);
-      if (!staged || iex < rx0 || iey < ry0 || iex + 16 > rx0 + RS || iey + 16 > ry0 + RS) {
+      wa = ((unsigned)w00 & 0xffffu) | ((unsigned)w01 << 16);
+      wb = ((unsigned)w10 & 0xffffu) | ((unsigned)w11 << 16);
+      if (!staged || iex < rx0 || iey < ry0 || iex + n1 > rx0 + RS || iey + n1 > ry0 + RS) {
         rx0 = iex - KLT_MARGIN;
         ry0 = iey - KLT_MARGIN;
         wave_sync();
-        stage16<24, 24>(J, pitch, rx0, ry0, s_reg, r);
+        stage16<RS, RS, LPK, K16_PITCH>(J, pitch, rx0, ry0, s_reg, r);
         wave_sync();
         staged = true;
       }
       const uint8_t* base = s_reg + (iey - ry0 + rr) * K16_PITCH + (iex - rx0);
-      unsigned B0[4], B1[4];
-      __builtin_memcpy(B0, base, 16);
-      __builtin_memcpy(B1, base + K16_PITCH, 16);
+      unsigned B0[6], B1[6];
+      load_row_bytes<n1>(base, B0);
+      load_row_bytes<n1>(base + K16_PITCH, B1);
       int sabs = 0;
 #pragma unroll
       for (int x = 0; x < win; ++x) {
-        const int jv = udot2(pair_at(B0, x), wa, udot2(pair_at(B1, x), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        const int jv = sdot2(pair_at(B0, x), wa, sdot2(pair_at(B1, x), wb, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
         const int diff = jv - tI[x];
         sabs += diff < 0 ? -diff : diff;
       }
-      e_out = (float)row_sum_i32(live * sabs) / (float)(32 * ww);
+      e_out = (float)kp_sum_i32<LPK>(live * sabs) / (float)(32 * ww);
     }
   }
   if (r == 0) {
@@ -915,16 +959,16 @@ int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_p
     const dim3 kgrid(vo_cdiv(N, KLT_WAVES)), kblock(64 * KLT_WAVES);
     switch (win) {
       case 15:
-        hipLaunchKernelGGL(klt_track16_kernel, dim3(vo_cdiv(N, 4)), dim3(64), 0, st, P, d_prev_xy, N, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<15, 16>), dim3(vo_cdiv(N, 4)), dim3(64), 0, st, P, d_prev_xy, N, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
-      case 17:
-        hipLaunchKernelGGL(klt_track_kernel<17>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
-                           me, d_next_xy, d_status, d_err, lds_wave);
+      case 17:   // the reference's default window (klt.py:29)
+        hipLaunchKernelGGL((klt_track16_kernel<17, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, max_iter,
+                           eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 21:
-        hipLaunchKernelGGL(klt_track_kernel<21>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
-                           me, d_next_xy, d_status, d_err, lds_wave);
+        hipLaunchKernelGGL((klt_track16_kernel<21, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, max_iter,
+                           eps * eps, me, d_next_xy, d_status, d_err);
         break;
       default:
         hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
