@@ -85,6 +85,7 @@ enum {
   VO_K_SIFT_SCALESPACE = 18,
   VO_K_SIFT_DETECT = 19,
   VO_K_SIFT_DESCRIBE = 20,
+  VO_K_REFINE = 21,
   VO_K_COUNT = 32
 };
 int vo_prof_enable(vo_ctx* ctx, int kernel_id);
@@ -183,6 +184,22 @@ int vo_reproj_inliers(vo_ctx* ctx, const double* X, const double* x, int N, cons
 int vo_reproj_inliers_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N,
                           const double* K, const double* d_Rt, double thr_sq,
                           uint8_t* d_mask, double* d_err);
+
+/* ---- pose refinement --------------------------------------------------------------
+ * [ref: src/vo/pose_estimation/p3p.py:188-213 _nonlinear_refinement; helpers.py:86-142]
+ * Minimises sum_i |x_i - proj(K, R X_i + t)|^2 over the pose, from (R0, t0), over the points
+ * whose mask byte is non-zero (all points if the mask is NULL) -- the objective the reference
+ * hands to scipy.optimize.least_squares.  Gauss-Newton on the left-multiplied increment with
+ * the analytic Jacobian, at most max_iter (<= 100) accepted steps, fp64; converges to the
+ * minimiser itself (SciPy's default tolerances stop within ~1e-4 of it).  Outputs R (9,
+ * row-major), t (3), the number of accepted steps and the final cost (sum of squared pixel
+ * errors).  The _dev form takes Rt0 = R0 then t0 (12 doubles) and writes 14 doubles:
+ * R, t, iterations, cost.                                                              */
+int vo_refine_pose(vo_ctx* ctx, const double* X, const double* x, int N, const double* K,
+                   const uint8_t* inlier_mask, const double* R0, const double* t0, int max_iter,
+                   double* R, double* t, int32_t* iterations, double* cost);
+int vo_refine_pose_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const double* K,
+                       const uint8_t* d_mask, const double* d_Rt0, int max_iter, double* d_out14);
 
 /* ---- descriptor matching ---------------------------------------------------------
  * [ref: src/vo/features/harris.py:246-262, src/vo/features/sift.py:38-54]

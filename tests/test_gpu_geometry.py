@@ -133,3 +133,35 @@ def test_klt_edge_cases(ctx):
     go, gs, ge = ctx.klt_track(prev, nxt, far)
     ro, rs, re = native.klt_track(prev, nxt, far)
     assert np.array_equal(gs, rs) and not gs.any() and np.array_equal(go, ro)
+
+
+@pytest.mark.parametrize("n,noise,masked", [(1000, 0.5, False), (2000, 0.5, True), (40, 1.0, False), (5, 0.3, False)])
+def test_refine_pose_matches_oracle(ctx, n, noise, masked):
+    """vo_refine_pose (p3p.py:188-213) against the Gauss-Newton oracle: same algorithm, different
+    summation order and libm -> 1e-9, not bits; and it lands near the pose the data came from."""
+    from oracle import refine_np
+    from test_oracle_refine import K as KR, scene as rscene
+    rng = np.random.default_rng(n)
+    X, x, R, t, R0, t0 = rscene(rng, n, noise)
+    mask = None
+    if masked:
+        mask = rng.uniform(size=n) < 0.6
+        x = x.copy()
+        x[~mask] += rng.normal(0, 40, ((~mask).sum(), 2))     # gross outliers the mask must keep out
+    sel = slice(None) if mask is None else mask
+    Ro, to, ito, costo = refine_np.refine_pose(X[sel], x[sel], KR, R0, t0)
+    Rg, tg, itg, costg = ctx.refine_pose(X, x, KR, R0, t0, inlier_mask=mask)
+    if n >= 40:
+        assert abs(itg - ito) <= 1        # the last step sits at the rounding floor: it may or may not count
+    tol = 1e-9 if n >= 40 else 1e-6       # five points leave the pose barely determined
+    assert np.abs(Rg - Ro).max() < tol and np.abs(tg - to).max() < tol
+    assert abs(costg - costo) <= tol * max(costo, 1.0)
+    if n >= 40:
+        assert np.abs(Rg - R).max() < 5e-3 and np.abs(tg - t).max() < 0.1
+
+
+def test_refine_pose_degenerate(ctx):
+    from test_oracle_refine import K as KR
+    R0, t0 = np.eye(3), np.array([0.1, 0.2, 0.3])
+    Rg, tg, it, cost = ctx.refine_pose(np.zeros((0, 3)), np.zeros((0, 2)), KR, R0, t0)
+    assert it == 0 and np.array_equal(Rg, R0) and np.array_equal(tg, t0)

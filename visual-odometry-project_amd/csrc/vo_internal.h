@@ -114,3 +114,7 @@ void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
 // DLT with a device-resident point count (dlt.hip)
 int vo_triangulate_dlt_ndev(vo_ctx* ctx, const double* d_x1, const double* d_x2, const int32_t* d_n, int n_cap,
                             const double* d_C1, const double* d_C2, double* d_X);
+// pose refinement with a device-resident point count and either kind of inlier mask (refine.hip)
+int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const int32_t* d_n, const double* K,
+                        const uint8_t* d_mask8, const uint64_t* d_mask_bits, const double* d_Rt0, int max_iter,
+                        double* d_out14);

@@ -110,6 +110,8 @@ _SIGS = {
     "vo_p3p_hypotheses_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "vo_reproj_inliers": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp]),
     "vo_reproj_inliers_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _d, _vp, _vp]),
+    "vo_refine_pose": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, C.POINTER(C.c_int32), C.POINTER(_d)]),
+    "vo_refine_pose_dev": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "vo_match_knn2_ratio": (_i, [_vp, _vp, _i, _vp, _i, _i, _d, _vp, _vp]),
     "vo_knn2_dev": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "vo_good_features": (_i, [_vp, _vp, _i, _i, _vp, _i, _d, _d, _i, _vp, _vp]),
@@ -380,6 +382,21 @@ class Context:
             bits = np.unpackbits(masks.view(np.uint8).reshape(h, words * 8), axis=1, bitorder="little")[:, :n]
             return R, t, valid, counts, bits.astype(bool)
         return R, t, valid, counts
+
+    def refine_pose(self, X, x, K, R0, t0, inlier_mask=None, max_iter=20):
+        """Least-squares pose from (R0, t0) over the (masked) correspondences: (R, t (3,), iterations, cost)
+        -- the minimiser p3p.py:188-213 asks SciPy for (vo_refine_pose)."""
+        X = _c(np.asarray(X).reshape(-1, 3), np.float64)
+        x = _c(np.asarray(x).reshape(-1, 2), np.float64)
+        K = _c(K, np.float64)
+        R0 = _c(np.asarray(R0).reshape(3, 3), np.float64)
+        t0 = _c(np.asarray(t0).reshape(3), np.float64)
+        m = None if inlier_mask is None else _c(np.asarray(inlier_mask).reshape(-1), np.uint8)
+        R, t = np.empty((3, 3)), np.empty(3)
+        it, cost = C.c_int32(), C.c_double()
+        self._chk(self._lib.vo_refine_pose(self._h, _ptr(X), _ptr(x), len(X), _ptr(K), _ptr(m), _ptr(R0), _ptr(t0),
+                                           int(max_iter), _ptr(R), _ptr(t), C.byref(it), C.byref(cost)))
+        return R, t, it.value, cost.value
 
     def reproj_inliers(self, X, x, K, R, t, thr_sq, want_err=False):
         X = _c(np.asarray(X).reshape(-1, 3), np.float64)
