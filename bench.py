@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 
 H, W, N_KP, HYP, WIN, MAX_LEVEL = 1241, 1376, 2000, 1000, 15, 2
 N_FRAMES = 8
+REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
 PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -130,7 +131,8 @@ def main():
     ctx = _native.Context(local, stream=comp.cuda_stream)
     stream = synthetic.Stream(N_FRAMES, H, W, seed=2023 + rank)
     pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
-                            hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000)
+                            hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
+                            refine_iters=REFINE_ITERS)
     for i in range(N_FRAMES):
         pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
 
@@ -143,7 +145,8 @@ def main():
     order = stream.order(args.warmup + args.steps + 64)
     pipe.prime(order[0])
     pos = 0
-    stats = {"tracked": [], "inliers": [], "rot_err": [], "trans_err": [], "iters": [], "tri_err": []}
+    stats = {"tracked": [], "inliers": [], "rot_err": [], "trans_err": [], "iters": [], "tri_err": [],
+             "rot_err_ref": [], "trans_err_ref": [], "ref_iters": []}
 
     def run(n, record=False):
         # Default: one frame of look-ahead, as a camera stream gives it -- frame k+1 is submitted (all of
@@ -178,6 +181,10 @@ def main():
             if record:
                 Tcw = np.linalg.inv(stream.T_world_cam(b))
                 R, t = np.array(r.R).reshape(3, 3), np.array(r.t)
+                Rr, tr = np.array(r.R_refined).reshape(3, 3), np.array(r.t_refined)
+                stats["rot_err_ref"].append(float(np.linalg.norm(Rr - Tcw[:3, :3])))
+                stats["trans_err_ref"].append(float(np.linalg.norm(tr - Tcw[:3, 3])))
+                stats["ref_iters"].append(r.refine_iterations)
                 stats["tracked"].append(r.n_tracked)
                 stats["inliers"].append(r.n_inliers)
                 stats["iters"].append(r.ransac_iterations)
@@ -266,7 +273,12 @@ def main():
             "pose_err": {"rot_fro_median": float(np.median(stats["rot_err"])), "trans_m_median": float(np.median(stats["trans_err"])),
                          "tracked_median": float(np.median(stats["tracked"])), "inliers_median": float(np.median(stats["inliers"])),
                          "ransac_iters_median": float(np.median(stats["iters"])),
-                         "note": "vs analytic ground truth of the synthetic stream; best RANSAC hypothesis, no refinement"},
+                         "refined_rot_fro_median": float(np.median(stats["rot_err_ref"])),
+                         "refined_trans_m_median": float(np.median(stats["trans_err_ref"])),
+                         "refine_steps_median": float(np.median(stats["ref_iters"])),
+                         "note": "vs analytic ground truth of the synthetic stream; rot/trans: best RANSAC hypothesis, "
+                                 "refined_*: after the Gauss-Newton refinement over its inliers (inside the timed step "
+                                 "when refine_steps >= 0)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(stream)

@@ -278,6 +278,8 @@ typedef struct vo_pipeline_config {
   double p3p_thr_sq, ransac_outlier_ratio, ransac_confidence;
   int64_t ransac_max_iterations;
   double K[9];
+  int32_t refine_iters;         /* > 0: refine the accepted pose over its inliers (vo_refine_pose) */
+  int32_t pad;
 } vo_pipeline_config;
 typedef struct vo_step_result {
   double R[9], t[3];            /* world -> camera pose of `next` (best hypothesis)   */
@@ -287,7 +289,9 @@ typedef struct vo_step_result {
   int32_t hyp_valid;            /* hypotheses with a P3P solution among those scored  */
   int64_t ransac_iterations;    /* iterations the reference loop would have counted   */
   int32_t draws_consumed;       /* samples consumed from the generator                */
-  int32_t pad;
+  int32_t refine_iterations;    /* accepted refinement steps; -1: not refined         */
+  double R_refined[9], t_refined[3];   /* refined pose (= R, t when not refined)      */
+  double refine_cost;           /* sum of squared inlier reprojection errors after it */
 } vo_step_result;
 int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out);
 void vo_pipeline_destroy(vo_pipeline* p);

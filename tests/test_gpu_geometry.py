@@ -138,7 +138,7 @@ def test_klt_edge_cases(ctx):
 @pytest.mark.parametrize("n,noise,masked", [(1000, 0.5, False), (2000, 0.5, True), (40, 1.0, False), (5, 0.3, False)])
 def test_refine_pose_matches_oracle(ctx, n, noise, masked):
     """vo_refine_pose (p3p.py:188-213) against the Gauss-Newton oracle: same algorithm, different
-    summation order and libm -> 1e-9, not bits; and it lands near the pose the data came from."""
+    summation order and libm -> 1e-8, not bits; and it lands near the pose the data came from."""
     from oracle import refine_np
     from test_oracle_refine import K as KR, scene as rscene
     rng = np.random.default_rng(n)
@@ -153,7 +153,7 @@ def test_refine_pose_matches_oracle(ctx, n, noise, masked):
     Rg, tg, itg, costg = ctx.refine_pose(X, x, KR, R0, t0, inlier_mask=mask)
     if n >= 40:
         assert abs(itg - ito) <= 1        # the last step sits at the rounding floor: it may or may not count
-    tol = 1e-9 if n >= 40 else 1e-6       # five points leave the pose barely determined
+    tol = 1e-8 if n >= 40 else 1e-6       # five points leave the pose barely determined
     assert np.abs(Rg - Ro).max() < tol and np.abs(tg - to).max() < tol
     assert abs(costg - costo) <= tol * max(costo, 1.0)
     if n >= 40:

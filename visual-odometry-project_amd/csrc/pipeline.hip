@@ -94,6 +94,9 @@ struct vo_pipeline {
                                               // [8+2s], [9+2s]: {tag, offset} of the slot's outputs in h_raw
   unsigned seq = 0;
   double* h_C = nullptr;             // 2 x 24 (C1, C2), alternating with the track sets
+  double* h_ref = nullptr;           // 2 x 32: [0..11] pose handed to the refinement, [16..30] its 14 outputs + tag
+  double* m_ref = nullptr;
+  unsigned ref_seq = 0;
   // device aliases of the mapped host buffers
   int32_t *m_ntracked = nullptr, *m_samples = nullptr, *m_counts = nullptr;
   uint32_t* m_raw = nullptr;
@@ -376,6 +379,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     p->h_seq = q;
   }
   PA(pin_alloc(ctx, &p->h_C, 48));
+  PA(pin_alloc(ctx, &p->h_ref, 64));
 #define MAP(dst, src) do { if (rc == VO_OK && hipHostGetDevicePointer((void**)&(dst), (void*)(src), 0) != hipSuccess) \
     rc = vo_set_error(ctx, VO_EHIP, "hipHostGetDevicePointer failed"); } while (0)
   MAP(p->m_ntracked, p->h_ntracked);
@@ -387,6 +391,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   MAP(p->m_R, p->h_R);
   MAP(p->m_t, p->h_t);
   MAP(p->m_C, p->h_C);
+  MAP(p->m_ref, p->h_ref);
 #undef MAP
 #undef PA
   if (rc == VO_OK && (hipEventCreateWithFlags(&p->evA, hipEventDisableTiming) != hipSuccess ||
@@ -437,7 +442,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
                  p->d_ntracked, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks};
   for (void* q : dev)
     if (q) (void)hipFree(q);
-  void* pin[] = {p->h_ntracked, p->h_samples, p->h_raw, p->h_valid, p->h_counts, p->h_pose, p->h_C, p->h_R, p->h_t, (void*)p->h_seq};
+  void* pin[] = {p->h_ntracked, p->h_samples, p->h_raw, p->h_valid, p->h_counts, p->h_pose, p->h_C, p->h_ref, p->h_R, p->h_t, (void*)p->h_seq};
   for (void* q : pin)
     if (q) (void)hipHostFree(q);
   if (p->evA) (void)hipEventDestroy(p->evA);
@@ -718,6 +723,7 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
   static const bool dbg = getenv("VO_DEBUG_TIMING") != nullptr;
   memset(out, 0, sizeof(*out));
   out->best_index = -1;
+  out->refine_iterations = -1;
   VO_TRY(flush_dlt(p));                                // (of the step collected before this one)
   const double t_wait = dbg ? now_us() : 0;
 
@@ -804,6 +810,36 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
     // was accepted at once (no flag) and only the device-side batch was used
     if (!redo && batches == 1 && f.raw_published) p->raw_pos += (size_t)7 * total_consumed;
     else raw_ok = false;
+    // ---- refinement of the accepted pose over its inliers (p3p.py:188-213), on the spare stream ----
+    memcpy(out->R_refined, out->R, 72);
+    memcpy(out->t_refined, out->t, 24);
+    out->refine_iterations = -1;
+    if (c.refine_iters > 0 && best_idx >= 0 && p->last_best >= 0) {
+      double* h = p->h_ref + 32 * cs;
+      memcpy(h, out->R, 72);
+      memcpy(h + 9, out->t, 24);
+      const unsigned tag = ++p->ref_seq;
+      ((volatile double*)h)[30] = 0.0;
+      p->redo->prof_on = ctx->prof_on;
+      p->redo->prof_kernel = ctx->prof_kernel;
+      p->redo->prof_every = ctx->prof_every;
+      const int rc = vo_refine_pose_ndev(p->redo, p->d_land_c[cs], p->d_next_c[cs], N, sl_nt(p, cs), c.K, nullptr,
+                                         sl_masks(p, cs) + (size_t)p->last_best * p->last_words, p->m_ref + 32 * cs,
+                                         c.refine_iters, p->m_ref + 32 * cs + 16, tag);
+      if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->redo));
+      long spins = 0;
+      while (((volatile double*)h)[30] != (double)tag) {
+        __builtin_ia32_pause();
+        if (++spins > 400000000L) {
+          VO_HIP_TRY(ctx, hipStreamSynchronize(p->redo->stream));
+          break;
+        }
+      }
+      memcpy(out->R_refined, h + 16, 72);
+      memcpy(out->t_refined, h + 25, 24);
+      out->refine_iterations = (int32_t)h[28];
+      out->refine_cost = h[29];
+    }
     out->n_inliers = best_count > 0 ? best_count : 0;
     out->best_index = best_idx;
     out->ransac_iterations = n_done;
@@ -817,10 +853,10 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
       rigid_inverse(&p->T_wc[(size_t)f.prev_idx * 16], Tcw);
       k_times_rt(c.K, Tcw, hC);
       for (int r = 0; r < 3; ++r) {
-        Rt[4 * r] = out->R[3 * r];
-        Rt[4 * r + 1] = out->R[3 * r + 1];
-        Rt[4 * r + 2] = out->R[3 * r + 2];
-        Rt[4 * r + 3] = out->t[r];
+        Rt[4 * r] = out->R_refined[3 * r];         // (= R, t when the refinement is off)
+        Rt[4 * r + 1] = out->R_refined[3 * r + 1];
+        Rt[4 * r + 2] = out->R_refined[3 * r + 2];
+        Rt[4 * r + 3] = out->t_refined[r];
       }
       k_times_rt(c.K, Rt, hC + 12);
       p->dlt_unflushed = true;
@@ -888,8 +924,12 @@ int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64
   int64_t nc = 0;
   rc = vo_prof_read(p->tri, kernel_id, &c, &nc);
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->tri));
-  if (total_ms) *total_ms = a + b + c;
-  if (launches) *launches = na + nb + nc;
+  double d = 0;
+  int64_t nd = 0;
+  rc = vo_prof_read(p->redo, kernel_id, &d, &nd);
+  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->redo));
+  if (total_ms) *total_ms = a + b + c + d;
+  if (launches) *launches = na + nb + nc + nd;
   return VO_OK;
 }
 
@@ -898,6 +938,7 @@ int vo_pipeline_prof_reset(vo_pipeline* p) {
   VO_TRY(worker_idle(p));
   VO_TRY(vo_prof_reset(p->ctx));
   VO_TRY(vo_prof_reset(p->tri));
+  VO_TRY(vo_prof_reset(p->redo));
   return vo_prof_reset(p->det);
 }
 

@@ -8,8 +8,9 @@
 // T <- [Exp(w) | v] T  (restated in oracle/refine_np.py) and converges to the minimiser itself
 // in 3-4 iterations; SciPy stops within ~1e-4 of it (tests/test_oracle_refine.py).
 //
-// One workgroup: every thread accumulates the 21 + 6 + 1 sums of its points, the wave sums go
-// through DPP, the four wave results through LDS, lane 0 solves the 6x6 system (Cholesky) and
+// One workgroup of 512 threads: every thread keeps its (up to four) points in registers and
+// accumulates their 21 + 6 + 1 terms once per iteration, the partial sums
+// are added by wave shuffles and then through LDS, lane 0 solves the 6x6 system (Cholesky) and
 // applies the update; all fp64.
 #include "vo_internal.h"
 
@@ -17,8 +18,9 @@
 
 namespace {
 
-constexpr int RF_T = 256;
+constexpr int RF_T = 512;
 constexpr int RF_S = 28;   // 21 (upper triangle of J^T J) + 6 (J^T e) + 1 (cost)
+constexpr int RF_PT = 4;   // points per thread kept in registers (N <= 2048; beyond that they are re-read)
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -26,47 +28,87 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
-// sums for the pose (R, t) over the points this thread owns
-__device__ __forceinline__ void accumulate(const double* __restrict__ X, const double* __restrict__ x, int N,
-                                           const uint8_t* __restrict__ mask8,
+struct rf_point {
+  double X, Y, Z, u, v;
+  bool on;
+};
+
+__device__ __forceinline__ rf_point load_point(const double* __restrict__ X, const double* __restrict__ x, int N,
+                                               const uint8_t* __restrict__ mask8,
+                                               const unsigned long long* __restrict__ mask_bits, int i) {
+  rf_point p;
+  const bool in = i < N;
+  const int j = in ? i : 0;
+  p.X = X[3 * j];
+  p.Y = X[3 * j + 1];
+  p.Z = X[3 * j + 2];
+  p.u = x[2 * j];
+  p.v = x[2 * j + 1];
+  bool on = in;
+  if (mask8) on = on && mask8[j] != 0;
+  if (mask_bits) on = on && ((mask_bits[j >> 6] >> (j & 63)) & 1ull) != 0;
+  p.on = on;
+  return p;
+}
+
+// adds one point's terms for the pose (R, t) to s[]
+__device__ __forceinline__ void add_point(const rf_point& p, const double* R, const double* t, double fx, double fy,
+                                          double cx, double cy, double* s) {
+  if (!p.on) return;
+  const double px = R[0] * p.X + R[1] * p.Y + R[2] * p.Z + t[0];
+  const double py = R[3] * p.X + R[4] * p.Y + R[5] * p.Z + t[1];
+  const double pz = R[6] * p.X + R[7] * p.Y + R[8] * p.Z + t[2];
+  const double iz = 1.0 / pz;
+  const double eu = p.u - (fx * px * iz + cx);
+  const double ev = p.v - (fy * py * iz + cy);
+  // rows of J = d proj / d (v, w):  d proj / d p = [[a, 0, c], [0, b, d]] with a = fx iz, c = -fx px iz^2,
+  // b = fy iz, d = -fy py iz^2;  d p / d v = I, d p / d w = -[p]_x.  The two structural zeros are
+  // written out (J0 = [a, 0, c, c py, a pz - c px, -a py], J1 = [0, b, d, d py - b pz, -d px, b px]):
+  // their products add exact zeros, so dropping them changes no bit and saves a quarter of the flops.
+  const double a = fx * iz, c = -fx * px * iz * iz;
+  const double b = fy * iz, d = -fy * py * iz * iz;
+  const double j03 = c * py, j04 = a * pz - c * px, j05 = -a * py;
+  const double j13 = -b * pz + d * py, j14 = -d * px, j15 = b * px;
+  s[0] += a * a;                       // (0,0)
+  s[2] += a * c;                       // (0,2)   [(0,1) stays 0]
+  s[3] += a * j03;
+  s[4] += a * j04;
+  s[5] += a * j05;
+  s[6] += b * b;                       // (1,1)
+  s[7] += b * d;
+  s[8] += b * j13;
+  s[9] += b * j14;
+  s[10] += b * j15;
+  s[11] += c * c + d * d;              // (2,2)
+  s[12] += c * j03 + d * j13;
+  s[13] += c * j04 + d * j14;
+  s[14] += c * j05 + d * j15;
+  s[15] += j03 * j03 + j13 * j13;      // (3,3)
+  s[16] += j03 * j04 + j13 * j14;
+  s[17] += j03 * j05 + j13 * j15;
+  s[18] += j04 * j04 + j14 * j14;      // (4,4)
+  s[19] += j04 * j05 + j14 * j15;
+  s[20] += j05 * j05 + j15 * j15;      // (5,5)
+  s[21] += a * eu;
+  s[22] += b * ev;
+  s[23] += c * eu + d * ev;
+  s[24] += j03 * eu + j13 * ev;
+  s[25] += j04 * eu + j14 * ev;
+  s[26] += j05 * eu + j15 * ev;
+  s[27] += eu * eu + ev * ev;
+}
+
+// sums for the pose (R, t): the thread's cached points, plus (N > RF_PT * RF_T) the rest re-read
+__device__ __forceinline__ void accumulate(const rf_point* cache, const double* __restrict__ X,
+                                           const double* __restrict__ x, int N, const uint8_t* __restrict__ mask8,
                                            const unsigned long long* __restrict__ mask_bits, const double* R,
                                            const double* t, double fx, double fy, double cx, double cy, double* s) {
 #pragma unroll
   for (int k = 0; k < RF_S; ++k) s[k] = 0.0;
-  for (int i = threadIdx.x; i < N; i += RF_T) {
-    if (mask8 && !mask8[i]) continue;
-    if (mask_bits && !((mask_bits[i >> 6] >> (i & 63)) & 1ull)) continue;
-    const double Xx = X[3 * i], Xy = X[3 * i + 1], Xz = X[3 * i + 2];
-    const double px = R[0] * Xx + R[1] * Xy + R[2] * Xz + t[0];
-    const double py = R[3] * Xx + R[4] * Xy + R[5] * Xz + t[1];
-    const double pz = R[6] * Xx + R[7] * Xy + R[8] * Xz + t[2];
-    const double iz = 1.0 / pz;
-    const double eu = x[2 * i] - (fx * px * iz + cx);
-    const double ev = x[2 * i + 1] - (fy * py * iz + cy);
-    // rows of J = d proj / d (v, w):  d proj / d p = [[fx iz, 0, -fx px iz^2], [0, fy iz, -fy py iz^2]],
-    // d p / d v = I, d p / d w = -[p]_x
-    double J0[6], J1[6];
-    J0[0] = fx * iz;
-    J0[1] = 0.0;
-    J0[2] = -fx * px * iz * iz;
-    J1[0] = 0.0;
-    J1[1] = fy * iz;
-    J1[2] = -fy * py * iz * iz;
-    J0[3] = -J0[1] * pz + J0[2] * py;
-    J0[4] = J0[0] * pz - J0[2] * px;
-    J0[5] = -J0[0] * py + J0[1] * px;
-    J1[3] = -J1[1] * pz + J1[2] * py;
-    J1[4] = J1[0] * pz - J1[2] * px;
-    J1[5] = -J1[0] * py + J1[1] * px;
-    int q = 0;
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = a; b < 6; ++b) s[q++] += J0[a] * J0[b] + J1[a] * J1[b];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) s[21 + a] += J0[a] * eu + J1[a] * ev;
-    s[27] += eu * eu + ev * ev;
-  }
+  for (int k = 0; k < RF_PT; ++k) add_point(cache[k], R, t, fx, fy, cx, cy, s);
+  for (int i = RF_PT * RF_T + threadIdx.x; i < N; i += RF_T)
+    add_point(load_point(X, x, N, mask8, mask_bits, i), R, t, fx, fy, cx, cy, s);
 }
 
 // block-wide sums of s[] -> s_tot[] (valid in every thread after the call)
@@ -143,7 +185,8 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
                                                            const uint8_t* __restrict__ mask8,
                                                            const unsigned long long* __restrict__ mask_bits,
                                                            const double* __restrict__ Rt0, double fx, double fy, double cx,
-                                                           double cy, int max_iter, double tol, double* __restrict__ out) {
+                                                           double cy, int max_iter, double tol, double* __restrict__ out,
+                                                           unsigned tag) {
   __shared__ double s_w[RF_T / 64][RF_S];
   __shared__ double s_tot[RF_S], s_new[RF_S];
   __shared__ double s_pose[12], s_try[12];
@@ -151,9 +194,13 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
   if (d_n) N = min(N, *d_n);
   if (threadIdx.x < 12) s_pose[threadIdx.x] = Rt0[threadIdx.x];
   __syncthreads();
+  // the thread's points stay in registers for every iteration (all loads go out together, once)
+  rf_point cache[RF_PT];
+#pragma unroll
+  for (int k = 0; k < RF_PT; ++k) cache[k] = load_point(X, x, N, mask8, mask_bits, k * RF_T + threadIdx.x);
   double s[RF_S];
   int it = 0;
-  accumulate(X, x, N, mask8, mask_bits, s_pose, s_pose + 9, fx, fy, cx, cy, s);
+  accumulate(cache, X, x, N, mask8, mask_bits, s_pose, s_pose + 9, fx, fy, cx, cy, s);
   block_sums(s, s_w, s_tot);
   double cost = s_tot[27];
   while (it < max_iter) {
@@ -177,7 +224,7 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
     }
     __syncthreads();
     if (s_state == 1) break;
-    accumulate(X, x, N, mask8, mask_bits, s_try, s_try + 9, fx, fy, cx, cy, s);
+    accumulate(cache, X, x, N, mask8, mask_bits, s_try, s_try + 9, fx, fy, cx, cy, s);
     block_sums(s, s_w, s_new);
     const double cost_new = s_new[27];
     if (!(cost_new <= cost)) break;   // no decrease: keep the previous pose (uniform: all threads read the same sums)
@@ -195,14 +242,20 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
     out[12] = (double)it;
     out[13] = cost;
   }
+  if (tag) {   // out is mapped host memory the host polls: the tag goes last
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) out[14] = (double)tag;
+  }
 }
 
 }  // namespace
 
-// count read on the device when d_n != nullptr (pipeline); exactly one of the masks may be given
+// count read on the device when d_n != nullptr (pipeline); at most one of the masks may be given;
+// tag != 0: d_out14 has a 15th slot that receives the tag once the other 14 are visible to the host
 int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const int32_t* d_n, const double* K,
                         const uint8_t* d_mask8, const uint64_t* d_mask_bits, const double* d_Rt0, int max_iter,
-                        double* d_out14) {
+                        double* d_out14, unsigned tag) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, d_X && d_x && K && d_Rt0 && d_out14, "refine_pose: null pointer");
   VO_REQUIRE(ctx, N >= 0 && max_iter >= 0 && max_iter <= 100, "refine_pose: bad arguments");
@@ -212,7 +265,7 @@ int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N
   {
     vo_prof_scope ps(ctx, VO_K_REFINE);
     hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(RF_T), 0, ctx->stream, d_X, d_x, N, d_n, d_mask8,
-                       (const unsigned long long*)d_mask_bits, d_Rt0, K[0], K[4], K[2], K[5], max_iter, 1e-14, d_out14);
+                       (const unsigned long long*)d_mask_bits, d_Rt0, K[0], K[4], K[2], K[5], max_iter, 1e-11, d_out14, tag);
   }
   return vo_check_launch(ctx, "refine_pose_kernel");
 }
@@ -221,7 +274,7 @@ extern "C" {
 
 int vo_refine_pose_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const double* K, const uint8_t* d_mask,
                        const double* d_Rt0, int max_iter, double* d_out14) {
-  return vo_refine_pose_ndev(ctx, d_X, d_x, N, nullptr, K, d_mask, nullptr, d_Rt0, max_iter, d_out14);
+  return vo_refine_pose_ndev(ctx, d_X, d_x, N, nullptr, K, d_mask, nullptr, d_Rt0, max_iter, d_out14, 0u);
 }
 
 int vo_refine_pose(vo_ctx* ctx, const double* X, const double* x, int N, const double* K, const uint8_t* inlier_mask,

@@ -117,4 +117,4 @@ int vo_triangulate_dlt_ndev(vo_ctx* ctx, const double* d_x1, const double* d_x2,
 // pose refinement with a device-resident point count and either kind of inlier mask (refine.hip)
 int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const int32_t* d_n, const double* K,
                         const uint8_t* d_mask8, const uint64_t* d_mask_bits, const double* d_Rt0, int max_iter,
-                        double* d_out14);
+                        double* d_out14, unsigned tag);

@@ -65,13 +65,14 @@ class PipelineConfig(C.Structure):
                 ("klt_eps", C.c_double), ("klt_min_eig", C.c_double), ("klt_err_threshold", C.c_double),
                 ("p3p_thr_sq", C.c_double), ("ransac_outlier_ratio", C.c_double), ("ransac_confidence", C.c_double),
                 ("ransac_max_iterations", C.c_int64),
-                ("K", C.c_double * 9)]
+                ("K", C.c_double * 9), ("refine_iters", C.c_int32), ("pad", C.c_int32)]
 
 
 class StepResult(C.Structure):
     _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("n_tracked", C.c_int32), ("n_inliers", C.c_int32),
                 ("best_index", C.c_int32), ("hyp_valid", C.c_int32), ("ransac_iterations", C.c_int64),
-                ("draws_consumed", C.c_int32), ("pad", C.c_int32)]
+                ("draws_consumed", C.c_int32), ("refine_iterations", C.c_int32),
+                ("R_refined", C.c_double * 9), ("t_refined", C.c_double * 3), ("refine_cost", C.c_double)]
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 _SIGS = {
@@ -470,7 +471,7 @@ class Pipeline:
     def __init__(self, ctx, H, W, n_frames, K, n_keypoints=2000, harris_patch=9, harris_kappa=0.09, nms_radius=5,
                  klt_win=15, klt_max_level=2, klt_max_iter=10, klt_eps=0.03, klt_min_eig=1e-4,
                  klt_err_threshold=100.0, hyp=1000, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99,
-                 max_iterations=1000, seed=2023):
+                 max_iterations=1000, seed=2023, refine_iters=0):
         self.ctx = ctx
         self.cfg = PipelineConfig()
         c = self.cfg
@@ -481,6 +482,7 @@ class Pipeline:
         c.p3p_thr_sq = p3p_threshold
         c.ransac_outlier_ratio, c.ransac_confidence = outlier_ratio, confidence
         c.ransac_max_iterations = -1 if max_iterations is None or max_iterations == np.inf else int(max_iterations)
+        c.refine_iters = int(refine_iters)
         for i, v in enumerate(np.asarray(K, np.float64).reshape(9)):
             c.K[i] = v
         h = C.c_void_p()
