@@ -50,6 +50,7 @@ def algorithmic_bytes(kernel_name, n_tracked):
         "p3p_solve": HYP * (16 + 4 * 40 + 96 + 1),
         "p3p_score": n_tracked * 40 + HYP * (96 + 1 + 4 + ((n_tracked + 63) // 64) * 8),
         "dlt_triangulate": n_tracked * (16 + 16 + 24) + 192,
+        "refine_pose": n_tracked * 40 + ((n_tracked + 63) // 64) * 8 + 96 + 120,   # points + mask row once, pose in / out
     }
     return table.get(kernel_name)
 
@@ -59,11 +60,11 @@ def pmc_traffic(kernel_name):
     (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this
     same command, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes); None if the
     file or the kernel is missing.  bench.py itself cannot run under the counters."""
-    names = {"klt_track": "klt_track16_kernel", "nms_round": "nms_round_kernel<5, true>",
+    names = {"klt_track": "klt_track16_kernel<15, 16>", "nms_round": "nms_round_kernel<5, true>",
              "nms_candidates": "nms_candidates_kernel<5>", "harris_response": "harris_response_kernel<9>",
              "p3p_solve": "p3p_solve_kernel<true>", "p3p_score": "p3p_score_kernel", "dlt_triangulate": "dlt_kernel",
              "nms_compact": "nms_compact_kernel", "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel",
-             "track_gather": "gather_tracks_kernel"}
+             "track_gather": "gather_tracks_kernel", "refine_pose": "refine_pose_kernel", "pyr_down": "pyramid3_kernel"}
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
             table = json.load(f)

@@ -710,6 +710,19 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   return VO_OK;
 }
 
+// the oldest step in flight has been replayed: drop it, and tell the step submitted after it
+// where its generator outputs start
+static int retire_step(vo_pipeline* p, bool raw_ok) {
+  if (!raw_ok) p->raw_valid = false;
+  p->flight[0] = p->flight[1];
+  --p->n_flight;
+  if (p->n_flight > 0 && !p->flight[0].raw_published) {
+    publish_raws(p, p->flight[0].slot, p->flight[0].seq);
+    p->flight[0].raw_published = true;
+  }
+  return VO_OK;
+}
+
 int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
   if (!p || !out) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
@@ -807,9 +820,11 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
       VO_TRY(vo_rng_choice(&p->rng, n, 4, total_consumed, tmp.data()));
     }
     // the look-ahead moves with the generator: 7 outputs per consumed sample when every draw
-    // was accepted at once (no flag) and only the device-side batch was used
+    // was accepted at once (no flag) and only the device-side batch was used.  The step submitted
+    // after this one is told where its outputs start now, before the refinement is waited for.
     if (!redo && batches == 1 && f.raw_published) p->raw_pos += (size_t)7 * total_consumed;
     else raw_ok = false;
+    VO_TRY(retire_step(p, raw_ok));
     // ---- refinement of the accepted pose over its inliers (p3p.py:188-213), on the spare stream ----
     memcpy(out->R_refined, out->R, 72);
     memcpy(out->t_refined, out->t, 24);
@@ -862,15 +877,7 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
       p->dlt_unflushed = true;
     }
   }
-  if (!raw_ok) p->raw_valid = false;
-
-  // this step is done; the one submitted after it learns where its generator outputs start
-  p->flight[0] = p->flight[1];
-  --p->n_flight;
-  if (p->n_flight > 0 && !p->flight[0].raw_published) {
-    publish_raws(p, p->flight[0].slot, p->flight[0].seq);
-    p->flight[0].raw_published = true;
-  }
+  if (n < 4) VO_TRY(retire_step(p, true));
   if (dbg) {
     const double t_ret = now_us();
     p->dbg_t[1] += t_res - t_wait;
