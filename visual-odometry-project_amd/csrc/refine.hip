@@ -265,7 +265,7 @@ int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N
   {
     vo_prof_scope ps(ctx, VO_K_REFINE);
     hipLaunchKernelGGL(refine_pose_kernel, dim3(1), dim3(RF_T), 0, ctx->stream, d_X, d_x, N, d_n, d_mask8,
-                       (const unsigned long long*)d_mask_bits, d_Rt0, K[0], K[4], K[2], K[5], max_iter, 1e-11, d_out14, tag);
+                       (const unsigned long long*)d_mask_bits, d_Rt0, K[0], K[4], K[2], K[5], max_iter, 1e-9, d_out14, tag);
   }
   return vo_check_launch(ctx, "refine_pose_kernel");
 }
