@@ -9,9 +9,9 @@
 // in 3-4 iterations; SciPy stops within ~1e-4 of it (tests/test_oracle_refine.py).
 //
 // One workgroup of 512 threads: every thread keeps its (up to four) points in registers and
-// accumulates their 21 + 6 + 1 terms once per iteration, the partial sums
-// are added by wave shuffles and then through LDS, lane 0 solves the 6x6 system (Cholesky) and
-// applies the update; all fp64.
+// accumulates their 21 + 6 + 1 terms once per iteration; a wave adds its lanes' terms with a
+// halving butterfly (32 shuffles for all 28 sums), wave 0 adds the eight wave totals, solves the
+// 6x6 system with one lane per row and applies the update; all fp64, two barriers per iteration.
 #include "vo_internal.h"
 
 #pragma clang fp contract(off)
@@ -21,12 +21,6 @@ namespace {
 constexpr int RF_T = 512;
 constexpr int RF_S = 28;   // 21 (upper triangle of J^T J) + 6 (J^T e) + 1 (cost)
 constexpr int RF_PT = 4;   // points per thread kept in registers (N <= 2048; beyond that they are re-read)
-
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
 
 struct rf_point {
   double X, Y, Z, u, v;
@@ -111,75 +105,90 @@ __device__ __forceinline__ void accumulate(const rf_point* cache, const double* 
     add_point(load_point(X, x, N, mask8, mask_bits, i), R, t, fx, fy, cx, cy, s);
 }
 
-// block-wide sums of s[] -> s_tot[] (valid in every thread after the call)
-__device__ __forceinline__ void block_sums(double* s, double (*s_w)[RF_S], double* s_tot) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// One butterfly step of the wave-wide sums: the lane pair (l, l ^ OFF) splits the CNT values it still
+// carries between its two lanes, so the number of values halves while the number of lanes summed doubles.
+template <int CNT, int OFF>
+__device__ __forceinline__ void fold_step(double* v, int lane) {
+  const bool hi = (lane & OFF) != 0;
 #pragma unroll
-  for (int k = 0; k < RF_S; ++k) {
-    const double v = wave_sum_f64(s[k]);
-    if (lane == 0) s_w[wv][k] = v;
+  for (int k = 0; k < CNT / 2; ++k) {
+    const double keep = hi ? v[k + CNT / 2] : v[k];
+    const double send = hi ? v[k] : v[k + CNT / 2];
+    v[k] = keep + __shfl_xor(send, OFF);
   }
-  __syncthreads();
-  if (threadIdx.x < RF_S) {
-    double v = 0.0;
-    for (int w = 0; w < RF_T / 64; ++w) v += s_w[w][threadIdx.x];
-    s_tot[threadIdx.x] = v;
-  }
-  __syncthreads();
 }
 
-__device__ bool cholesky_solve6(const double* s, double* d) {
-  // A (upper triangle in s[0..20], row-major) d = b (s[21..26])
-  double A[6][6], L[6][6];
-  int q = 0;
-  for (int a = 0; a < 6; ++a)
-    for (int b = a; b < 6; ++b) {
-      A[a][b] = s[q];
-      A[b][a] = s[q];
-      ++q;
-    }
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j <= i; ++j) {
-      double v = A[i][j];
-      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-      if (i == j) {
-        if (!(v > 0.0)) return false;
-        L[i][i] = sqrt(v);
-      } else {
-        L[i][j] = v / L[j][j];
-      }
-    }
-  double y[6];
-  for (int i = 0; i < 6; ++i) {
-    double v = s[21 + i];
-    for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
-    y[i] = v / L[i][i];
-  }
-  for (int i = 5; i >= 0; --i) {
-    double v = y[i];
-    for (int k = i + 1; k < 6; ++k) v -= L[k][i] * d[k];
-    d[i] = v / L[i][i];
-  }
-  return true;
+// wave-wide sums of s[0..27]: afterwards lanes 2j and 2j+1 hold the total of s[j] (32 shuffles, not 28 * 6)
+__device__ __forceinline__ double wave_sums(const double* s, int lane) {
+  double v[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) v[k] = k < RF_S ? s[k] : 0.0;
+  fold_step<32, 32>(v, lane);
+  fold_step<16, 16>(v, lane);
+  fold_step<8, 8>(v, lane);
+  fold_step<4, 4>(v, lane);
+  fold_step<2, 2>(v, lane);
+  return v[0] + __shfl_xor(v[0], 1);
 }
 
-__device__ void exp_so3(const double* w, double* E) {
-  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-  double a = 1.0, b = 0.0;
-  if (th >= 1e-12) {
-    a = sin(th) / th;
-    b = (1.0 - cos(th)) / (th * th);
-  }
-  const double Wx[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) {
-      double w2 = 0.0;
-      for (int k = 0; k < 3; ++k) w2 += Wx[3 * r + k] * Wx[3 * k + c];
-      E[3 * r + c] = (r == c ? 1.0 : 0.0) + a * Wx[3 * r + c] + b * w2;
+// position of (a, b), a <= b, in the row-major upper triangle s[0..20]
+__device__ __forceinline__ int tri_index(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
+
+// Solves the 6x6 normal equations held one total per lane (lane k of the wave: s[k]) by Gauss-Jordan
+// elimination, lane i < 6 working on row i (no pivoting: the matrix is positive definite or the solve
+// is refused, the same condition under which a Cholesky factorisation exists).  Returns d[i] in lane i.
+__device__ __forceinline__ bool solve6_rows(double tot, int lane, double* d_out) {
+  const int i = min(lane, 5);
+  double row[7];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) row[j] = __shfl(tot, tri_index(min(i, j), max(i, j)));
+  row[6] = __shfl(tot, 21 + i);
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double pk[7];
+#pragma unroll
+    for (int j = k; j < 7; ++j) pk[j] = __shfl(row[j], k);
+    ok = ok && pk[k] > 0.0;
+    const double f = row[k] / pk[k];
+    if (i != k) {
+#pragma unroll
+      for (int j = k + 1; j < 7; ++j) row[j] -= f * pk[j];
+      row[k] = 0.0;
     }
+  }
+  double diag = row[0];
+#pragma unroll
+  for (int j = 1; j < 6; ++j) diag = i == j ? row[j] : diag;
+  *d_out = row[6] / diag;
+  return ok;
+}
+
+// Rodrigues coefficients sin(th)/th and (1 - cos th)/th^2: their Taylor series in th^2 for the small
+// rotations an update step makes (nine terms, below 1e-17 for th < 1/4), the library functions otherwise
+__device__ __forceinline__ void rodrigues_coefficients(double th2, double* a, double* b) {
+  if (th2 < 0.0625) {
+    double sa = 1.0, sb = 1.0;
+    const double ca[8] = {1.0 / 272, 1.0 / 210, 1.0 / 156, 1.0 / 110, 1.0 / 72, 1.0 / 42, 1.0 / 20, 1.0 / 6};
+    const double cb[8] = {1.0 / 306, 1.0 / 240, 1.0 / 182, 1.0 / 132, 1.0 / 90, 1.0 / 56, 1.0 / 30, 1.0 / 12};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sa = 1.0 - th2 * ca[k] * sa;
+      sb = 1.0 - th2 * cb[k] * sb;
+    }
+    *a = sa;
+    *b = 0.5 * sb;
+  } else {
+    const double th = sqrt(th2);
+    *a = sin(th) / th;
+    *b = (1.0 - cos(th)) / th2;
+  }
 }
 
 // Rt0: R (9, row-major) then t (3).  out: R (9), t (3), iterations, cost (14 doubles).
+// Two barriers per iteration: every wave adds up its points for the trial pose and leaves 28 wave totals
+// in LDS; wave 0 alone then adds those, accepts or rejects the trial, solves for the next step and
+// writes the next trial pose while the other waves wait.
 __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restrict__ X, const double* __restrict__ x, int N,
                                                            const int* __restrict__ d_n,
                                                            const uint8_t* __restrict__ mask8,
@@ -188,64 +197,108 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
                                                            double cy, int max_iter, double tol, double* __restrict__ out,
                                                            unsigned tag) {
   __shared__ double s_w[RF_T / 64][RF_S];
-  __shared__ double s_tot[RF_S], s_new[RF_S];
   __shared__ double s_pose[12], s_try[12];
-  __shared__ int s_state;   // 0 continue, 1 stop (keep s_pose)
+  __shared__ int s_state;   // 0 run the next trial, 1 finished (s_pose holds the result)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (d_n) N = min(N, *d_n);
-  if (threadIdx.x < 12) s_pose[threadIdx.x] = Rt0[threadIdx.x];
-  __syncthreads();
+  if (threadIdx.x < 12) {
+    const double v = Rt0[threadIdx.x];
+    s_pose[threadIdx.x] = v;
+    s_try[threadIdx.x] = v;
+  }
+  if (threadIdx.x == 0) s_state = 0;
   // the thread's points stay in registers for every iteration (all loads go out together, once)
   rf_point cache[RF_PT];
 #pragma unroll
   for (int k = 0; k < RF_PT; ++k) cache[k] = load_point(X, x, N, mask8, mask_bits, k * RF_T + threadIdx.x);
-  double s[RF_S];
-  int it = 0;
-  accumulate(cache, X, x, N, mask8, mask_bits, s_pose, s_pose + 9, fx, fy, cx, cy, s);
-  block_sums(s, s_w, s_tot);
-  double cost = s_tot[27];
-  while (it < max_iter) {
-    if (threadIdx.x == 0) {
-      double d[6];
-      s_state = 0;
-      if (!cholesky_solve6(s_tot, d)) {
-        s_state = 1;
+  // wave 0's bookkeeping (uniform across its lanes)
+  int it = -1;              // -1: the first pass evaluates the starting pose
+  double cost = 0.0;
+  bool converged = false;
+  for (;;) {
+    __syncthreads();
+    if (s_state != 0) break;
+    double s[RF_S];
+    accumulate(cache, X, x, N, mask8, mask_bits, s_try, s_try + 9, fx, fy, cx, cy, s);
+    const double wsum = wave_sums(s, lane);
+    if ((lane & 1) == 0 && (lane >> 1) < RF_S) s_w[wv][lane >> 1] = wsum;
+    __syncthreads();
+    if (wv != 0) continue;
+    double tot = 0.0;
+    if (lane < RF_S) {
+#pragma unroll
+      for (int w = 0; w < RF_T / 64; ++w) tot += s_w[w][lane];
+    }
+    const double cost_new = __shfl(tot, 27);
+    bool stop = false;
+    if (it < 0) {
+      it = 0;
+      cost = cost_new;
+    } else if (!(cost_new <= cost)) {
+      stop = true;           // no decrease: keep the previous pose
+    } else {
+      if (lane < 12) s_pose[lane] = s_try[lane];
+      ++it;
+      stop = converged || cost - cost_new <= 1e-16 * cost;
+      cost = cost_new;
+    }
+    if (!stop && it >= max_iter) stop = true;
+    if (!stop) {
+      double di;
+      const bool ok = solve6_rows(tot, lane, &di);
+      if (!ok) {
+        stop = true;
       } else {
+        double d[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[j] = __shfl(di, j);
+        double ca, cb;
+        rodrigues_coefficients(d[3] * d[3] + d[4] * d[4] + d[5] * d[5], &ca, &cb);
+        const double Wx[9] = {0.0, -d[5], d[4], d[5], 0.0, -d[3], -d[4], d[3], 0.0};
         double E[9];
-        exp_so3(d + 3, E);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double w2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w2 += Wx[3 * r + k] * Wx[3 * k + c];
+            E[3 * r + c] = (r == c ? 1.0 : 0.0) + ca * Wx[3 * r + c] + cb * w2;
+          }
+        // every lane computes the same 12 numbers; lane 0 stores them (s_pose was written above by this wave)
+        double P[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) P[q] = s_pose[q];
+        double T[12];
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
-          for (int c = 0; c < 3; ++c)
-            s_try[3 * r + c] = E[3 * r] * s_pose[c] + E[3 * r + 1] * s_pose[3 + c] + E[3 * r + 2] * s_pose[6 + c];
-          s_try[9 + r] = E[3 * r] * s_pose[9] + E[3 * r + 1] * s_pose[10] + E[3 * r + 2] * s_pose[11] + d[r];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) T[3 * r + c] = E[3 * r] * P[c] + E[3 * r + 1] * P[3 + c] + E[3 * r + 2] * P[6 + c];
+          T[9 + r] = E[3 * r] * P[9] + E[3 * r + 1] * P[10] + E[3 * r + 2] * P[11] + d[r];
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 12; ++q) s_try[q] = T[q];
         }
         const double dn = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
-        const double tn = sqrt(s_try[9] * s_try[9] + s_try[10] * s_try[10] + s_try[11] * s_try[11]);
-        if (dn <= tol * (1.0 + tn)) s_state = 2;   // converged after this update
+        const double tn = sqrt(T[9] * T[9] + T[10] * T[10] + T[11] * T[11]);
+        converged = dn <= tol * (1.0 + tn);   // converged once this update is accepted
       }
     }
-    __syncthreads();
-    if (s_state == 1) break;
-    accumulate(cache, X, x, N, mask8, mask_bits, s_try, s_try + 9, fx, fy, cx, cy, s);
-    block_sums(s, s_w, s_new);
-    const double cost_new = s_new[27];
-    if (!(cost_new <= cost)) break;   // no decrease: keep the previous pose (uniform: all threads read the same sums)
-    __syncthreads();
-    if (threadIdx.x < 12) s_pose[threadIdx.x] = s_try[threadIdx.x];
-    if (threadIdx.x < RF_S) s_tot[threadIdx.x] = s_new[threadIdx.x];
-    ++it;
-    const bool done = s_state == 2 || cost - cost_new <= 1e-16 * cost;
-    cost = cost_new;
-    __syncthreads();
-    if (done) break;
+    if (stop && lane == 0) s_state = 1;
   }
-  if (threadIdx.x < 12) out[threadIdx.x] = s_pose[threadIdx.x];
-  if (threadIdx.x == 0) {
-    out[12] = (double)it;
-    out[13] = cost;
-  }
-  if (tag) {   // out is mapped host memory the host polls: the tag goes last
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) out[14] = (double)tag;
+  if (wv == 0) {
+    if (lane < 12) out[lane] = s_pose[lane];
+    if (lane == 0) {
+      out[12] = (double)(it < 0 ? 0 : it);
+      out[13] = cost;
+    }
+    if (tag) {   // out is mapped host memory the host polls: the tag goes last
+      __threadfence_system();
+      if (lane == 0) {
+        __hip_atomic_store(&out[14], (double)tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
