@@ -5,7 +5,8 @@ The reference minimises  sum_i || x_i - proj(K, R X_i + t) ||^2  (one residual p
 reprojection distance) over the twist of the pose (helpers.py:86-142) with TRF and a numerical
 Jacobian, default tolerances 1e-8.  The objective does not depend on the parametrisation, so the
 device kernel -- and this restatement -- run Gauss-Newton with the analytic Jacobian on the
-left-multiplied increment  T <- [Exp(w) | v] T  and stop at a relative step of 1e-9 (the step after it would move the pose by ~1e-18).  SciPy
+left-multiplied increment  T <- [Exp(w) | v] T  until the next step would be below 1e-9 relative
+(that step is not taken: the pose returned is the last one evaluated, its cost is exact).  SciPy
 stops when the cost changes by < 1e-8 of itself, i.e. up to ~1e-4 away from the minimiser in
 pose; tests compare against SciPy at its default tolerances (1e-4) and at tightened ones (1e-8).
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py)."""
@@ -63,14 +64,15 @@ def refine_pose(X, x, K, R0, t0, max_iter=20, tol=1e-9):
         d = np.linalg.solve(L.T, np.linalg.solve(L, b))
         E = exp_so3(d[3:])
         Rn, tn = E @ R, E @ t + d[:3]
+        if np.sqrt(d @ d) <= tol * (1.0 + np.sqrt(tn @ tn)):   # converged: the step is not worth an evaluation
+            break
         An, bn, costn = normal_equations(X, x, K, Rn, tn)
         if not costn <= cost:          # no decrease: keep the previous pose
             break
         R, t, A, b = Rn, tn, An, bn
         it += 1
-        small = np.sqrt(d @ d) <= tol * (1.0 + np.sqrt(t @ t))
         done = cost - costn <= 1e-16 * cost
         cost = costn
-        if small or done:
+        if done:
             break
     return R, t, it, cost

@@ -5,8 +5,8 @@
 // residual per inlier = its reprojection distance, started from the best RANSAC hypothesis.
 // The objective  sum_i |x_i - proj(K, R X_i + t)|^2  does not depend on the parametrisation, so
 // this kernel runs Gauss-Newton with the analytic Jacobian on the left-multiplied increment
-// T <- [Exp(w) | v] T  (restated in oracle/refine_np.py) and converges to the minimiser itself
-// in 3-4 iterations; SciPy stops within ~1e-4 of it (tests/test_oracle_refine.py).
+// T <- [Exp(w) | v] T  (restated in oracle/refine_np.py) until the next step would be below 1e-9
+// relative, 2-3 iterations; SciPy stops within ~1e-4 of the minimiser (tests/test_oracle_refine.py).
 //
 // One workgroup of 512 threads: every thread keeps its (up to four) points in registers and
 // accumulates their 21 + 6 + 1 terms once per iteration; a wave adds its lanes' terms with a
@@ -214,7 +214,6 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
   // wave 0's bookkeeping (uniform across its lanes)
   int it = -1;              // -1: the first pass evaluates the starting pose
   double cost = 0.0;
-  bool converged = false;
   for (;;) {
     __syncthreads();
     if (s_state != 0) break;
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
     } else {
       if (lane < 12) s_pose[lane] = s_try[lane];
       ++it;
-      stop = converged || cost - cost_new <= 1e-16 * cost;
+      stop = cost - cost_new <= 1e-16 * cost;
       cost = cost_new;
     }
     if (!stop && it >= max_iter) stop = true;
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
         }
         const double dn = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
         const double tn = sqrt(T[9] * T[9] + T[10] * T[10] + T[11] * T[11]);
-        converged = dn <= tol * (1.0 + tn);   // converged once this update is accepted
+        if (dn <= tol * (1.0 + tn)) stop = true;   // converged: a step this small is not taken (nor evaluated)
       }
     }
     if (stop && lane == 0) s_state = 1;
