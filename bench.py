@@ -105,8 +105,8 @@ def cpu_baseline(stream, frames=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
                     help="one blocking vo_pipeline_step per frame instead of submitting frame k+1 before "

@@ -14,9 +14,14 @@ file:line it follows.  Pinning status per module:
 * ``dlt_np``      pinned to 1e-9 by tests/golden/dlt_*.npz (same capture).
 * ``ransac_np``   pinned by tests/golden/ransac_*.npz (sampler known answers,
                   iteration-bound table, full parabola trace).
+* ``refine_np``   the minimiser the reference asks scipy.optimize.least_squares
+                  for (p3p.py:188-213); pinned by running SciPy's TRF on the
+                  reference's residual in tests/test_oracle_refine.py (1e-4 at
+                  SciPy's default tolerances, 1e-8 tightened).
 * ``bookkeeping`` (Matches/State restatement lives in the product shim; the
                   golden tests/golden/bookkeeping_*.npz pins it.)
-* ``csrc/p3p.c``, ``csrc/klt.c``, ``csrc/match.c``: the reference delegates
+* ``csrc/p3p.c``, ``csrc/klt.c``, ``csrc/match.c``, ``csrc/goodfeatures.c``,
+  ``csrc/sift.c``: the reference delegates
                   this arithmetic to opencv-python==4.8.1.78, which is not in
                   /root/reference and not installable here: PARITY UNPINNED
                   against OpenCV; checked against analytic ground truth.
