@@ -26,6 +26,8 @@
 struct vo_pipeline {
   vo_ctx* ctx = nullptr;
   vo_ctx* det = nullptr;            // second context (own stream + NMS workspace): detection runs beside tracking
+  vo_ctx* det2 = nullptr;           // a second detection stream: with a frame of look-ahead consecutive detections overlap
+  vo_ctx* pyr = nullptr;            // stream the next frame's pyramid is built on while a step is in flight
   vo_ctx* tri = nullptr;            // stream of the DLT (independent of the detection it used to queue behind)
   vo_ctx* redo = nullptr;           // another stream: hypothesis batches of the sequential sampler (rare) must not queue
                                     // behind a step submitted later, whose solve kernel waits for this step's outcome
@@ -38,9 +40,10 @@ struct vo_pipeline {
   std::thread worker;
   std::atomic<unsigned> job_posted{0}, job_done{0};
   std::atomic<bool> quit{false};
-  struct job_t { int kind, frame, slot, ev; };   // kind 0: detection of `frame` into keypoint buffer `slot`; 1: DLT of track set `slot`
+  struct job_t { int kind, frame, slot, ev, which; };   // kind 0: detection of `frame` into keypoint buffer `slot`; 1: DLT of track set `slot`
   job_t jobs[8];
   int job_rc = 0;
+  int job_which = 0;                 // whose error text goes with job_rc: 0 det, 1 det2, 2 tri
   bool det_warm = false;
   vo_pipeline_config cfg;
   int n_levels = 1;
@@ -51,12 +54,18 @@ struct vo_pipeline {
   std::vector<double> T_wc;          // n_frames * 16 (camera -> world)
   double* d_T_wc = nullptr;          // same, on the device
   // per-step state (double-buffered where the next step reads the previous one's output)
-  uint8_t* d_pyr[2] = {nullptr, nullptr};
-  double* d_kp[2] = {nullptr, nullptr};
-  int cur = 0;                       // buffer index holding `prev`'s pyramid / keypoints
+  // Pyramids and keypoints of a frame live in slot (frame count mod 3): with a step in flight the next
+  // frame's pyramid and detection run beside it on their own streams, so they must not land in
+  // a buffer the step in flight still reads.
+  uint8_t* d_pyr[3] = {nullptr, nullptr, nullptr};
+  double* d_kp[3] = {nullptr, nullptr, nullptr};
+  int cur = 0;                       // slot holding `prev`'s pyramid / keypoints
+  int det_flip = 0;                  // detections alternate between two streams (det, det2)
+  hipEvent_t evPyr[3] = {nullptr, nullptr, nullptr};   // pyramid of a slot built (when built off the main stream)
   int prev_frame = -1;
   double* d_scores = nullptr;
-  float *d_kp_f32[2] = {nullptr, nullptr}, *d_next_f32 = nullptr, *d_err = nullptr;   // d_kp as float pairs
+  double* d_scores2 = nullptr;       // score map of the second detection stream
+  float *d_kp_f32[3] = {nullptr, nullptr, nullptr}, *d_next_f32 = nullptr, *d_err = nullptr;   // d_kp as float pairs
   uint8_t* d_status = nullptr;
   // compacted tracks, two sets: the deferred DLT of step k reads set k&1 while step k+1 fills the other
   double *d_prev_c[2] = {nullptr, nullptr}, *d_next_c[2] = {nullptr, nullptr}, *d_land_c[2] = {nullptr, nullptr};
@@ -321,9 +330,12 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   p->ctx = ctx;
   p->cfg = *cfg;
   if (vo_create(ctx->device, nullptr, &p->det) != VO_OK || vo_create(ctx->device, nullptr, &p->redo) != VO_OK ||
-      vo_create(ctx->device, nullptr, &p->tri) != VO_OK) {
+      vo_create(ctx->device, nullptr, &p->tri) != VO_OK || vo_create(ctx->device, nullptr, &p->det2) != VO_OK ||
+      vo_create(ctx->device, nullptr, &p->pyr) != VO_OK) {
     if (p->det) vo_destroy(p->det);
     if (p->redo) vo_destroy(p->redo);
+    if (p->tri) vo_destroy(p->tri);
+    if (p->det2) vo_destroy(p->det2);
     delete p;
     return vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the detection stream");
   }
@@ -341,13 +353,13 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     PA(dev_alloc(ctx, &p->d_depth[f], px));
   }
   PA(dev_alloc(ctx, &p->d_T_wc, (size_t)cfg->n_frames * 16));
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     PA(dev_alloc(ctx, &p->d_pyr[k], p->pyr_bytes));
     PA(dev_alloc(ctx, &p->d_kp[k], (size_t)N * 2));
+    PA(dev_alloc(ctx, &p->d_kp_f32[k], (size_t)N * 2));
   }
   PA(dev_alloc(ctx, &p->d_scores, px));
-  PA(dev_alloc(ctx, &p->d_kp_f32[0], (size_t)N * 2));
-  PA(dev_alloc(ctx, &p->d_kp_f32[1], (size_t)N * 2));
+  PA(dev_alloc(ctx, &p->d_scores2, px));
   PA(dev_alloc(ctx, &p->d_next_f32, (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_err, (size_t)N));
   PA(dev_alloc(ctx, &p->d_status, (size_t)N));
@@ -398,6 +410,9 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
                       hipEventCreateWithFlags(&p->evB, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evDet[0], hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evDet[1], hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evPyr[0], hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evPyr[1], hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evPyr[2], hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evDlt[0], hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evDlt[1], hipEventDisableTiming) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
@@ -436,7 +451,8 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     p->quit.store(true, std::memory_order_release);
     p->worker.join();
   }
-  void* dev[] = {p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_kp[0], p->d_kp[1], p->d_scores, p->d_kp_f32[0], p->d_kp_f32[1],
+  void* dev[] = {p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_pyr[2], p->d_kp[0], p->d_kp[1], p->d_kp[2], p->d_scores,
+                 p->d_scores2, p->d_kp_f32[0], p->d_kp_f32[1], p->d_kp_f32[2],
                  p->d_next_f32, p->d_err, p->d_status, p->d_prev_c[0], p->d_next_c[0], p->d_land_c[0], p->d_prev_c[1],
                  p->d_next_c[1], p->d_land_c[1], p->d_tri,
                  p->d_ntracked, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks};
@@ -451,7 +467,11 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (p->evDet[k]) (void)hipEventDestroy(p->evDet[k]);
   for (int k = 0; k < 2; ++k)
     if (p->evDlt[k]) (void)hipEventDestroy(p->evDlt[k]);
+  for (int k = 0; k < 3; ++k)
+    if (p->evPyr[k]) (void)hipEventDestroy(p->evPyr[k]);
   if (p->det) vo_destroy(p->det);
+  if (p->det2) vo_destroy(p->det2);
+  if (p->pyr) vo_destroy(p->pyr);
   if (p->redo) vo_destroy(p->redo);
   if (p->tri) vo_destroy(p->tri);
   delete p;
@@ -491,12 +511,13 @@ static inline int32_t* sl_nt(vo_pipeline* p, int s) { return p->d_ntracked + 8 *
 static inline double* sl_tri(vo_pipeline* p, int s) { return p->d_tri + (size_t)s * p->cfg.n_keypoints * 3; }
 
 // detection of `frame` into keypoint buffer `slot`; evDet[ev]: the next step's tracker may start
-static int enqueue_detection(vo_pipeline* p, int frame, int slot, int ev) {
+static int enqueue_detection(vo_pipeline* p, int frame, int slot, int ev, int which) {
   const vo_pipeline_config& c = p->cfg;
-  vo_ctx* det = p->det;
+  vo_ctx* det = which ? p->det2 : p->det;
+  double* scores = which ? p->d_scores2 : p->d_scores;
   det->nms_kp_f32 = p->d_kp_f32[slot];   // the tracker's float copy of the keypoints
-  int rc = vo_harris_response_dev(det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, p->d_scores);
-  if (rc == VO_OK) rc = vo_nms_keypoints_dev(det, p->d_scores, c.H, c.W, c.n_keypoints, c.nms_radius, p->d_kp[slot]);
+  int rc = vo_harris_response_dev(det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, scores);
+  if (rc == VO_OK) rc = vo_nms_keypoints_dev(det, scores, c.H, c.W, c.n_keypoints, c.nms_radius, p->d_kp[slot]);
   if (rc == VO_OK && hipEventRecord(p->evDet[ev], det->stream) != hipSuccess) rc = VO_EHIP;
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(det));
   return VO_OK;
@@ -574,27 +595,33 @@ static void worker_main(vo_pipeline* p) {
     }
     idle = 0;
     const vo_pipeline::job_t j = p->jobs[seen & 7];
-    const int rc = j.kind == 0 ? enqueue_detection(p, j.frame, j.slot, j.ev) : enqueue_dlt(p, j.slot);
-    if (rc != VO_OK) p->job_rc = rc;
+    const int rc = j.kind == 0 ? enqueue_detection(p, j.frame, j.slot, j.ev, j.which) : enqueue_dlt(p, j.slot);
+    if (rc != VO_OK) {
+      p->job_rc = rc;
+      p->job_which = j.kind == 0 ? j.which : 2;
+    }
     ++seen;
     p->job_done.store(seen, std::memory_order_release);
   }
 }
 
-static void post_job(vo_pipeline* p, int kind, int frame, int slot, int ev) {
-  p->det->prof_on = p->tri->prof_on = p->ctx->prof_on;
-  p->det->prof_kernel = p->tri->prof_kernel = p->ctx->prof_kernel;
-  p->det->prof_every = p->tri->prof_every = p->ctx->prof_every;
+static void post_job(vo_pipeline* p, int kind, int frame, int slot, int ev, int which) {
+  for (vo_ctx* q : {p->det, p->det2, p->tri, p->pyr}) {
+    q->prof_on = p->ctx->prof_on;
+    q->prof_kernel = p->ctx->prof_kernel;
+    q->prof_every = p->ctx->prof_every;
+  }
   const unsigned n = p->job_posted.load(std::memory_order_relaxed);
   while (n - p->job_done.load(std::memory_order_acquire) >= 8) __builtin_ia32_pause();   // ring full (never in practice)
-  p->jobs[n & 7] = {kind, frame, slot, ev};
+  p->jobs[n & 7] = {kind, frame, slot, ev, which};
   p->job_posted.store(n + 1, std::memory_order_release);
 }
 
 // hands the detection of `frame` to the worker; returns the index of the event it will record
 static int post_detection(vo_pipeline* p, int frame, int slot) {
   p->ev_last ^= 1;
-  post_job(p, 0, frame, slot, p->ev_last);
+  p->det_flip ^= 1;
+  post_job(p, 0, frame, slot, p->ev_last, p->det_flip);
   return p->ev_last;
 }
 
@@ -605,7 +632,8 @@ static int worker_idle(vo_pipeline* p) {
   if (p->job_rc != VO_OK) {
     const int rc = p->job_rc;
     p->job_rc = VO_OK;
-    return vo_set_error(p->ctx, rc, "detection branch: %s", vo_last_error(p->det));
+    return vo_set_error(p->ctx, rc, "detection branch: %s",
+                        vo_last_error(p->job_which == 0 ? p->det : p->job_which == 1 ? p->det2 : p->tri));
   }
   return VO_OK;
 }
@@ -620,7 +648,7 @@ static int detect_join(vo_pipeline* p) {
 static int flush_dlt(vo_pipeline* p) {
   if (!p->dlt_unflushed) return VO_OK;
   p->dlt_unflushed = false;
-  post_job(p, 1, 0, p->cset_collected, 0);
+  post_job(p, 1, 0, p->cset_collected, 0, 0);
   return VO_OK;
 }
 
@@ -670,7 +698,7 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
              prev_idx, p->prev_frame);
   VO_REQUIRE(ctx, p->n_flight < 2, "pipeline_submit: two steps are already in flight, collect one first");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int a = p->cur, b = 1 - p->cur;
+  const int a = p->cur, b = (p->cur + 1) % 3;
   const int cs = 1 - p->cset;                          // slot (track set) this step fills
   static const bool dbg = getenv("VO_DEBUG_TIMING") != nullptr;
   double t_entry = 0;
@@ -690,7 +718,16 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   const int ev_prev = p->ev_last;                      // recorded behind the last step's detection
   post_detection(p, next_idx, b);
   VO_TRY(flush_dlt(p));                                // the last collected step's DLT, behind this detection
-  VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
+  if (p->n_flight == 0) {
+    VO_TRY(vo_pyramid_build_dev(ctx, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]));
+  } else {
+    // a step is in flight on the main stream: the pyramid need not queue behind it (slot b is not
+    // one of the two that step reads), the tracker of this step waits for its event instead
+    const int rc = vo_pyramid_build_dev(p->pyr, p->d_img[next_idx], c.H, c.W, p->n_levels, p->d_pyr[b]);
+    if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->pyr));
+    VO_HIP_TRY(ctx, hipEventRecord(p->evPyr[b], p->pyr->stream));
+    VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evPyr[b], 0));
+  }
   // keypoints of `prev`: usually long finished, and then no barrier goes into the queue
   if (hipEventQuery(p->evDet[ev_prev]) != hipSuccess)
     VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[ev_prev], 0));
@@ -918,35 +955,30 @@ int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int ca
   return vo_check_launch(ctx, "export_state_kernel");
 }
 
-// per-kernel event times accumulated on the detection stream (vo_prof_read covers the main one)
+// per-kernel event times accumulated over all of the pipeline's streams
 int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64_t* launches) {
   if (!p) return VO_EINVAL;
-  double a = 0, b = 0;
-  int64_t na = 0, nb = 0;
   VO_TRY(worker_idle(p));
-  VO_TRY(vo_prof_read(p->ctx, kernel_id, &a, &na));
-  int rc = vo_prof_read(p->det, kernel_id, &b, &nb);
-  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->det));
-  double c = 0;
-  int64_t nc = 0;
-  rc = vo_prof_read(p->tri, kernel_id, &c, &nc);
-  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->tri));
-  double d = 0;
-  int64_t nd = 0;
-  rc = vo_prof_read(p->redo, kernel_id, &d, &nd);
-  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(p->redo));
-  if (total_ms) *total_ms = a + b + c + d;
-  if (launches) *launches = na + nb + nc + nd;
+  double sum = 0;
+  int64_t n = 0;
+  for (vo_ctx* q : {p->ctx, p->det, p->det2, p->pyr, p->tri, p->redo}) {
+    double ms = 0;
+    int64_t k = 0;
+    const int rc = vo_prof_read(q, kernel_id, &ms, &k);
+    if (rc != VO_OK) return q == p->ctx ? rc : vo_set_error(p->ctx, rc, "%s", vo_last_error(q));
+    sum += ms;
+    n += k;
+  }
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = n;
   return VO_OK;
 }
 
 int vo_pipeline_prof_reset(vo_pipeline* p) {
   if (!p) return VO_EINVAL;
   VO_TRY(worker_idle(p));
-  VO_TRY(vo_prof_reset(p->ctx));
-  VO_TRY(vo_prof_reset(p->tri));
-  VO_TRY(vo_prof_reset(p->redo));
-  return vo_prof_reset(p->det);
+  for (vo_ctx* q : {p->ctx, p->det, p->det2, p->pyr, p->tri, p->redo}) VO_TRY(vo_prof_reset(q));
+  return VO_OK;
 }
 
 int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* next_xy, double* landmarks,
