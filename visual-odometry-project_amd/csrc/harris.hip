@@ -52,6 +52,9 @@ constexpr int RY = 32;   // response tile height (four strips of eight rows)
 struct resp_geom {
   int pr, GW, GWp, GH, IWp, IH;
 };
+typedef short pk16 __attribute__((ext_vector_type(2)));   // two 16-bit lanes of one register (packed math)
+__device__ __forceinline__ pk16 as_pk16(unsigned v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ unsigned as_u32(pk16 v) { return __builtin_bit_cast(unsigned, v); }
 __host__ __device__ inline resp_geom response_geometry(int p) {
   resp_geom g;
   g.pr = p >> 1;
@@ -84,21 +87,39 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
   // A: image tile + halo (zeros outside the image; such pixels only feed outputs
   //    that the border rule forces to 0)
   if (P_T > 0) {
-    constexpr int PG = ((RX + 2 * (P_T >> 1) + 3) & ~3) + 4;
-    constexpr int PER = (PG * (RY + 2 * (P_T >> 1) + 2) + NT - 1) / NT;
-    uint8_t v[PER];
+    constexpr int PG = ((RX + 2 * (P_T >> 1) + 3) & ~3) + 4;      // = IWp
+    constexpr int PH = RY + 2 * (P_T >> 1) + 2;                   // = IH
+    if (ix0 >= 0 && iy0 >= 0 && ix0 + PG <= W && iy0 + PH <= H) {
+      // interior tile: whole words (global addresses of any alignment), all in flight together
+      constexpr int WPR = PG / 4, NWORD = WPR * PH, PERW = (NWORD + NT - 1) / NT;
+      unsigned v[PERW];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = tid + k * NT;
-      const int ly = i / IWp, lx = i - ly * IWp;
-      const int gy = iy0 + ly, gx = ix0 + lx;
-      const bool in = i < IWp * IH && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      v[k] = in ? img[(size_t)gy * W + gx] : (uint8_t)0;
-    }
+      for (int k = 0; k < PERW; ++k) {
+        const int i = min(tid + k * NT, NWORD - 1);
+        const int ly = i / WPR, j = i - ly * WPR;
+        __builtin_memcpy(&v[k], img + (size_t)(iy0 + ly) * W + ix0 + 4 * j, 4);
+      }
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = tid + k * NT;
-      if (i < IWp * IH) s_img[i] = v[k];
+      for (int k = 0; k < PERW; ++k) {
+        const int i = tid + k * NT;
+        if (i < NWORD) reinterpret_cast<unsigned*>(s_img)[i] = v[k];
+      }
+    } else {
+      constexpr int PER = (PG * PH + NT - 1) / NT;
+      uint8_t v[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * NT;
+        const int ly = i / IWp, lx = i - ly * IWp;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        const bool in = i < IWp * IH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        v[k] = in ? img[(size_t)gy * W + gx] : (uint8_t)0;
+      }
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * NT;
+        if (i < IWp * IH) s_img[i] = v[k];
+      }
     }
   } else {
     for (int i = tid; i < IWp * IH; i += NT) {
@@ -111,49 +132,114 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
   }
   __syncthreads();
 
-  // B: Sobel as a TRUE convolution (kernel flipped): left minus right, top minus bottom
   const int groups = GWp >> 2;
-  for (int i = tid; i < GH * groups; i += NT) {
-    const int ly = i / groups, j = i - ly * groups;
-    const unsigned* r0 = reinterpret_cast<const unsigned*>(s_img + ly * IWp + 4 * j);   // row above centre
-    const unsigned* r1 = r0 + (IWp >> 2);
-    const unsigned* r2 = r1 + (IWp >> 2);
-    const unsigned long long a0 = r0[0] | ((unsigned long long)r0[1] << 32);
-    const unsigned long long a1 = r1[0] | ((unsigned long long)r1[1] << 32);
-    const unsigned long long a2 = r2[0] | ((unsigned long long)r2[1] << 32);
-    int o[4];
+  if (P_T > 0) {
+    // B (packed): Sobel as a TRUE convolution (kernel flipped: left minus right, top minus bottom) on
+    // pairs of 16-bit lanes.  Per row the six bytes b0..b5 under four neighbouring outputs become three
+    // pairs; c = r0 + 2 r1 + r2 (column smoothing), d = r0 - r2; Ix = c[k] - c[k+2], Iy = d[k] + 2 d[k+1] + d[k+2].
+    // The two gradients go to separate 16-bit planes so that step C can use packed dot products.
+    short* s_ix = reinterpret_cast<short*>(s_g);
+    short* s_iy = s_ix + GWp * GH;
+    for (int i = tid; i < GH * groups; i += NT) {
+      const int ly = i / groups, j = i - ly * groups;
+      const unsigned* r0 = reinterpret_cast<const unsigned*>(s_img + ly * IWp + 4 * j);   // row above centre
+      const unsigned* r1 = r0 + (IWp >> 2);
+      const unsigned* r2 = r1 + (IWp >> 2);
+      pk16 c[3], d[3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int a00 = (int)((a0 >> (8 * k)) & 255), a01 = (int)((a0 >> (8 * k + 8)) & 255),
-                a02 = (int)((a0 >> (8 * k + 16)) & 255);
-      const int a10 = (int)((a1 >> (8 * k)) & 255), a12 = (int)((a1 >> (8 * k + 16)) & 255);
-      const int a20 = (int)((a2 >> (8 * k)) & 255), a21 = (int)((a2 >> (8 * k + 8)) & 255),
-                a22 = (int)((a2 >> (8 * k + 16)) & 255);
-      const int gx = (a00 - a02) + 2 * (a10 - a12) + (a20 - a22);
-      const int gy = (a00 - a20) + 2 * (a01 - a21) + (a02 - a22);
-      o[k] = (gx & 0xffff) | (gy << 16);
-    }
-    *reinterpret_cast<int4*>(s_g + ly * GWp + 4 * j) = make_int4(o[0], o[1], o[2], o[3]);
-  }
-  __syncthreads();
-
-  // C: horizontal box sums of the three products
-  for (int i = tid; i < GH * RX; i += NT) {
-    const int ly = i / RX, lx = i - ly * RX;
-    const int* gp = s_g + ly * GWp + lx;
-    int sxx = 0, syy = 0, sxy = 0;
-    if (P_T > 0) {
-      int v[P_T > 0 ? P_T : 1];
-#pragma unroll
-      for (int k = 0; k < P_T; ++k) v[k] = gp[k];
-#pragma unroll
-      for (int k = 0; k < P_T; ++k) {
-        const int gx = (int)(short)(v[k] & 0xffff), gy = v[k] >> 16;
-        sxx += gx * gx;
-        syy += gy * gy;
-        sxy += gx * gy;
+      for (int h = 0; h < 3; ++h) {
+        const unsigned w0 = h < 2 ? r0[0] : r0[1], w1 = h < 2 ? r1[0] : r1[1], w2 = h < 2 ? r2[0] : r2[1];
+        const unsigned sel = h == 1 ? 0x0c030c02u : 0x0c010c00u;
+        const pk16 a0 = as_pk16(__builtin_amdgcn_perm(0u, w0, sel));
+        const pk16 a1 = as_pk16(__builtin_amdgcn_perm(0u, w1, sel));
+        const pk16 a2 = as_pk16(__builtin_amdgcn_perm(0u, w2, sel));
+        c[h] = a0 + a1 + a1 + a2;
+        d[h] = a0 - a2;
       }
-    } else {
+      const pk16 d12 = as_pk16(__builtin_amdgcn_alignbit(as_u32(d[1]), as_u32(d[0]), 16));
+      const pk16 d34 = as_pk16(__builtin_amdgcn_alignbit(as_u32(d[2]), as_u32(d[1]), 16));
+      const pk16 gx01 = c[0] - c[1], gx23 = c[1] - c[2];
+      const pk16 gy01 = d[0] + d12 + d12 + d[1], gy23 = d[1] + d34 + d34 + d[2];
+      *reinterpret_cast<uint2*>(s_ix + ly * GWp + 4 * j) = make_uint2(as_u32(gx01), as_u32(gx23));
+      *reinterpret_cast<uint2*>(s_iy + ly * GWp + 4 * j) = make_uint2(as_u32(gy01), as_u32(gy23));
+    }
+    __syncthreads();
+
+    // C (packed): horizontal box sums of Ix^2, Iy^2, Ix Iy for two neighbouring output columns per work
+    // item.  Output 2q sums taps 2q .. 2q+P-1, output 2q+1 taps 2q+1 .. 2q+P: the (P-3)/2 aligned pairs
+    // in the middle are shared, each output adds one more pair and one single tap.
+    constexpr int NW = P_T > 0 ? (P_T + 1) / 2 : 2;   // words (pairs of columns) a work item reads per plane
+    const int wpr = GWp >> 1;                   // words per gradient row
+    for (int i = tid; i < GH * (RX / 2); i += NT) {
+      const int ly = i / (RX / 2), q = i - ly * (RX / 2);
+      const unsigned* px = reinterpret_cast<const unsigned*>(s_ix) + ly * wpr + q;
+      const unsigned* py = reinterpret_cast<const unsigned*>(s_iy) + ly * wpr + q;
+      unsigned wx[NW], wy[NW];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        wx[k] = px[k];
+        wy[k] = py[k];
+      }
+      int sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+      for (int k = 1; k < NW - 1; ++k) {
+        sxx = __builtin_amdgcn_sdot2(as_pk16(wx[k]), as_pk16(wx[k]), sxx, false);
+        syy = __builtin_amdgcn_sdot2(as_pk16(wy[k]), as_pk16(wy[k]), syy, false);
+        sxy = __builtin_amdgcn_sdot2(as_pk16(wx[k]), as_pk16(wy[k]), sxy, false);
+      }
+      const pk16 x0 = as_pk16(wx[0]), y0p = as_pk16(wy[0]);
+      const pk16 x0h = as_pk16(wx[0] & 0xffff0000u), y0h = as_pk16(wy[0] & 0xffff0000u);
+      const pk16 xl = as_pk16(wx[NW - 1]), yl = as_pk16(wy[NW - 1]);
+      const pk16 xll = as_pk16(wx[NW - 1] & 0x0000ffffu), yll = as_pk16(wy[NW - 1] & 0x0000ffffu);
+      int axx = __builtin_amdgcn_sdot2(x0, x0, sxx, false);
+      int ayy = __builtin_amdgcn_sdot2(y0p, y0p, syy, false);
+      int axy = __builtin_amdgcn_sdot2(x0, y0p, sxy, false);
+      axx = __builtin_amdgcn_sdot2(xll, xll, axx, false);
+      ayy = __builtin_amdgcn_sdot2(yll, yll, ayy, false);
+      axy = __builtin_amdgcn_sdot2(xll, yll, axy, false);
+      int bxx = __builtin_amdgcn_sdot2(xl, xl, sxx, false);
+      int byy = __builtin_amdgcn_sdot2(yl, yl, syy, false);
+      int bxy = __builtin_amdgcn_sdot2(xl, yl, sxy, false);
+      bxx = __builtin_amdgcn_sdot2(x0h, x0h, bxx, false);
+      byy = __builtin_amdgcn_sdot2(y0h, y0h, byy, false);
+      bxy = __builtin_amdgcn_sdot2(x0h, y0h, bxy, false);
+      const int o = ly * RX + 2 * q;
+      *reinterpret_cast<int2*>(s_hxx + o) = make_int2(axx, bxx);
+      *reinterpret_cast<int2*>(s_hyy + o) = make_int2(ayy, byy);
+      *reinterpret_cast<int2*>(s_hxy + o) = make_int2(axy, bxy);
+    }
+    __syncthreads();
+  } else {
+    // B: Sobel as a TRUE convolution (kernel flipped): left minus right, top minus bottom
+    for (int i = tid; i < GH * groups; i += NT) {
+      const int ly = i / groups, j = i - ly * groups;
+      const unsigned* r0 = reinterpret_cast<const unsigned*>(s_img + ly * IWp + 4 * j);   // row above centre
+      const unsigned* r1 = r0 + (IWp >> 2);
+      const unsigned* r2 = r1 + (IWp >> 2);
+      const unsigned long long a0 = r0[0] | ((unsigned long long)r0[1] << 32);
+      const unsigned long long a1 = r1[0] | ((unsigned long long)r1[1] << 32);
+      const unsigned long long a2 = r2[0] | ((unsigned long long)r2[1] << 32);
+      int o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int a00 = (int)((a0 >> (8 * k)) & 255), a01 = (int)((a0 >> (8 * k + 8)) & 255),
+                  a02 = (int)((a0 >> (8 * k + 16)) & 255);
+        const int a10 = (int)((a1 >> (8 * k)) & 255), a12 = (int)((a1 >> (8 * k + 16)) & 255);
+        const int a20 = (int)((a2 >> (8 * k)) & 255), a21 = (int)((a2 >> (8 * k + 8)) & 255),
+                  a22 = (int)((a2 >> (8 * k + 16)) & 255);
+        const int gx = (a00 - a02) + 2 * (a10 - a12) + (a20 - a22);
+        const int gy = (a00 - a20) + 2 * (a01 - a21) + (a02 - a22);
+        o[k] = (gx & 0xffff) | (gy << 16);
+      }
+      *reinterpret_cast<int4*>(s_g + ly * GWp + 4 * j) = make_int4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+
+    // C: horizontal box sums of the three products
+    for (int i = tid; i < GH * RX; i += NT) {
+      const int ly = i / RX, lx = i - ly * RX;
+      const int* gp = s_g + ly * GWp + lx;
+      int sxx = 0, syy = 0, sxy = 0;
       for (int k = 0; k < p; ++k) {
         const int v = gp[k];
         const int gx = (int)(short)(v & 0xffff), gy = v >> 16;
@@ -161,12 +247,12 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
         syy += gy * gy;
         sxy += gx * gy;
       }
+      s_hxx[i] = sxx;
+      s_hyy[i] = syy;
+      s_hxy[i] = sxy;
     }
-    s_hxx[i] = sxx;
-    s_hyy[i] = syy;
-    s_hxy[i] = sxy;
+    __syncthreads();
   }
-  __syncthreads();
 
   // D: vertical sums + response
   const int lx = tid & (RX - 1);
