@@ -29,6 +29,7 @@ import numpy as np  # noqa: E402
 H, W, N_KP, HYP, WIN, MAX_LEVEL = 1241, 1376, 2000, 1000, 15, 2
 N_FRAMES = 8
 REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
+EXCHANGE_EVERY = 8       # frames per all-gather of {pose, landmarks} records (multi-GPU / --exchange)
 PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -111,6 +112,9 @@ def main():
     ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
                     help="one blocking vo_pipeline_step per frame instead of submitting frame k+1 before "
                          "collecting frame k (vo_pipeline_submit / _collect)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="run the per-frame all-gather of {pose, landmarks} records even on one GPU "
+                         "(always on for --gpus > 1); rehearses the multi-GPU step on a single device")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,9 +126,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    exchange = False                     # switched on below, once the pipeline's streams exist and have run
+    want_exchange = world > 1 or args.exchange
 
     from vo import _native, sharding, synthetic
     comp = torch.cuda.Stream()
@@ -139,9 +142,9 @@ def main():
 
     cap = N_KP
     rec_len = sharding.record_length(cap)
-    recs = [torch.zeros(rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
-    gathered = [torch.zeros(world * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
-    comm_done = [None, None]
+    recs = [torch.zeros(EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
+    gathered = [torch.zeros(world * EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
+    batch_fill, batch_buf = 0, 0
 
     order = stream.order(args.warmup + args.steps + 64)
     pipe.prime(order[0])
@@ -167,18 +170,19 @@ def main():
                 r = pipe.collect()
             else:
                 r = pipe.step(a, b)
-            if world > 1:
-                s = k & 1
-                if comm_done[s] is not None:
-                    comp.wait_event(comm_done[s])           # record buffer free again
-                pipe.export_state_dev(r, cap, recs[s].data_ptr())
-                ev = torch.cuda.Event()
-                ev.record(comp)
-                comm.wait_event(ev)
-                with torch.cuda.stream(comm):
-                    sharding.allgather_records(recs[s], gathered[s])
-                    comm_done[s] = torch.cuda.Event()
-                    comm_done[s].record(comm)
+            if exchange:
+                # The record of every collected step is written behind its DLT on the pipeline's own stream
+                # (no host synchronisation); every EXCHANGE_EVERY frames the records gathered so far go to
+                # all ranks in ONE all-gather on the side stream (fewer, larger collectives: the per-call
+                # host cost of a collective is ~45 us, a third of a step).
+                nonlocal batch_fill, batch_buf
+                pipe.export_state_post(r, cap, recs[batch_buf].data_ptr() + batch_fill * rec_len * 8)
+                batch_fill += 1
+                if batch_fill == EXCHANGE_EVERY or k == n - 1:
+                    pipe.export_state_join(comm.cuda_stream)
+                    sharding.allgather_records(recs[batch_buf], gathered[batch_buf])
+                    batch_buf ^= 1
+                    batch_fill = 0
             if record:
                 Tcw = np.linalg.inv(stream.T_world_cam(b))
                 R, t = np.array(r.R).reshape(3, 3), np.array(r.t)
@@ -193,10 +197,23 @@ def main():
                 stats["trans_err"].append(float(np.linalg.norm(t - Tcw[:3, 3])))
 
     def fence():
-        if world > 1:
+        if exchange:
             dist.barrier()
         ctx.sync()
         torch.cuda.synchronize()
+
+    # The process group comes up only now.  HIP spreads streams over four hardware queues in the order they
+    # first run; the pipeline's tracking stream must not end up sharing a queue with a detection stream
+    # (kernels of one hardware queue run in order: measured 8.5k -> 6k frames/s when RCCL's streams were
+    # created first and shifted that assignment), so the pipeline runs a few steps before RCCL exists.
+    run(4)
+    ctx.sync()
+    if want_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        torch.cuda.set_stream(comm)      # the collectives are issued from this stream; the pipeline has its own
+        exchange = True
 
     # untimed: warmup, and one all-kernel event profile to find the dominant kernel
     run(args.warmup)
@@ -268,7 +285,7 @@ def main():
                                    "15x15 -> P3P-RANSAC 1000 hyps -> DLT; one independent sequence per GPU",
                        "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP,
                        "frame_lookahead": 1 if args.lookahead else 0,
-                       "parallelism": "sequence-sharded x%d%s" % (world, ", RCCL all-gather of {pose, landmarks} per frame" if world > 1 else "")},
+                       "parallelism": "sequence-sharded x%d%s" % (world, ", RCCL all-gather of the {pose, landmarks} records of %d frames every %d frames" % (EXCHANGE_EVERY, EXCHANGE_EVERY) if exchange else "")},
             "roofline": roof,
             "per_kernel_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(per_kernel.items())},
             "pose_err": {"rot_fro_median": float(np.median(stats["rot_err"])), "trans_m_median": float(np.median(stats["trans_err"])),
@@ -286,7 +303,7 @@ def main():
         print(json.dumps(out), flush=True)
     pipe.close()
     ctx.close()
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
 
 

@@ -312,11 +312,23 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out);
  * second stream beside tracking).                                                   */
 int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64_t* launches);
 int vo_pipeline_prof_reset(vo_pipeline* p);
-/* Writes this rank's shared-map record for the last step into DEVICE memory (async):
- * [T_cw 4x4 row-major (16) | n (1) | n triangulated landmarks x 3, n <= cap], all f64,
- * 17 + 3*cap doubles.  The caller all-gathers the records over RCCL (bench.py).     */
+/* Shared-map record of the last collected step -> DEVICE memory (async):
+ * [T_cw 4x4 row-major (16, the refined pose) | n (1) | n triangulated landmarks x 3,
+ * n <= cap], all f64, 17 + 3*cap doubles.  The caller all-gathers records over RCCL
+ * (bench.py), one or several frames per collective:
+ *   _post  queues the record behind the step's DLT on the pipeline's own stream and
+ *          returns at once (no synchronisation; steps in flight are not waited for);
+ *   _join  orders the pipeline's stream and `consumer` (hipStream_t; NULL = the
+ *          context's stream) both ways: work enqueued on `consumer` after the call sees
+ *          every record posted so far, and records posted after the call are written
+ *          after everything `consumer` held at the time of the call (an exchange still
+ *          reading the buffer);
+ *   _dev   = join, post, join: one record, usable immediately.                      */
+int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int cap,
+                                  double* d_record);
+int vo_pipeline_export_state_join(vo_pipeline* p, void* consumer);
 int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int cap,
-                                 double* d_record);
+                                 double* d_record, void* consumer);
 /* copies of the last step's device arrays: keypoints of `next` (n_keypoints*2 f64),
  * tracked pairs (n_tracked: prev xy f64, next xy f64, landmark xyz f64), triangulated
  * points (n_tracked*3 f64), inlier mask (n_tracked bytes).  Any pointer may be NULL. */

@@ -40,8 +40,11 @@ struct vo_pipeline {
   std::thread worker;
   std::atomic<unsigned> job_posted{0}, job_done{0};
   std::atomic<bool> quit{false};
-  struct job_t { int kind, frame, slot, ev, which; };   // kind 0: detection of `frame` into keypoint buffer `slot`; 1: DLT of track set `slot`
+  struct job_t { int kind, frame, slot, ev, which; };   // kind 0: detection of `frame` into keypoint buffer `slot`; 1: DLT of track set `slot`;
+                                                        // 2: shared-map record of track set `slot` (behind its DLT)
   job_t jobs[8];
+  struct export_t { double head[17]; int n, cap; double* rec; };   // payload of a kind-2 job (same ring index)
+  export_t exports[8];
   int job_rc = 0;
   int job_which = 0;                 // whose error text goes with job_rc: 0 det, 1 det2, 2 tri
   bool det_warm = false;
@@ -536,6 +539,17 @@ static int enqueue_dlt(vo_pipeline* p, int s) {
   return VO_OK;
 }
 
+// shared-map record of track set `s`, on the DLT's stream right behind it
+static int enqueue_export(vo_pipeline* p, int s, const vo_pipeline::export_t& e) {
+  pose17 h;
+  memcpy(h.v, e.head, sizeof(h.v));
+  const int threads = e.n * 3 > 17 ? e.n * 3 : 17;
+  hipLaunchKernelGGL(export_state_kernel, dim3(vo_cdiv(threads, 256)), dim3(256), 0, p->tri->stream, h, sl_tri(p, s), e.n,
+                     e.cap, e.rec);
+  if (hipGetLastError() != hipSuccess) return vo_set_error(p->tri, VO_EHIP, "launch of export_state_kernel failed");
+  return VO_OK;
+}
+
 // tracking branch (main stream): KLT -> gather -> hypotheses
 static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, int b, int cs, unsigned raw_tag,
                             bool raw_known) {
@@ -595,10 +609,12 @@ static void worker_main(vo_pipeline* p) {
     }
     idle = 0;
     const vo_pipeline::job_t j = p->jobs[seen & 7];
-    const int rc = j.kind == 0 ? enqueue_detection(p, j.frame, j.slot, j.ev, j.which) : enqueue_dlt(p, j.slot);
+    const int rc = j.kind == 0   ? enqueue_detection(p, j.frame, j.slot, j.ev, j.which)
+                   : j.kind == 1 ? enqueue_dlt(p, j.slot)
+                                 : enqueue_export(p, j.slot, p->exports[seen & 7]);
     if (rc != VO_OK) {
       p->job_rc = rc;
-      p->job_which = j.kind == 0 ? j.which : 2;
+      p->job_which = j.kind == 0 ? j.which : 2;   // (DLT and export both run on the tri context)
     }
     ++seen;
     p->job_done.store(seen, std::memory_order_release);
@@ -932,27 +948,48 @@ int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result*
   return vo_pipeline_collect(p, out);
 }
 
-int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record) {
+int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record) {
   if (!p || !r || !d_record) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
   VO_REQUIRE(ctx, cap >= 0, "pipeline_export_state: bad capacity");
-  // the triangulated landmarks of the last collected step: its DLT runs on the detection stream
-  VO_TRY(flush_dlt(p));
-  VO_TRY(worker_idle(p));
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDlt[p->cset_collected], 0));
-  pose17 h;
+  VO_TRY(flush_dlt(p));                                  // the step's DLT job first: the record job follows it in the FIFO
+  const unsigned slot = p->job_posted.load(std::memory_order_relaxed);
+  while (slot - p->job_done.load(std::memory_order_acquire) >= 8) __builtin_ia32_pause();
+  vo_pipeline::export_t& e = p->exports[slot & 7];
   for (int row = 0; row < 3; ++row) {
-    for (int c = 0; c < 3; ++c) h.v[4 * row + c] = r->R[3 * row + c];
-    h.v[4 * row + 3] = r->t[row];
+    for (int c = 0; c < 3; ++c) e.head[4 * row + c] = r->R_refined[3 * row + c];
+    e.head[4 * row + 3] = r->t_refined[row];
   }
-  h.v[12] = h.v[13] = h.v[14] = 0.0;
-  h.v[15] = 1.0;
-  const int n = r->best_index >= 0 ? (r->n_tracked < cap ? r->n_tracked : cap) : 0;
-  h.v[16] = (double)n;
-  const int threads = n * 3 > 17 ? n * 3 : 17;
-  hipLaunchKernelGGL(export_state_kernel, dim3(vo_cdiv(threads, 256)), dim3(256), 0, ctx->stream, h,
-                     sl_tri(p, p->cset_collected), n, cap, d_record);
-  return vo_check_launch(ctx, "export_state_kernel");
+  e.head[12] = e.head[13] = e.head[14] = 0.0;
+  e.head[15] = 1.0;
+  e.n = r->best_index >= 0 ? (r->n_tracked < cap ? r->n_tracked : cap) : 0;
+  e.head[16] = (double)e.n;
+  e.cap = cap;
+  e.rec = d_record;
+  post_job(p, 2, 0, p->cset_collected, 0, 0);
+  return VO_OK;
+}
+
+int vo_pipeline_export_state_join(vo_pipeline* p, void* consumer) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t use = consumer ? (hipStream_t)consumer : ctx->stream;
+  hipStream_t st = p->tri->stream;
+  VO_TRY(worker_idle(p));                                // every posted record has been enqueued; the worker is quiet
+  VO_HIP_TRY(ctx, hipEventRecord(p->evB, st));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(use, p->evB, 0));   // consumer: behind the records
+  VO_HIP_TRY(ctx, hipEventRecord(p->evA, use));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(st, p->evA, 0));    // later records: behind what the consumer holds so far
+  return VO_OK;
+}
+
+int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record, void* consumer) {
+  if (!p) return VO_EINVAL;
+  // (records posted earlier and everything the consumer already holds are ordered before this one)
+  VO_TRY(vo_pipeline_export_state_join(p, consumer));
+  VO_TRY(vo_pipeline_export_state_post(p, r, cap, d_record));
+  return vo_pipeline_export_state_join(p, consumer);
 }
 
 // per-kernel event times accumulated over all of the pipeline's streams

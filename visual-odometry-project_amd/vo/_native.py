@@ -130,7 +130,9 @@ _SIGS = {
     "vo_pipeline_submit": (_i, [_vp, _i, _i]),
     "vo_pipeline_collect": (_i, [_vp, _vp]),
     "vo_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vo_pipeline_export_state_dev": (_i, [_vp, _vp, _i, _vp]),
+    "vo_pipeline_export_state_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "vo_pipeline_export_state_post": (_i, [_vp, _vp, _i, _vp]),
+    "vo_pipeline_export_state_join": (_i, [_vp, _vp]),
     "vo_pipeline_prof_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_int64)]),
     "vo_pipeline_prof_reset": (_i, [_vp]),
 }
@@ -529,8 +531,20 @@ class Pipeline:
     def prof_reset(self):
         self.ctx._chk(self.ctx._lib.vo_pipeline_prof_reset(self._h))
 
-    def export_state_dev(self, result, cap, d_record):
-        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_dev(self._h, C.byref(result), int(cap), C.c_void_p(d_record)))
+    def export_state_dev(self, result, cap, d_record, consumer_stream=None):
+        """Record of the last collected step -> device memory at d_record; `consumer_stream` (raw hipStream_t,
+        default the context's) is the stream the exchange of the record is enqueued on."""
+        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_dev(self._h, C.byref(result), int(cap), C.c_void_p(d_record),
+                                                                 C.c_void_p(consumer_stream or 0)))
+
+    def export_state_post(self, result, cap, d_record):
+        """Queues the record of the last collected step behind its DLT (no synchronisation)."""
+        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_post(self._h, C.byref(result), int(cap), C.c_void_p(d_record)))
+
+    def export_state_join(self, consumer_stream=None):
+        """Orders the records posted so far before later work of `consumer_stream`, and later records after
+        what that stream holds now."""
+        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_join(self._h, C.c_void_p(consumer_stream or 0)))
 
     def fetch(self, n_tracked, want_inliers=True):
         N = self.cfg.n_keypoints
