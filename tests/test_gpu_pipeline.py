@@ -164,3 +164,50 @@ def test_pipeline_stress_configuration_properties(ctx):
         left = np.where(occupied, 0.0, sc)
         assert left.max() <= s[-1]
     pipe.close()
+
+
+def test_pipeline_records_for_the_shared_map(ctx):
+    """vo_pipeline_export_state_post / _join with a step in flight: the record of every collected step
+    [T_cw | n | landmarks] equals the refined pose of its result and what fetch() returns for the same step
+    run blocking (the per-GPU record that is all-gathered)."""
+    from vo import _native, sharding, synthetic
+    H, W, N, hyp, F = 240, 320, 300, 256, 5
+    stream = synthetic.Stream(F, H, W)
+    order = stream.order(8)
+    pairs = list(zip(order[:-1], order[1:]))
+
+    def make():
+        pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp,
+                                p3p_threshold=1.0, max_iterations=1000, refine_iters=10)
+        for i in range(F):
+            pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
+        pipe.prime(order[0])
+        return pipe
+
+    pipe = make()
+    ref = []
+    for a, b in pairs:
+        r = pipe.step(a, b)
+        ref.append((np.array(r.R_refined).reshape(3, 3), np.array(r.t_refined), pipe.fetch(r.n_tracked)["triangulated"]))
+    pipe.close()
+
+    cap = N
+    L = sharding.record_length(cap)
+    recs = ctx.to_device(np.zeros(len(pairs) * L))
+    pipe = make()
+    pipe.submit(*pairs[0])
+    for k in range(len(pairs)):
+        if k + 1 < len(pairs):
+            pipe.submit(*pairs[k + 1])
+        r = pipe.collect()
+        pipe.export_state_post(r, cap, recs + k * L * 8)
+    pipe.export_state_join()                 # consumer = the context's stream, which the download uses
+    host = ctx.download(recs, (len(pairs) * L,), np.float64)
+    pipe.close()
+    ctx.free(recs)
+    got = sharding.unpack_records(host, len(pairs), cap)
+    for (T, lm), (R, t, tri) in zip(got, ref):
+        np.testing.assert_array_equal(T[:3, :3], R)
+        np.testing.assert_array_equal(T[:3, 3], t)
+        np.testing.assert_array_equal(T[3], [0, 0, 0, 1])
+        np.testing.assert_array_equal(lm, tri[:cap])
