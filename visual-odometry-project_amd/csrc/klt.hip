@@ -587,28 +587,43 @@ __device__ __forceinline__ void load_row_bytes(const uint8_t* p, unsigned* w) {
 // rows [0, NR) x bytes [0, NC) of the image block whose top-left pixel is (x0, y0) -> s, pitch
 // PITCH; lane r takes rows r, r + LPK, ...  The block may hang over the image by up to WIN + 4
 // pixels: the level is stored with PYR_PAD pixels of reflected border.
-template <int NC, int NR, int LPK, int PITCH>
-__device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pitch, int x0, int y0, uint8_t* s, int r) {
-  constexpr int PASSES = (NR + LPK - 1) / LPK;
-  unsigned v[PASSES][(NC + 3) / 4];
+// The two halves are separate so that a block can be requested long before it is needed (the template
+// block of the next level while this level iterates, the search region while the template is built).
+template <int NC, int NR, int LPK>
+struct staged_block {
+  static constexpr int PASSES = (NR + LPK - 1) / LPK, WORDS = (NC + 3) / 4;
+  unsigned v[PASSES][WORDS];
+};
+template <int NC, int NR, int LPK>
+__device__ __forceinline__ void stage_load(const uint8_t* __restrict__ img, int pitch, int x0, int y0, int r,
+                                           staged_block<NC, NR, LPK>& b) {
 #pragma unroll
-  for (int pass = 0; pass < PASSES; ++pass) {
+  for (int pass = 0; pass < b.PASSES; ++pass) {
     const int row = r + LPK * pass;
     const bool on = row < NR;
     const uint8_t* src = img + (ptrdiff_t)(y0 + (on ? row : 0)) * pitch + x0;
 #pragma unroll
-    for (int k = 0; k < NC / 4; ++k) v[pass][k] = *(const u32_any*)(src + 4 * k);
-    if (NC & 2) v[pass][NC / 4] = *(const u16_any*)(src + (NC & ~3));
+    for (int k = 0; k < NC / 4; ++k) b.v[pass][k] = *(const u32_any*)(src + 4 * k);
+    if (NC & 2) b.v[pass][NC / 4] = *(const u16_any*)(src + (NC & ~3));
   }
+}
+template <int NC, int NR, int LPK, int PITCH>
+__device__ __forceinline__ void stage_store(const staged_block<NC, NR, LPK>& b, uint8_t* s, int r) {
 #pragma unroll
-  for (int pass = 0; pass < PASSES; ++pass) {
+  for (int pass = 0; pass < b.PASSES; ++pass) {
     const int row = r + LPK * pass;
     if (row < NR) {
       unsigned* d = reinterpret_cast<unsigned*>(s + row * PITCH);
 #pragma unroll
-      for (int k = 0; k < (NC + 3) / 4; ++k) d[k] = v[pass][k];
+      for (int k = 0; k < b.WORDS; ++k) d[k] = b.v[pass][k];
     }
   }
+}
+template <int NC, int NR, int LPK, int PITCH>
+__device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pitch, int x0, int y0, uint8_t* s, int r) {
+  staged_block<NC, NR, LPK> b;
+  stage_load<NC, NR, LPK>(img, pitch, x0, y0, r, b);
+  stage_store<NC, NR, LPK, PITCH>(b, s, r);
 }
 
 template <int WIN, int LPK>
@@ -636,11 +651,25 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   float e_out = 0.f;
   float nx = 0.f, ny = 0.f;
 
+  // Template blocks depend on the previous keypoint only, so the block of level l - 1 is requested
+  // while level l is being worked on (tplI holds the block of the level about to start).
+  staged_block<n3, n3, LPK> tplI;
+  auto request_template = [&](int level) {
+    const float sc = (float)(1. / (double)(1 << level));
+    const float px = p0x * sc - half, py = p0y * sc - half;
+    int ipx = (int)floorf(px), ipy = (int)floorf(py);
+    ipx = min(max(ipx, -win), P.W[level] - 1);       // (a level whose block would leave the border is skipped below)
+    ipy = min(max(ipy, -win), P.H[level] - 1);
+    stage_load<n3, n3, LPK>(P.prev[level], P.pitch[level], ipx - 1, ipy - 1, r, tplI);
+  };
+  request_template(P.n_levels - 1);
+
   for (int level = P.n_levels - 1; level >= 0; --level) {
-    const uint8_t* I = P.prev[level];
     const uint8_t* J = P.next[level];
     const int H = P.H[level], W = P.W[level], pitch = P.pitch[level];
     const float sc = (float)(1. / (double)(1 << level));
+    const staged_block<n3, n3, LPK> curI = tplI;
+    if (level > 0) request_template(level - 1);
     float px = p0x * sc, py = p0y * sc;
     float qx, qy;
     if (level == P.n_levels - 1) {
@@ -667,9 +696,17 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
     // (w11 = 2^14 - w00 - w01 - w10 can come out as -1: the packed weights are signed 16-bit halves)
     unsigned wa = ((unsigned)w00 & 0xffffu) | ((unsigned)w01 << 16), wb = ((unsigned)w10 & 0xffffu) | ((unsigned)w11 << 16);
 
+    // the search region around the starting guess is requested now and lands while the template is built
+    qx -= half;
+    qy -= half;
+    int rx0 = (int)floorf(qx) - KLT_MARGIN, ry0 = (int)floorf(qy) - KLT_MARGIN;
+    const bool first_in = rx0 + KLT_MARGIN >= -win && rx0 + KLT_MARGIN < W && ry0 + KLT_MARGIN >= -win && ry0 + KLT_MARGIN < H;
+    staged_block<RS, RS, LPK> regJ;
+    stage_load<RS, RS, LPK>(J, pitch, first_in ? rx0 : 0, first_in ? ry0 : 0, r, regJ);
+
     // ---- template: image block, Scharr derivatives, interpolated patch (all in registers) ----
     wave_sync();
-    stage16<n3, n3, LPK, K16_PITCH>(I, pitch, ipx - 1, ipy - 1, s_reg, r);
+    stage_store<n3, n3, LPK, K16_PITCH>(curI, s_reg, r);
     wave_sync();
     int tI[win], tX[win], tY[win];
     int a11 = 0, a12 = 0, a22 = 0;   // per-lane partial sums stay below 2^31
@@ -736,13 +773,16 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
       continue;
     }
     D = 1.f / D;
-    qx -= half;
-    qy -= half;
     float pdx = 0.f, pdy = 0.f;
-    // search region of `next`: staged once with KLT_MARGIN pixels of slack, re-staged
+    // search region of `next`: staged once with KLT_MARGIN pixels of slack (requested above), re-staged
     // only when the window walks out of it
-    int rx0 = 0, ry0 = 0;
     bool staged = false;
+    if (first_in) {
+      wave_sync();
+      stage_store<RS, RS, LPK, K16_PITCH>(regJ, s_reg, r);
+      wave_sync();
+      staged = true;
+    }
     for (int j = 0; j < max_iter; ++j) {
       const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
       if (iqx < -win || iqx >= W || iqy < -win || iqy >= H) {
