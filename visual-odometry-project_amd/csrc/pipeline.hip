@@ -68,6 +68,7 @@ struct vo_pipeline {
   int prev_frame = -1;
   double* d_scores = nullptr;
   double* d_scores2 = nullptr;       // score map of the second detection stream
+  double* d_land_all[3] = {nullptr, nullptr, nullptr};   // landmark of every keypoint of the slot's frame (N x 3)
   float *d_kp_f32[3] = {nullptr, nullptr, nullptr}, *d_next_f32 = nullptr, *d_err = nullptr;   // d_kp as float pairs
   uint8_t* d_status = nullptr;
   // compacted tracks, two sets: the deferred DLT of step k reads set k&1 while step k+1 fills the other
@@ -130,31 +131,46 @@ struct vo_pipeline {
 
 namespace {
 
+// Landmark of every detected keypoint of a frame, X_w = T_wc * (depth * K^-1 (x, y, 1)), computed behind
+// the detection (off the tracking chain): the gather below then needs a single round trip to memory.
+__global__ __launch_bounds__(256) void keypoint_landmarks_kernel(const double* __restrict__ kp, int N,
+                                                                 const float* __restrict__ depth, int H, int W,
+                                                                 double fx, double fy, double cx, double cy,
+                                                                 const double* __restrict__ T_wc,
+                                                                 double* __restrict__ land) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double x = kp[2 * i], y = kp[2 * i + 1];
+  int xi = (int)x, yi = (int)y;
+  xi = min(max(xi, 0), W - 1);
+  yi = min(max(yi, 0), H - 1);
+  const double z = (double)depth[(size_t)yi * W + xi];
+  const double xc = (x - cx) / fx * z, yc = (y - cy) / fy * z;
+  land[3 * i] = T_wc[0] * xc + T_wc[1] * yc + T_wc[2] * z + T_wc[3];
+  land[3 * i + 1] = T_wc[4] * xc + T_wc[5] * yc + T_wc[6] * z + T_wc[7];
+  land[3 * i + 2] = T_wc[8] * xc + T_wc[9] * yc + T_wc[10] * z + T_wc[11];
+}
+
 // Keeps tracks with status != 0 and err < thr in their original order (the boolean
-// mask of klt.py:244-269), converts to float64 and looks the landmark of each
-// previous keypoint up in the depth map:  X_w = T_wc * (depth * K^-1 (x, y, 1)).
+// mask of klt.py:244-269), converts to float64 and carries the landmark of each
+// previous keypoint along (keypoint_landmarks_kernel).
 __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __restrict__ kp_prev,
                                                              const float* __restrict__ next_xy,
                                                              const uint8_t* __restrict__ status,
                                                              const float* __restrict__ err, int N, float err_thr,
-                                                             const float* __restrict__ depth, int H, int W, double fx,
-                                                             double fy, double cx, double cy,
-                                                             const double* __restrict__ T_wc,
+                                                             const double* __restrict__ land_prev,
                                                              double* __restrict__ prev_c, double* __restrict__ next_c,
                                                              double* __restrict__ land_c, int32_t* __restrict__ n_out) {
   // All loads of up to four passes (4096 keypoints) go out before anything is consumed: one
-  // round trip for the tracker's outputs, one for the depth look-ups that depend on them.
+  // round trip to memory.
   constexpr int GE = 4;
   __shared__ int s_w[GE][16];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) s_base = 0;
-  double Tm[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) Tm[k] = T_wc[k];
   for (int c0 = 0; c0 < N; c0 += GE * 1024) {
     bool keep[GE];
-    double x[GE], y[GE], z[GE];
+    double x[GE], y[GE], lx[GE], ly[GE], lz[GE];
     float nxv[GE], nyv[GE];
 #pragma unroll
     for (int k = 0; k < GE; ++k) {
@@ -166,13 +182,9 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
       y[k] = kp_prev[2 * ii + 1];
       nxv[k] = next_xy[2 * ii];
       nyv[k] = next_xy[2 * ii + 1];
-    }
-#pragma unroll
-    for (int k = 0; k < GE; ++k) {
-      int xi = (int)x[k], yi = (int)y[k];
-      xi = min(max(xi, 0), W - 1);
-      yi = min(max(yi, 0), H - 1);
-      z[k] = (double)depth[(size_t)yi * W + xi];
+      lx[k] = land_prev[3 * ii];
+      ly[k] = land_prev[3 * ii + 1];
+      lz[k] = land_prev[3 * ii + 2];
     }
     unsigned long long m[GE];
 #pragma unroll
@@ -195,10 +207,9 @@ __global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __res
         prev_c[2 * o + 1] = y[k];
         next_c[2 * o] = (double)nxv[k];
         next_c[2 * o + 1] = (double)nyv[k];
-        const double xc = (x[k] - cx) / fx * z[k], yc = (y[k] - cy) / fy * z[k];
-        land_c[3 * o] = Tm[0] * xc + Tm[1] * yc + Tm[2] * z[k] + Tm[3];
-        land_c[3 * o + 1] = Tm[4] * xc + Tm[5] * yc + Tm[6] * z[k] + Tm[7];
-        land_c[3 * o + 2] = Tm[8] * xc + Tm[9] * yc + Tm[10] * z[k] + Tm[11];
+        land_c[3 * o] = lx[k];
+        land_c[3 * o + 1] = ly[k];
+        land_c[3 * o + 2] = lz[k];
       }
     }
     __syncthreads();
@@ -360,6 +371,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     PA(dev_alloc(ctx, &p->d_pyr[k], p->pyr_bytes));
     PA(dev_alloc(ctx, &p->d_kp[k], (size_t)N * 2));
     PA(dev_alloc(ctx, &p->d_kp_f32[k], (size_t)N * 2));
+    PA(dev_alloc(ctx, &p->d_land_all[k], (size_t)N * 3));
   }
   PA(dev_alloc(ctx, &p->d_scores, px));
   PA(dev_alloc(ctx, &p->d_scores2, px));
@@ -455,7 +467,8 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     p->worker.join();
   }
   void* dev[] = {p->d_T_wc, p->d_pyr[0], p->d_pyr[1], p->d_pyr[2], p->d_kp[0], p->d_kp[1], p->d_kp[2], p->d_scores,
-                 p->d_scores2, p->d_kp_f32[0], p->d_kp_f32[1], p->d_kp_f32[2],
+                 p->d_scores2, p->d_kp_f32[0], p->d_kp_f32[1], p->d_kp_f32[2], p->d_land_all[0], p->d_land_all[1],
+                 p->d_land_all[2],
                  p->d_next_f32, p->d_err, p->d_status, p->d_prev_c[0], p->d_next_c[0], p->d_land_c[0], p->d_prev_c[1],
                  p->d_next_c[1], p->d_land_c[1], p->d_tri,
                  p->d_ntracked, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks};
@@ -521,6 +534,12 @@ static int enqueue_detection(vo_pipeline* p, int frame, int slot, int ev, int wh
   det->nms_kp_f32 = p->d_kp_f32[slot];   // the tracker's float copy of the keypoints
   int rc = vo_harris_response_dev(det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, scores);
   if (rc == VO_OK) rc = vo_nms_keypoints_dev(det, scores, c.H, c.W, c.n_keypoints, c.nms_radius, p->d_kp[slot]);
+  if (rc == VO_OK) {
+    hipLaunchKernelGGL(keypoint_landmarks_kernel, dim3(vo_cdiv(c.n_keypoints, 256)), dim3(256), 0, det->stream,
+                       p->d_kp[slot], c.n_keypoints, p->d_depth[frame], c.H, c.W, c.K[0], c.K[4], c.K[2], c.K[5],
+                       p->d_T_wc + (size_t)frame * 16, p->d_land_all[slot]);
+    rc = vo_check_launch(det, "keypoint_landmarks_kernel");
+  }
   if (rc == VO_OK && hipEventRecord(p->evDet[ev], det->stream) != hipSuccess) rc = VO_EHIP;
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(det));
   return VO_OK;
@@ -556,7 +575,6 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
   const int N = c.n_keypoints;
-  const double fx = c.K[0], fy = c.K[4], cx = c.K[2], cy = c.K[5];
   VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
                           p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
@@ -565,9 +583,8 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
   {
     vo_prof_scope ps(ctx, VO_K_GATHER);
     hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->d_kp[a], p->d_next_f32,
-                       p->d_status, p->d_err, N, (float)c.klt_err_threshold, p->d_depth[prev_idx], c.H, c.W, fx, fy, cx,
-                       cy, p->d_T_wc + (size_t)prev_idx * 16, p->d_prev_c[cs], p->d_next_c[cs], p->d_land_c[cs],
-                       sl_nt(p, cs));
+                       p->d_status, p->d_err, N, (float)c.klt_err_threshold, p->d_land_all[a], p->d_prev_c[cs],
+                       p->d_next_c[cs], p->d_land_c[cs], sl_nt(p, cs));
   }
   VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
   // where the generator outputs start: known now (passed by value), or published later by the
