@@ -45,9 +45,9 @@ def algorithmic_bytes(kernel_name, n_tracked):
         "nms_round": N_KP * 4 * 2,                            # state words of the picks (list traffic is not compulsory)
         "nms_rank": N_KP * 12,
         "nms_select": N_KP * 16,                              # keypoints written
-        "pyr_down": (2 * px + px // 4 + px // 4 + px // 16) // 3,   # per launch (3 launches): bordered copy of level 0, levels 1 and 2
+        "pyr_down": 2 * px + px // 4 + px // 16,              # one launch: frame read, bordered copy of level 0, levels 1 and 2 written
         "klt_track": N_KP * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + N_KP * (8 + 8 + 1 + 4),
-        "track_gather": N_KP * (8 + 1 + 4 + 16) + n_tracked * (16 + 16 + 24 + 4),
+        "track_gather": N_KP * (8 + 1 + 4 + 16 + 24) + n_tracked * (16 + 16 + 24),
         "p3p_solve": HYP * (16 + 4 * 40 + 96 + 1),
         "p3p_score": n_tracked * 40 + HYP * (96 + 1 + 4 + ((n_tracked + 63) // 64) * 8),
         "dlt_triangulate": n_tracked * (16 + 16 + 24) + 192,
@@ -287,6 +287,12 @@ def main():
                        "frame_lookahead": 1 if args.lookahead else 0,
                        "parallelism": "sequence-sharded x%d%s" % (world, ", RCCL all-gather of the {pose, landmarks} records of %d frames every %d frames" % (EXCHANGE_EVERY, EXCHANGE_EVERY) if exchange else "")},
             "roofline": roof,
+            # the image-wide (streaming) kernels against the same HBM peak, from the untimed all-kernel event pass
+            "roofline_streaming": {k: {"avg_launch_us": round(per_kernel[k][0] / per_kernel[k][1] * 1e3, 2),
+                                       "algorithmic_bytes_per_launch": algorithmic_bytes(k, ntr),
+                                       "achieved": round(algorithmic_bytes(k, ntr) / (per_kernel[k][0] / per_kernel[k][1] * 1e-3) / 1e9, 1),
+                                       "frac": round(algorithmic_bytes(k, ntr) / (per_kernel[k][0] / per_kernel[k][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                   for k in ("harris_response", "nms_candidates", "pyr_down") if k in per_kernel},
             "per_kernel_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(per_kernel.items())},
             "pose_err": {"rot_fro_median": float(np.median(stats["rot_err"])), "trans_m_median": float(np.median(stats["trans_err"])),
                          "tracked_median": float(np.median(stats["tracked"])), "inliers_median": float(np.median(stats["inliers"])),
