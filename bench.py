@@ -47,8 +47,9 @@ def algorithmic_bytes(kernel_name, n_tracked):
         "nms_select": N_KP * 16,                              # keypoints written
         "pyr_down": 2 * px + px // 4 + px // 16,              # one launch: frame read, bordered copy of level 0, levels 1 and 2 written
         "klt_track": N_KP * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + N_KP * (8 + 8 + 1 + 4),
-        "track_gather": N_KP * (8 + 1 + 4 + 16 + 24) + n_tracked * (16 + 16 + 24),
-        "p3p_solve": HYP * (16 + 4 * 40 + 96 + 1),
+        # (flags of all keypoints per workgroup are re-reads, not compulsory) selection of the tracked keypoints
+        # + compacted arrays, then samples, poses, valid flags
+        "p3p_solve": N_KP * (1 + 4 + 8 + 16 + 24) + n_tracked * (16 + 16 + 24) + HYP * (28 + 4 * 32 + 96 + 1),
         "p3p_score": n_tracked * 40 + HYP * (96 + 1 + 4 + ((n_tracked + 63) // 64) * 8),
         "dlt_triangulate": n_tracked * (16 + 16 + 24) + 192,
         "refine_pose": n_tracked * 40 + ((n_tracked + 63) // 64) * 8 + 96 + 120,   # points + mask row once, pose in / out

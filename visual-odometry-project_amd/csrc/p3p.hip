@@ -188,6 +188,25 @@ __device__ __forceinline__ unsigned bounded_from_raw(unsigned raw, unsigned rng,
   return (unsigned)(m >> 32);
 }
 
+// Tracks straight from the tracker's outputs (pipeline): with status != nullptr the solve kernel selects
+// the tracked keypoints itself -- status != 0 and err < err_thr, in their original order (the boolean
+// mask of klt.py:244-269) -- instead of reading arrays a separate kernel compacted: every workgroup
+// builds the bit masks and their prefix counts (one round trip, overlapping the generator words it
+// waits for anyway), maps its sample positions through them, and writes its share of the compacted
+// arrays (prev_c, next_c, land_c, *n_out) for the kernels that follow.
+struct p3p_tracks {
+  const uint8_t* status = nullptr;
+  const float* err = nullptr;
+  float err_thr = 0.f;
+  int N = 0;                        // keypoints (<= P3P_TRACK_CHUNKS * 64)
+  const double* kp_prev = nullptr;  // N x 2
+  const float* next_xy = nullptr;   // N x 2
+  const double* land_all = nullptr; // N x 3
+  double *prev_c = nullptr, *next_c = nullptr, *land_c = nullptr;
+  int* n_out = nullptr;
+};
+constexpr int P3P_TRACK_CHUNKS = 256;   // 64 keypoints each: 16384
+
 // RAW == false: sample indices are given.
 // RAW == true : hypothesis h derives its sample from generator outputs raws[7h .. 7h+6] and the
 //   population size *d_n, both of which may still be in flight when the kernel is enqueued:
@@ -204,13 +223,76 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
                                                        int Hyp, double fx,
                                                        double fy, double cx, double cy, double* __restrict__ Rout,
                                                        double* __restrict__ tout, uint8_t* __restrict__ valid,
-                                                       double* __restrict__ Rhost, double* __restrict__ thost) {
+                                                       double* __restrict__ Rhost, double* __restrict__ thost,
+                                                       p3p_tracks T) {
   // Rhost / thost (optional, mapped host memory): the poses are also written there, so the host
   // finds the winner's without a copy kernel moving all of them.
   // four lanes (a DPP quad) per hypothesis: the set-up and the quartic are computed by all four,
   // then lane `sub` takes root `sub` through the triad alignment and the fourth-point test
   const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = gt >> 2, sub = gt & 3;
+  __shared__ unsigned long long s_tmask[RAW ? P3P_TRACK_CHUNKS : 1];
+  __shared__ int s_tpref[RAW ? P3P_TRACK_CHUNKS + 1 : 1];
+  int n_tracks = 0;
+  const bool own_tracks = RAW && T.status != nullptr;
+  if (RAW && own_tracks) {
+    const int lane = threadIdx.x;
+    const int chunks = (T.N + 63) >> 6;
+    // masks: 32 chunks' flags are requested together (one round trip per group)
+    for (int c0 = 0; c0 < chunks; c0 += 32) {
+      uint8_t st[32];
+      float er[32];
+      // (unconditional loads at clamped indices and non-short-circuit flags: with `&&` the compiler
+      //  nests the second load under the first and the 64 requests become 32 dependent round trips)
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const int i = min((c0 + k) * 64 + lane, T.N - 1);
+        st[k] = T.status[i];
+        er[k] = T.err[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const int i = (c0 + k) * 64 + lane;
+        const int keep = (int)(i < T.N) & (int)(st[k] != 0) & (int)(er[k] < T.err_thr);
+        const unsigned long long m = __ballot(keep != 0);
+        if (lane == 0 && c0 + k < chunks) s_tmask[c0 + k] = m;
+      }
+    }
+    __syncthreads();
+    // exclusive prefix counts over the chunks (64 chunks per pass, wave scan)
+    int base = 0;
+    for (int c0 = 0; c0 < chunks; c0 += 64) {
+      const int c = c0 + lane;
+      const int cnt = c < chunks ? __popcll(s_tmask[c]) : 0;
+      int inc = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      if (c < chunks) s_tpref[c] = base + inc - cnt;
+      base += __shfl(inc, 63);
+    }
+    n_tracks = base;
+    if (lane == 0) s_tpref[chunks] = base;
+    __syncthreads();
+    // this workgroup's share of the compacted arrays
+    for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
+      const unsigned long long m = s_tmask[c];
+      const int i = c * 64 + lane;
+      if ((m >> lane) & 1ull) {
+        const int o = s_tpref[c] + __popcll(m & ((1ull << lane) - 1ull));
+        T.prev_c[2 * o] = T.kp_prev[2 * i];
+        T.prev_c[2 * o + 1] = T.kp_prev[2 * i + 1];
+        T.next_c[2 * o] = (double)T.next_xy[2 * i];
+        T.next_c[2 * o + 1] = (double)T.next_xy[2 * i + 1];
+        T.land_c[3 * o] = T.land_all[3 * i];
+        T.land_c[3 * o + 1] = T.land_all[3 * i + 1];
+        T.land_c[3 * o + 2] = T.land_all[3 * i + 2];
+      }
+    }
+    if (gt == 0) T.n_out[0] = n_tracks;
+  }
   if (RAW && rawctl) {
     // Where this step's outputs start in the host's look-ahead buffer is known once the previous
     // step's consumption is: the host publishes {tag, position} in mapped memory, normally long
@@ -237,7 +319,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
   if (h >= Hyp) return;                 // whole quads leave together
   int sidx[4];
   if (RAW) {
-    const int n = *d_n;
+    const int n = own_tracks ? n_tracks : *d_n;
     if (n < 8) {
       if (gt == 0) atomicOr(flag, 1u);
       if (sub == 0) {
@@ -278,14 +360,48 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
     for (int k = 0; k < 4; ++k) sidx[k] = samples[4 * h + k];
   }
   double P[4][3], px[4][2];
+  if (RAW && own_tracks) {
+    // position among the tracked keypoints -> keypoint: the chunk by bisection over the prefix counts,
+    // the bit inside its mask by bisection over popcounts
+    const int chunks = (T.N + 63) >> 6;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int idx = sidx[k];
-    P[k][0] = Xw[3 * idx];
-    P[k][1] = Xw[3 * idx + 1];
-    P[k][2] = Xw[3 * idx + 2];
-    px[k][0] = xi[2 * idx];
-    px[k][1] = xi[2 * idx + 1];
+    for (int k = 0; k < 4; ++k) {
+      const int pos = sidx[k];
+      int lo = 0, hi = chunks;              // s_tpref[lo] <= pos < s_tpref[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_tpref[mid] <= pos) lo = mid;
+        else hi = mid;
+      }
+      unsigned long long m = s_tmask[lo];
+      int want = pos - s_tpref[lo];         // the want-th set bit of m
+      int bit = 0;
+#pragma unroll
+      for (int w = 32; w >= 1; w >>= 1) {
+        const int c = __popcll(m & ((1ull << w) - 1ull));
+        if (want >= c) {
+          want -= c;
+          m >>= w;
+          bit += w;
+        }
+      }
+      const int idx = lo * 64 + bit;
+      P[k][0] = T.land_all[3 * idx];
+      P[k][1] = T.land_all[3 * idx + 1];
+      P[k][2] = T.land_all[3 * idx + 2];
+      px[k][0] = (double)T.next_xy[2 * idx];
+      px[k][1] = (double)T.next_xy[2 * idx + 1];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = sidx[k];
+      P[k][0] = Xw[3 * idx];
+      P[k][1] = Xw[3 * idx + 1];
+      P[k][2] = Xw[3 * idx + 2];
+      px[k][0] = xi[2 * idx];
+      px[k][1] = xi[2 * idx + 1];
+    }
   }
   double f[3][3];
   for (int i = 0; i < 3; ++i) {
@@ -469,18 +585,37 @@ __global__ __launch_bounds__(256) void reproj_kernel(const double* __restrict__ 
 int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
                               const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
                               int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
-                              uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t) {
+                              uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t,
+                              const vo_track_source* tracks) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, d_X && d_x && d_n && K && d_raws && d_R && d_t && d_valid && d_counts && d_flag,
              "p3p_hypotheses_raw: null pointer");
   VO_REQUIRE(ctx, n_cap >= 4 && Hyp >= 1, "p3p_hypotheses_raw: need n_cap >= 4 and Hyp >= 1");
   VO_REQUIRE(ctx, K[0] != 0.0 && K[4] != 0.0, "p3p_hypotheses_raw: singular intrinsics");
   const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  p3p_tracks T;
+  if (tracks) {
+    VO_REQUIRE(ctx, tracks->status && tracks->err && tracks->kp_prev && tracks->next_xy && tracks->land_all,
+               "p3p_hypotheses_raw: incomplete track source");
+    VO_REQUIRE(ctx, tracks->N >= 1 && tracks->N <= P3P_TRACK_CHUNKS * 64 && tracks->N <= n_cap,
+               "p3p_hypotheses_raw: track source holds %d keypoints (1..%d)", tracks->N, P3P_TRACK_CHUNKS * 64);
+    T.status = tracks->status;
+    T.err = tracks->err;
+    T.err_thr = tracks->err_thr;
+    T.N = tracks->N;
+    T.kp_prev = tracks->kp_prev;
+    T.next_xy = tracks->next_xy;
+    T.land_all = tracks->land_all;
+    T.prev_c = tracks->prev_c;
+    T.next_c = const_cast<double*>(d_x);
+    T.land_c = const_cast<double*>(d_X);
+    T.n_out = const_cast<int*>(d_n);
+  }
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<true>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
                        (const int*)nullptr, d_raws, d_rawctl, raw_tag, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t,
-                       d_valid, m_R, m_t);
+                       d_valid, m_R, m_t, T);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   {
@@ -506,7 +641,8 @@ int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<false>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
                        d_samples, (const unsigned*)nullptr, (const unsigned*)nullptr, 0u, (const int*)nullptr,
-                       (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid, (double*)nullptr, (double*)nullptr);
+                       (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid, (double*)nullptr, (double*)nullptr,
+                       p3p_tracks());
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   const int words = vo_cdiv(N, 64);

@@ -151,77 +151,6 @@ __global__ __launch_bounds__(256) void keypoint_landmarks_kernel(const double* _
   land[3 * i + 2] = T_wc[8] * xc + T_wc[9] * yc + T_wc[10] * z + T_wc[11];
 }
 
-// Keeps tracks with status != 0 and err < thr in their original order (the boolean
-// mask of klt.py:244-269), converts to float64 and carries the landmark of each
-// previous keypoint along (keypoint_landmarks_kernel).
-__global__ __launch_bounds__(1024) void gather_tracks_kernel(const double* __restrict__ kp_prev,
-                                                             const float* __restrict__ next_xy,
-                                                             const uint8_t* __restrict__ status,
-                                                             const float* __restrict__ err, int N, float err_thr,
-                                                             const double* __restrict__ land_prev,
-                                                             double* __restrict__ prev_c, double* __restrict__ next_c,
-                                                             double* __restrict__ land_c, int32_t* __restrict__ n_out) {
-  // All loads of up to four passes (4096 keypoints) go out before anything is consumed: one
-  // round trip to memory.
-  constexpr int GE = 4;
-  __shared__ int s_w[GE][16];
-  __shared__ int s_base;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) s_base = 0;
-  for (int c0 = 0; c0 < N; c0 += GE * 1024) {
-    bool keep[GE];
-    double x[GE], y[GE], lx[GE], ly[GE], lz[GE];
-    float nxv[GE], nyv[GE];
-#pragma unroll
-    for (int k = 0; k < GE; ++k) {
-      const int i = c0 + k * 1024 + tid;
-      const bool in = i < N;
-      const int ii = in ? i : 0;
-      keep[k] = in && status[ii] != 0 && err[ii] < err_thr;
-      x[k] = kp_prev[2 * ii];
-      y[k] = kp_prev[2 * ii + 1];
-      nxv[k] = next_xy[2 * ii];
-      nyv[k] = next_xy[2 * ii + 1];
-      lx[k] = land_prev[3 * ii];
-      ly[k] = land_prev[3 * ii + 1];
-      lz[k] = land_prev[3 * ii + 2];
-    }
-    unsigned long long m[GE];
-#pragma unroll
-    for (int k = 0; k < GE; ++k) {
-      m[k] = __ballot(keep[k]);
-      if (lane == 0) s_w[k][wv] = __popcll(m[k]);
-    }
-    __syncthreads();
-    int off = s_base;
-#pragma unroll
-    for (int k = 0; k < GE; ++k) {
-      int mine = off;
-      for (int w = 0; w < 16; ++w) {
-        if (w < wv) mine += s_w[k][w];
-        off += s_w[k][w];
-      }
-      if (keep[k]) {
-        const int o = mine + __popcll(m[k] & ((1ull << lane) - 1ull));
-        prev_c[2 * o] = x[k];
-        prev_c[2 * o + 1] = y[k];
-        next_c[2 * o] = (double)nxv[k];
-        next_c[2 * o + 1] = (double)nyv[k];
-        land_c[3 * o] = lx[k];
-        land_c[3 * o + 1] = ly[k];
-        land_c[3 * o + 2] = lz[k];
-      }
-    }
-    __syncthreads();
-    if (tid == 0) s_base = off;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    n_out[0] = s_base;
-    n_out[2] = 0;           // "sampler needs the sequential path" flag of the solve kernel that follows
-  }
-}
-
 // Copies the hypotheses' (valid, count, R, t) into mapped host memory and then publishes a
 // sequence number: the host polls that word, which costs far less than an event wait.
 __global__ __launch_bounds__(256) void mirror_hypotheses_kernel(const uint8_t* __restrict__ valid,
@@ -233,12 +162,13 @@ __global__ __launch_bounds__(256) void mirror_hypotheses_kernel(const uint8_t* _
                                                                 unsigned* __restrict__ seq_host,
                                                                 const unsigned* __restrict__ seq_expect,
                                                                 unsigned* __restrict__ done,
-                                                                const int32_t* __restrict__ n_flag,
+                                                                int32_t* __restrict__ n_flag,
                                                                 int32_t* __restrict__ h_n_flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0 && n_flag) {
     h_n_flag[0] = n_flag[0];   // tracked count
     h_n_flag[2] = n_flag[2];   // sampler flag
+    n_flag[2] = 0;             // (the slot's next solve kernel raises it again if it has to)
   }
   const int stride = gridDim.x * blockDim.x;
   for (int k = i; k < hyp; k += stride) {
@@ -578,15 +508,19 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
   VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
                           p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
-  // the track set this gather fills was the input of the DLT of two steps ago
+  // the track set this step fills was the input of the DLT of two steps ago
   if (hipEventQuery(p->evDlt[cs]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDlt[cs], 0));
-  {
-    vo_prof_scope ps(ctx, VO_K_GATHER);
-    hipLaunchKernelGGL(gather_tracks_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->d_kp[a], p->d_next_f32,
-                       p->d_status, p->d_err, N, (float)c.klt_err_threshold, p->d_land_all[a], p->d_prev_c[cs],
-                       p->d_next_c[cs], p->d_land_c[cs], sl_nt(p, cs));
-  }
-  VO_TRY(vo_check_launch(ctx, "gather_tracks_kernel"));
+  // The solve kernel selects the tracked keypoints itself (no separate gather launch on the chain) and
+  // leaves the compacted arrays and the count for the kernels behind it.
+  vo_track_source src;
+  src.status = p->d_status;
+  src.err = p->d_err;
+  src.err_thr = (float)c.klt_err_threshold;
+  src.N = N;
+  src.kp_prev = p->d_kp[a];
+  src.next_xy = p->d_next_f32;
+  src.land_all = p->d_land_all[a];
+  src.prev_c = p->d_prev_c[cs];
   // where the generator outputs start: known now (passed by value), or published later by the
   // collect of the step before (the kernel polls the mapped word)
   VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], sl_nt(p, cs), N, c.K,
@@ -595,7 +529,7 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
                                    raw_tag, c.hyp, c.p3p_thr_sq, sl_R(p, cs),
                                    sl_t(p, cs), sl_valid(p, cs), sl_counts(p, cs), sl_masks(p, cs),
                                    (uint32_t*)sl_nt(p, cs) + 2, p->m_R + (size_t)cs * c.hyp * 9,
-                                   p->m_t + (size_t)cs * c.hyp * 3));
+                                   p->m_t + (size_t)cs * c.hyp * 3, &src));
   return VO_OK;
 }
 
@@ -607,7 +541,7 @@ static int launch_mirror(vo_pipeline* p, int s, bool with_count, hipStream_t st)
                      sl_R(p, s), sl_t(p, s), c.hyp, p->m_valid + h, p->m_counts + h,
                      with_count ? (double*)nullptr : p->m_R + h * 9, with_count ? (double*)nullptr : p->m_t + h * 3,
                      p->m_seq + 4 * s + 1, p->m_seq + 4 * s + 2, (unsigned*)sl_nt(p, s) + 1,
-                     with_count ? (const int32_t*)sl_nt(p, s) : (const int32_t*)nullptr, p->m_ntracked + 4 * s);
+                     with_count ? sl_nt(p, s) : (int32_t*)nullptr, p->m_ntracked + 4 * s);
   return vo_check_launch(p->ctx, "mirror_hypotheses_kernel");
 }
 

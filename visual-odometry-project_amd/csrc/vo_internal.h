@@ -104,11 +104,23 @@ static inline int vo_cdiv(int a, int b) { return (a + b - 1) / b; }
 // and a device-resident population size (p3p.hip).
 // d_rawctl (optional, mapped host memory): {tag, offset}; the kernel waits (bounded) until the tag
 // equals raw_tag and reads its outputs from d_raws + offset.
+struct vo_track_source {   // tracker outputs the solve kernel selects the tracked keypoints from (p3p.hip)
+  const uint8_t* status;
+  const float* err;
+  float err_thr;
+  int N;
+  const double* kp_prev;     // N x 2
+  const float* next_xy;      // N x 2
+  const double* land_all;    // N x 3
+  double* prev_c;            // compacted previous keypoints (the next ones and the landmarks go to d_x / d_X, the count to d_n)
+};
 int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
                               const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
                               int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
-                              uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t);
+                              uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t,
+                              const vo_track_source* tracks);
 // m_R / m_t (optional, mapped host memory): every pose is also written there.
+// tracks (optional): d_X / d_x / *d_n are then OUTPUTS too -- the kernel compacts the tracked keypoints itself.
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
 void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
 // DLT with a device-resident point count (dlt.hip)
