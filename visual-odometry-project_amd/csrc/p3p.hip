@@ -99,16 +99,29 @@ __device__ int quartic_roots(double c0, double c1, double c2, double c3, double 
   const double p = a2 - 0.375 * a3sq;
   const double q = a1 - 0.5 * a2 * a3 + 0.125 * a3sq * a3;
   const double r = a0 - 0.25 * a1 * a3 + 0.0625 * a2 * a3sq - (3.0 / 256.0) * a3sq * a3sq;
-  double y[4] = {0.0, 0.0, 0.0, 0.0};
+  // the (up to four) roots of the depressed quartic in the order the oracle lists them; scalars, not an
+  // array filled through a running index (that array lived in scratch memory: a memory round trip in the
+  // middle of the dependent chain, and a private segment for every wave of the launch)
+  double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
   int n = 0;
   if (q == 0.0) {
     double z[2];
-    const int nz = quad_roots(p, r, z);
-    for (int i = 0; i < nz; ++i) {
-      if (z[i] >= 0.0) {
-        const double s = sqrt(z[i]);
-        y[n++] = s;
-        y[n++] = -s;
+    if (quad_roots(p, r, z) != 0) {
+      const bool ua = z[0] >= 0.0, ub = z[1] >= 0.0;
+      const double sa = ua ? sqrt(z[0]) : 0.0, sb = ub ? sqrt(z[1]) : 0.0;
+      if (ua) {
+        y0 = sa;
+        y1 = -sa;
+        n = 2;
+        if (ub) {
+          y2 = sb;
+          y3 = -sb;
+          n = 4;
+        }
+      } else if (ub) {
+        y0 = sb;
+        y1 = -sb;
+        n = 2;
       }
     }
   } else {
@@ -117,15 +130,27 @@ __device__ int quartic_roots(double c0, double c1, double c2, double c3, double 
     const double s = sqrt(2.0 * m);
     const double h = 0.5 * p + m;
     const double g = q / (2.0 * s);
-    n += quad_roots(s, h - g, y + n);
-    n += quad_roots(-s, h + g, y + n);
+    double za[2], zb[2];
+    const int na = quad_roots(s, h - g, za), nb = quad_roots(-s, h + g, zb);
+    if (na != 0) {
+      y0 = za[0];
+      y1 = za[1];
+      if (nb != 0) {
+        y2 = zb[0];
+        y3 = zb[1];
+      }
+    } else if (nb != 0) {
+      y0 = zb[0];
+      y1 = zb[1];
+    }
+    n = na + nb;
   }
   const double shift = 0.25 * a3;
   {
-    double ys = y[0];
-    if (sub == 1) ys = y[1];
-    if (sub == 2) ys = y[2];
-    if (sub == 3) ys = y[3];
+    double ys = y0;
+    if (sub == 1) ys = y1;
+    if (sub == 2) ys = y2;
+    if (sub == 3) ys = y3;
     double x = ys - shift;
     if (sub < n) {
       for (int it = 0; it < 3; ++it) {
