@@ -49,6 +49,8 @@ def test_harris_matches_reference_golden(ctx, path):
     ((64, 64), 7, 4, 16, 0, 3),           # r = 0
     ((17, 300), 8, 4, 20, 5, 9),          # thin images
     ((300, 19), 9, 4, 20, 5, 9),
+    ((201, 333), 10, 6, 400, 5, 9),       # interior tiles of the packed kernel with rows at every byte alignment
+    ((150, 270), 11, 1, 300, 5, 9),       # per-pixel noise: dense maxima
 ])
 def test_harris_matches_oracle_seeded(ctx, shape, seed, block, n, r, patch):
     img = synthetic_image(shape[0], shape[1], seed, block=block)
@@ -57,6 +59,26 @@ def test_harris_matches_oracle_seeded(ctx, shape, seed, block, n, r, patch):
     kp, scores = ctx.harris_keypoints(img, patch, 0.09, n, r, want_scores=True)
     assert np.array_equal(scores, ref_scores)
     assert np.array_equal(kp, ref_kp[:, :, 0])
+
+
+@pytest.mark.parametrize("kind", ["checker1", "checker3", "stripes", "edges"])
+def test_response_extreme_gradients(ctx, kind):
+    """0 / 255 patterns drive the Sobel sums to +-1020 and the box sums to their maxima: the packed 16-bit
+    gradients and the dot-product sums of the response kernel must still be exact."""
+    H, W = 141, 275
+    y, x = np.mgrid[0:H, 0:W]
+    if kind == "checker1":
+        img = ((x + y) & 1) * 255
+    elif kind == "checker3":
+        img = (((x // 3) + (y // 3)) & 1) * 255
+    elif kind == "stripes":
+        img = ((x // 2) & 1) * 255
+    else:
+        img = np.where((x % 37 < 18) ^ (y % 29 < 14), 255, 0)
+    img = img.astype(np.uint8)
+    ref = harris_np.harris_scores(img, 9, 0.09)
+    got = ctx.harris_response(img, 9, 0.09)
+    assert np.array_equal(got, ref)
 
 
 def test_nms_plateaus_and_ties(ctx):
