@@ -108,6 +108,18 @@ def test_klt_matches_oracle_and_flow(ctx, dx, dy, win, lvl):
     assert np.abs(np.median(flow[:, 0]) - dx) < 0.1 and np.abs(np.median(flow[:, 1]) - dy) < 0.1
 
 
+@pytest.mark.parametrize("dx,dy,win,lvl", [(7.3, -5.6, 15, 2), (12.5, 9.25, 15, 3), (-9.4, 6.1, 17, 2), (5.5, 5.5, 21, 1)])
+def test_klt_large_motion_restages(ctx, dx, dy, win, lvl):
+    """Motions beyond the slack staged around the search window: the window walks out of the region the
+    row kernels requested ahead of time and they stage again; still bit-identical to the oracle."""
+    prev, nxt = shift_image(240, 320, 6, dx, dy)
+    rng = np.random.default_rng(7)
+    pts = np.stack([rng.uniform(-20, 340, 500), rng.uniform(-20, 260, 500)], axis=1).astype(np.float32)
+    ro, rs, re = native.klt_track(prev, nxt, pts, win=win, max_level=lvl)
+    go, gs, ge = ctx.klt_track(prev, nxt, pts, win=win, max_level=lvl)
+    assert np.array_equal(gs, rs) and np.array_equal(go, ro) and np.array_equal(ge, re)
+
+
 def test_klt_full_size(ctx):
     dx, dy = 3.25, -1.5
     prev, nxt = shift_image(1241, 1376, 8, dx, dy)
