@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 H, W, N_KP, HYP, WIN, MAX_LEVEL = 1241, 1376, 2000, 1000, 15, 2
 N_FRAMES = 8
 REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
-EXCHANGE_EVERY = 8       # frames per all-gather of {pose, landmarks} records (multi-GPU / --exchange)
+EXCHANGE_EVERY = int(os.environ.get("VO_BENCH_EXCHANGE_EVERY", "16"))   # frames per all-gather of {pose, landmarks} records (multi-GPU / --exchange)
 PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 

@@ -34,7 +34,7 @@ struct vo_pipeline {
   hipEvent_t evDet[2] = {nullptr, nullptr};   // keypoints ready; steps alternate, so the wait for the last step's
                                               // event cannot catch this step's record
   int ev_last = 0;                            // index of the event the latest detection records
-  hipEvent_t evDlt[2] = {nullptr, nullptr};   // the DLT of track set s has run (its inputs may be overwritten, its output read)
+  hipEvent_t evDlt[3] = {nullptr, nullptr, nullptr};   // the DLT of track set s has run (its inputs may be overwritten, its output read)
   // detection worker: a mailbox the main thread posts (frame, buffers) to; it enqueues the branch
   // on det->stream and records evDet[ev]
   std::thread worker;
@@ -45,6 +45,8 @@ struct vo_pipeline {
   job_t jobs[8];
   struct export_t { double head[17]; int n, cap; double* rec; };   // payload of a kind-2 job (same ring index)
   export_t exports[8];
+  unsigned last_det_job = 0;         // job count after the latest detection post (the worker has enqueued it once job_done reaches it)
+  unsigned dlt_job[3] = {0, 0, 0};   // same for the latest DLT of each track set
   int job_rc = 0;
   int job_which = 0;                 // whose error text goes with job_rc: 0 det, 1 det2, 2 tri
   bool det_warm = false;
@@ -72,10 +74,19 @@ struct vo_pipeline {
   float *d_kp_f32[3] = {nullptr, nullptr, nullptr}, *d_next_f32 = nullptr, *d_err = nullptr;   // d_kp as float pairs
   uint8_t* d_status = nullptr;
   // compacted tracks, two sets: the deferred DLT of step k reads set k&1 while step k+1 fills the other
-  double *d_prev_c[2] = {nullptr, nullptr}, *d_next_c[2] = {nullptr, nullptr}, *d_land_c[2] = {nullptr, nullptr};
+  // Track sets (compacted pairs + landmarks, triangulated points, DLT cameras) rotate over THREE slots: the
+  // DLT of step k reads set k mod 3 on its own stream after step k has been collected, and the first step
+  // that writes that set again is k + 3, submitted a whole step later -- by then the DLT has long run
+  // (checked: its job must have been enqueued and its event is asked).  With two sets the writer was the
+  // step submitted right after the DLT was posted.
+  double *d_prev_c[3] = {nullptr, nullptr, nullptr}, *d_next_c[3] = {nullptr, nullptr, nullptr},
+         *d_land_c[3] = {nullptr, nullptr, nullptr};
+  int tset = 0;                      // track set of the last submitted step
+  int tset_collected = 0;            // ... of the last collected step
+  int dlt_n = 0;                     // tracked pairs of the last collected step (the DLT's point count)
   // Everything a step's hypotheses produce exists twice ("slot" = its track set, alternating):
   // a step may be submitted while the previous one's results are still being read.
-  double* d_tri = nullptr;           // 2 x N x 3
+  double* d_tri = nullptr;           // 3 x N x 3
   int cset = 0;                      // set of the last submitted step
   int32_t* d_ntracked = nullptr;     // 2 x 8: [0] tracked count, [1] mirror arrival counter, [2] sampler flag
   double *d_R = nullptr, *d_t = nullptr;
@@ -83,7 +94,7 @@ struct vo_pipeline {
   int32_t* d_counts = nullptr;
   uint64_t* d_masks = nullptr;
   // steps submitted and not yet collected (at most two), oldest first
-  struct flight_t { int prev_idx, next_idx, slot; unsigned seq; bool raw_published; };
+  struct flight_t { int prev_idx, next_idx, slot, tslot; unsigned seq; bool raw_published; };
   flight_t flight[2];
   int n_flight = 0;
   bool dlt_unflushed = false;        // the last collected step's DLT job has not been posted
@@ -106,7 +117,7 @@ struct vo_pipeline {
   volatile unsigned* h_seq = nullptr;         // per slot s: [4s+1] published by the mirror kernel, [4s+2] value it shall publish;
                                               // [8+2s], [9+2s]: {tag, offset} of the slot's outputs in h_raw
   unsigned seq = 0;
-  double* h_C = nullptr;             // 2 x 24 (C1, C2), alternating with the track sets
+  double* h_C = nullptr;             // 3 x 24 (C1, C2), one pair per track set
   double* h_ref = nullptr;           // 2 x 32: [0..11] pose handed to the refinement, [16..30] its 14 outputs + tag
   double* m_ref = nullptr;
   unsigned ref_seq = 0;
@@ -255,6 +266,7 @@ void k_times_rt(const double* K, const double* Rt34, double* C) {
 
 static void worker_main(vo_pipeline* p);
 static int worker_idle(vo_pipeline* p);
+static int wait_job(vo_pipeline* p, unsigned target);
 
 extern "C" {
 
@@ -308,12 +320,12 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_next_f32, (size_t)N * 2));
   PA(dev_alloc(ctx, &p->d_err, (size_t)N));
   PA(dev_alloc(ctx, &p->d_status, (size_t)N));
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     PA(dev_alloc(ctx, &p->d_prev_c[k], (size_t)N * 2));
     PA(dev_alloc(ctx, &p->d_next_c[k], (size_t)N * 2));
     PA(dev_alloc(ctx, &p->d_land_c[k], (size_t)N * 3));
   }
-  PA(dev_alloc(ctx, &p->d_tri, (size_t)2 * N * 3));
+  PA(dev_alloc(ctx, &p->d_tri, (size_t)3 * N * 3));
   PA(dev_alloc(ctx, &p->d_ntracked, 16));
   PA(dev_alloc(ctx, &p->d_R, (size_t)2 * Hyp * 9));
   PA(dev_alloc(ctx, &p->d_t, (size_t)2 * Hyp * 3));
@@ -335,7 +347,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     if (q) memset(q, 0, 64);
     p->h_seq = q;
   }
-  PA(pin_alloc(ctx, &p->h_C, 48));
+  PA(pin_alloc(ctx, &p->h_C, 72));
   PA(pin_alloc(ctx, &p->h_ref, 64));
 #define MAP(dst, src) do { if (rc == VO_OK && hipHostGetDevicePointer((void**)&(dst), (void*)(src), 0) != hipSuccess) \
     rc = vo_set_error(ctx, VO_EHIP, "hipHostGetDevicePointer failed"); } while (0)
@@ -359,7 +371,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
                       hipEventCreateWithFlags(&p->evPyr[1], hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evPyr[2], hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&p->evDlt[0], hipEventDisableTiming) != hipSuccess ||
-                      hipEventCreateWithFlags(&p->evDlt[1], hipEventDisableTiming) != hipSuccess))
+                      hipEventCreateWithFlags(&p->evDlt[1], hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&p->evDlt[2], hipEventDisableTiming) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   if (rc != VO_OK) {
     vo_pipeline_destroy(p);
@@ -400,7 +413,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
                  p->d_scores2, p->d_kp_f32[0], p->d_kp_f32[1], p->d_kp_f32[2], p->d_land_all[0], p->d_land_all[1],
                  p->d_land_all[2],
                  p->d_next_f32, p->d_err, p->d_status, p->d_prev_c[0], p->d_next_c[0], p->d_land_c[0], p->d_prev_c[1],
-                 p->d_next_c[1], p->d_land_c[1], p->d_tri,
+                 p->d_next_c[1], p->d_land_c[1], p->d_prev_c[2], p->d_next_c[2], p->d_land_c[2], p->d_tri,
                  p->d_ntracked, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks};
   for (void* q : dev)
     if (q) (void)hipFree(q);
@@ -411,7 +424,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   if (p->evB) (void)hipEventDestroy(p->evB);
   for (int k = 0; k < 2; ++k)
     if (p->evDet[k]) (void)hipEventDestroy(p->evDet[k]);
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 3; ++k)
     if (p->evDlt[k]) (void)hipEventDestroy(p->evDlt[k]);
   for (int k = 0; k < 3; ++k)
     if (p->evPyr[k]) (void)hipEventDestroy(p->evPyr[k]);
@@ -475,14 +488,14 @@ static int enqueue_detection(vo_pipeline* p, int frame, int slot, int ev, int wh
   return VO_OK;
 }
 
-// DLT of track set `s`; evDlt[s]: the set may be overwritten.  Cameras are read from mapped
-// host memory (set s is rewritten two steps later at the earliest), the point count from the
-// word the gather kernel of that step left in HBM.
-static int enqueue_dlt(vo_pipeline* p, int s) {
+// DLT of track set `s` (n pairs); evDlt[s]: the set may be overwritten.  Cameras are read from mapped
+// host memory (one pair per track set); the point count comes with the job: the word the solve kernel
+// left in HBM belongs to the step's hypothesis slot, which the step after next writes again.
+static int enqueue_dlt(vo_pipeline* p, int s, int n) {
   vo_ctx* det = p->tri;   // (own stream: the tracks are complete -- the host has collected the step -- and nothing
                           //  on the detection stream depends on it)
-  int rc = vo_triangulate_dlt_ndev(det, p->d_prev_c[s], p->d_next_c[s], sl_nt(p, s), p->cfg.n_keypoints, p->m_C + 24 * s,
-                                   p->m_C + 24 * s + 12, sl_tri(p, s));
+  int rc = vo_triangulate_dlt_dev(det, p->d_prev_c[s], p->d_next_c[s], n, p->m_C + 24 * s, 0, p->m_C + 24 * s + 12,
+                                  sl_tri(p, s));
   if (rc == VO_OK && hipEventRecord(p->evDlt[s], det->stream) != hipSuccess) rc = VO_EHIP;
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "%s", vo_last_error(det));
   return VO_OK;
@@ -500,7 +513,7 @@ static int enqueue_export(vo_pipeline* p, int s, const vo_pipeline::export_t& e)
 }
 
 // tracking branch (main stream): KLT -> gather -> hypotheses
-static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, int b, int cs, unsigned raw_tag,
+static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, int b, int cs, int ts, unsigned raw_tag,
                             bool raw_known) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
@@ -508,8 +521,10 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
   VO_TRY(vo_klt_track_dev(ctx, p->d_img[prev_idx], p->d_pyr[a], p->d_img[next_idx], p->d_pyr[b], c.H, c.W,
                           p->n_levels, p->d_kp_f32[a], N, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
                           p->d_next_f32, p->d_status, p->d_err));
-  // the track set this step fills was the input of the DLT of two steps ago
-  if (hipEventQuery(p->evDlt[cs]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDlt[cs], 0));
+  // the track set this step fills was the input of the DLT of three steps ago: that DLT must have been
+  // enqueued (its event recorded) before the event can speak for it
+  VO_TRY(wait_job(p, p->dlt_job[ts]));
+  if (hipEventQuery(p->evDlt[ts]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDlt[ts], 0));
   // The solve kernel selects the tracked keypoints itself (no separate gather launch on the chain) and
   // leaves the compacted arrays and the count for the kernels behind it.
   vo_track_source src;
@@ -520,10 +535,10 @@ static int enqueue_tracking(vo_pipeline* p, int prev_idx, int next_idx, int a, i
   src.kp_prev = p->d_kp[a];
   src.next_xy = p->d_next_f32;
   src.land_all = p->d_land_all[a];
-  src.prev_c = p->d_prev_c[cs];
+  src.prev_c = p->d_prev_c[ts];
   // where the generator outputs start: known now (passed by value), or published later by the
   // collect of the step before (the kernel polls the mapped word)
-  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[cs], p->d_next_c[cs], sl_nt(p, cs), N, c.K,
+  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, p->d_land_c[ts], p->d_next_c[ts], sl_nt(p, cs), N, c.K,
                                    raw_known ? p->m_raw + p->raw_pos : p->m_raw,
                                    raw_known ? (const uint32_t*)nullptr : (const uint32_t*)(p->m_seq + 8 + 2 * cs),
                                    raw_tag, c.hyp, c.p3p_thr_sq, sl_R(p, cs),
@@ -561,7 +576,7 @@ static void worker_main(vo_pipeline* p) {
     idle = 0;
     const vo_pipeline::job_t j = p->jobs[seen & 7];
     const int rc = j.kind == 0   ? enqueue_detection(p, j.frame, j.slot, j.ev, j.which)
-                   : j.kind == 1 ? enqueue_dlt(p, j.slot)
+                   : j.kind == 1 ? enqueue_dlt(p, j.slot, j.frame)
                                  : enqueue_export(p, j.slot, p->exports[seen & 7]);
     if (rc != VO_OK) {
       p->job_rc = rc;
@@ -589,7 +604,20 @@ static int post_detection(vo_pipeline* p, int frame, int slot) {
   p->ev_last ^= 1;
   p->det_flip ^= 1;
   post_job(p, 0, frame, slot, p->ev_last, p->det_flip);
+  p->last_det_job = p->job_posted.load(std::memory_order_relaxed);
   return p->ev_last;
+}
+
+// waits (host) until the worker has enqueued the first `target` jobs, their event records included
+static int wait_job(vo_pipeline* p, unsigned target) {
+  while ((int)(p->job_done.load(std::memory_order_acquire) - target) < 0) __builtin_ia32_pause();
+  if (p->job_rc != VO_OK) {
+    const int rc = p->job_rc;
+    p->job_rc = VO_OK;
+    return vo_set_error(p->ctx, rc, "worker: %s",
+                        vo_last_error(p->job_which == 0 ? p->det : p->job_which == 1 ? p->det2 : p->tri));
+  }
+  return VO_OK;
 }
 
 // waits (host) until the worker has enqueued everything it was given, its event records included
@@ -615,7 +643,8 @@ static int detect_join(vo_pipeline* p) {
 static int flush_dlt(vo_pipeline* p) {
   if (!p->dlt_unflushed) return VO_OK;
   p->dlt_unflushed = false;
-  post_job(p, 1, 0, p->cset_collected, 0, 0);
+  post_job(p, 1, p->dlt_n, p->tset_collected, 0, 0);
+  p->dlt_job[p->tset_collected] = p->job_posted.load(std::memory_order_relaxed);
   return VO_OK;
 }
 
@@ -666,7 +695,8 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   VO_REQUIRE(ctx, p->n_flight < 2, "pipeline_submit: two steps are already in flight, collect one first");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int a = p->cur, b = (p->cur + 1) % 3;
-  const int cs = 1 - p->cset;                          // slot (track set) this step fills
+  const int cs = 1 - p->cset;                          // hypothesis slot this step fills
+  const int ts = (p->tset + 1) % 3;                    // track set this step fills
   static const bool dbg = getenv("VO_DEBUG_TIMING") != nullptr;
   double t_entry = 0;
   if (dbg) {
@@ -681,7 +711,7 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   if (publish_now) publish_raws(p, cs, seq);
 
   // ---- all launches of the step: detection from the worker thread, tracking from this one ----
-  VO_TRY(worker_idle(p));                              // (everything posted earlier has recorded its events)
+  VO_TRY(wait_job(p, p->last_det_job));                // (the last detection has recorded its event; it was posted a step ago)
   const int ev_prev = p->ev_last;                      // recorded behind the last step's detection
   post_detection(p, next_idx, b);
   VO_TRY(flush_dlt(p));                                // the last collected step's DLT, behind this detection
@@ -698,16 +728,18 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   // keypoints of `prev`: usually long finished, and then no barrier goes into the queue
   if (hipEventQuery(p->evDet[ev_prev]) != hipSuccess)
     VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[ev_prev], 0));
-  VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, seq, publish_now));
+  VO_TRY(enqueue_tracking(p, prev_idx, next_idx, a, b, cs, ts, seq, publish_now));
   VO_TRY(launch_mirror(p, cs, true, ctx->stream));
 
   vo_pipeline::flight_t& f = p->flight[p->n_flight++];
   f.prev_idx = prev_idx;
   f.next_idx = next_idx;
   f.slot = cs;
+  f.tslot = ts;
   f.seq = seq;
   f.raw_published = publish_now;
   p->cset = cs;
+  p->tset = ts;
   p->cur = b;
   p->prev_frame = next_idx;
   if (dbg) p->dbg_t[0] += now_us() - t_entry;
@@ -734,7 +766,7 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
   VO_REQUIRE(ctx, p->n_flight > 0, "pipeline_collect: nothing submitted");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const vo_pipeline::flight_t f = p->flight[0];
-  const int N = c.n_keypoints, cs = f.slot;
+  const int N = c.n_keypoints, cs = f.slot, ts = f.tslot;
   const size_t need = (size_t)7 * c.hyp;
   const bool seq_sampler = getenv("VO_SEQ_SAMPLER") != nullptr;   // test hook: always take the sequential path
   static const bool dbg = getenv("VO_DEBUG_TIMING") != nullptr;
@@ -764,6 +796,8 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
   p->last_best = -1;
   p->last_words = vo_cdiv(N, 64);
   p->cset_collected = cs;
+  p->tset_collected = ts;
+  p->dlt_n = n;
   bool raw_ok = true;                                  // the look-ahead is still aligned with the generator
 
   if (n >= 4) {
@@ -789,7 +823,7 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
         // belongs to this step's slot, and the main stream may already hold the next step, whose
         // solve kernel waits for what this collect publishes.
         {
-          const int rc = vo_p3p_hypotheses_dev(p->redo, p->d_land_c[cs], p->d_next_c[cs], n, c.K, p->m_samples, c.hyp,
+          const int rc = vo_p3p_hypotheses_dev(p->redo, p->d_land_c[ts], p->d_next_c[ts], n, c.K, p->m_samples, c.hyp,
                                                c.p3p_thr_sq, sl_R(p, cs), sl_t(p, cs), sl_valid(p, cs), sl_counts(p, cs),
                                                sl_masks(p, cs));
           if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->redo));
@@ -842,7 +876,7 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
       p->redo->prof_on = ctx->prof_on;
       p->redo->prof_kernel = ctx->prof_kernel;
       p->redo->prof_every = ctx->prof_every;
-      const int rc = vo_refine_pose_ndev(p->redo, p->d_land_c[cs], p->d_next_c[cs], N, sl_nt(p, cs), c.K, nullptr,
+      const int rc = vo_refine_pose_ndev(p->redo, p->d_land_c[ts], p->d_next_c[ts], N, sl_nt(p, cs), c.K, nullptr,
                                          sl_masks(p, cs) + (size_t)p->last_best * p->last_words, p->m_ref + 32 * cs,
                                          c.refine_iters, p->m_ref + 32 * cs + 16, tag);
       if (rc != VO_OK) return vo_set_error(ctx, rc, "%s", vo_last_error(p->redo));
@@ -868,7 +902,7 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
     // ---- cameras for the DLT of the tracked pairs: C1 = K T_cw(prev) (stream pose), C2 = K [R | t] ----
     if (best_idx >= 0) {
       double Tcw[16], Rt[12];
-      double* hC = p->h_C + 24 * cs;
+      double* hC = p->h_C + 24 * ts;
       rigid_inverse(&p->T_wc[(size_t)f.prev_idx * 16], Tcw);
       k_times_rt(c.K, Tcw, hC);
       for (int r = 0; r < 3; ++r) {
@@ -879,6 +913,10 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
       }
       k_times_rt(c.K, Rt, hC + 12);
       p->dlt_unflushed = true;
+      // posted now, not with the next submit: the step that reuses this track set checks that the DLT
+      // has been enqueued before it asks its event (enqueue_tracking), and the worker has it out of the
+      // way before the next detection arrives
+      VO_TRY(flush_dlt(p));
     }
   }
   if (n < 4) VO_TRY(retire_step(p, true));
@@ -917,7 +955,7 @@ int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int c
   e.head[16] = (double)e.n;
   e.cap = cap;
   e.rec = d_record;
-  post_job(p, 2, 0, p->cset_collected, 0, 0);
+  post_job(p, 2, 0, p->tset_collected, 0, 0);
   return VO_OK;
 }
 
@@ -976,17 +1014,17 @@ int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* 
   hipStream_t st = ctx->stream;
   VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_fetch: %d submitted step(s) not collected", p->n_flight);
   const int n = p->last_ntracked, N = p->cfg.n_keypoints;
-  const int cs = p->cset_collected;
+  const int cs = p->cset_collected, ts = p->tset_collected;
   VO_TRY(flush_dlt(p));
   VO_TRY(detect_join(p));
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(st, p->evDlt[cs], 0));
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(st, p->evDlt[ts], 0));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   if (kp_next) VO_HIP_TRY(ctx, hipMemcpy(kp_next, p->d_kp[p->cur], (size_t)N * 16, hipMemcpyDeviceToHost));
   if (n > 0) {
-    if (prev_xy) VO_HIP_TRY(ctx, hipMemcpy(prev_xy, p->d_prev_c[cs], (size_t)n * 16, hipMemcpyDeviceToHost));
-    if (next_xy) VO_HIP_TRY(ctx, hipMemcpy(next_xy, p->d_next_c[cs], (size_t)n * 16, hipMemcpyDeviceToHost));
-    if (landmarks) VO_HIP_TRY(ctx, hipMemcpy(landmarks, p->d_land_c[cs], (size_t)n * 24, hipMemcpyDeviceToHost));
-    if (triangulated) VO_HIP_TRY(ctx, hipMemcpy(triangulated, sl_tri(p, cs), (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (prev_xy) VO_HIP_TRY(ctx, hipMemcpy(prev_xy, p->d_prev_c[ts], (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (next_xy) VO_HIP_TRY(ctx, hipMemcpy(next_xy, p->d_next_c[ts], (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (landmarks) VO_HIP_TRY(ctx, hipMemcpy(landmarks, p->d_land_c[ts], (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (triangulated) VO_HIP_TRY(ctx, hipMemcpy(triangulated, sl_tri(p, ts), (size_t)n * 24, hipMemcpyDeviceToHost));
     if (inliers) {
       VO_REQUIRE(ctx, p->last_best >= 0, "pipeline_fetch: no inlier mask for the last step");
       std::vector<uint64_t> row(p->last_words);
