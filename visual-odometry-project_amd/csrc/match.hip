@@ -35,23 +35,15 @@ __device__ __forceinline__ void top2_insert(unsigned long long& k0, unsigned lon
   }
 }
 
-// descriptors as bytes, rows padded with zeros to Dp = multiple of 16.
-// A workgroup owns QB queries (kept in LDS, read as broadcasts) and walks the train set in tiles of MT
-// rows: a tile is fetched with coalesced 16-byte loads into LDS (row pitch Dp/4 + 4 words: 128-bit reads
-// of consecutive lanes fall on disjoint banks), then lane j takes row j of the tile against all QB
-// queries -- 16 bytes of the row and of each query per LDS read, four byte-dot-products per word.
-// (Reading its row straight from global memory, every lane of a wave hit a different cache line per
-// instruction: 517 us for 2000 x 2000 x 128 against 150-200 us for this form; the tile fetch is not yet overlapped
-// with the dot products of the previous tile.)
+// descriptors as bytes, rows padded to Dp = multiple of 4
 __global__ __launch_bounds__(MT) void knn2_u8_kernel(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t,
                                                      int nt, int Dp, int* __restrict__ best, double* __restrict__ d2) {
   extern __shared__ __align__(16) unsigned s_mem[];
-  const int words = Dp / 4, vecs = words / 4, pitch = words + 4;
-  unsigned* s_q = s_mem;                                    // QB rows of `words` words
-  unsigned* s_t = s_q + QB * words;                         // MT rows, pitch `pitch`
-  unsigned long long* s_k = reinterpret_cast<unsigned long long*>(s_t);   // [QB][MT][2], reuses the tile after the walk
+  unsigned* s_q = s_mem;                                    // QB rows of Dp/4 words
+  unsigned long long* s_k = reinterpret_cast<unsigned long long*>(s_q + QB * (Dp / 4));   // [QB][MT][2]
   const int tid = threadIdx.x;
   const int q0 = blockIdx.x * QB;
+  const int words = Dp / 4;
   for (int i = tid; i < QB * words; i += MT) {
     const int r = i / words, w = i - r * words;
     s_q[i] = (q0 + r < nq) ? reinterpret_cast<const unsigned*>(q)[(size_t)(q0 + r) * words + w] : 0u;
@@ -67,44 +59,23 @@ __global__ __launch_bounds__(MT) void knn2_u8_kernel(const uint8_t* __restrict__
   unsigned long long k0[QB], k1[QB];
 #pragma unroll
   for (int r = 0; r < QB; ++r) k0[r] = k1[r] = ~0ull;
-  const uint4* tv = reinterpret_cast<const uint4*>(t);
-  for (int j0 = 0; j0 < nt; j0 += MT) {
-    const int rows = min(MT, nt - j0);
-    __syncthreads();                                        // (the previous tile has been read)
-    for (int i = tid; i < rows * vecs; i += MT) {           // contiguous in global memory: coalesced
-      const int r = i / vecs, v = i - r * vecs;
-      *reinterpret_cast<uint4*>(s_t + r * pitch + 4 * v) = tv[(size_t)j0 * vecs + i];
+  for (int j = tid; j < nt; j += MT) {
+    const unsigned* row = reinterpret_cast<const unsigned*>(t) + (size_t)j * words;
+    unsigned nb = 0, ab[QB];
+#pragma unroll
+    for (int r = 0; r < QB; ++r) ab[r] = 0;
+    for (int w = 0; w < words; ++w) {
+      const unsigned b = row[w];
+      nb = __builtin_amdgcn_udot4(b, b, nb, false);
+#pragma unroll
+      for (int r = 0; r < QB; ++r) ab[r] = __builtin_amdgcn_udot4(s_q[r * words + w], b, ab[r], false);
     }
-    __syncthreads();
-    if (tid < rows) {
-      const uint4* row = reinterpret_cast<const uint4*>(s_t + tid * pitch);
-      unsigned nb = 0, ab[QB];
 #pragma unroll
-      for (int r = 0; r < QB; ++r) ab[r] = 0;
-      for (int v = 0; v < vecs; ++v) {
-        const uint4 b = row[v];
-        nb = __builtin_amdgcn_udot4(b.x, b.x, nb, false);
-        nb = __builtin_amdgcn_udot4(b.y, b.y, nb, false);
-        nb = __builtin_amdgcn_udot4(b.z, b.z, nb, false);
-        nb = __builtin_amdgcn_udot4(b.w, b.w, nb, false);
-#pragma unroll
-        for (int r = 0; r < QB; ++r) {
-          const uint4 a = *reinterpret_cast<const uint4*>(s_q + r * words + 4 * v);   // same address in all lanes
-          ab[r] = __builtin_amdgcn_udot4(a.x, b.x, ab[r], false);
-          ab[r] = __builtin_amdgcn_udot4(a.y, b.y, ab[r], false);
-          ab[r] = __builtin_amdgcn_udot4(a.z, b.z, ab[r], false);
-          ab[r] = __builtin_amdgcn_udot4(a.w, b.w, ab[r], false);
-        }
-      }
-      const int j = j0 + tid;
-#pragma unroll
-      for (int r = 0; r < QB; ++r) {
-        const unsigned dist = nq2[r] + nb - 2u * ab[r];
-        top2_insert(k0[r], k1[r], ((unsigned long long)dist << 32) | (unsigned)j);
-      }
+    for (int r = 0; r < QB; ++r) {
+      const unsigned dist = nq2[r] + nb - 2u * ab[r];
+      top2_insert(k0[r], k1[r], ((unsigned long long)dist << 32) | (unsigned)j);
     }
   }
-  __syncthreads();
 #pragma unroll
   for (int r = 0; r < QB; ++r) {
     s_k[(r * MT + tid) * 2] = k0[r];
@@ -222,7 +193,7 @@ int vo_match_knn2_ratio(vo_ctx* ctx, const float* q, int nq, const float* t, int
   VO_TRY(vo_ensure(ctx, s[2], (size_t)nq * 8));
   VO_TRY(vo_ensure(ctx, s[3], (size_t)nq * 16));
   if (all_bytes(q, (size_t)nq * D) && all_bytes(t, (size_t)nt * D) && (size_t)D * 255 * 255 < (1ull << 31)) {
-    const int Dp = (D + 15) & ~15;   // zero padding: whole 16-byte pieces, the dot products do not see it
+    const int Dp = (D + 3) & ~3;
     std::vector<uint8_t> qb((size_t)nq * Dp, 0), tb((size_t)nt * Dp, 0);
     for (int i = 0; i < nq; ++i)
       for (int k = 0; k < D; ++k) qb[(size_t)i * Dp + k] = (uint8_t)q[(size_t)i * D + k];
@@ -232,11 +203,7 @@ int vo_match_knn2_ratio(vo_ctx* ctx, const float* q, int nq, const float* t, int
     VO_TRY(vo_ensure(ctx, s[1], tb.size()));
     VO_HIP_TRY(ctx, hipMemcpyAsync(s[0].p, qb.data(), qb.size(), hipMemcpyHostToDevice, st));
     VO_HIP_TRY(ctx, hipMemcpyAsync(s[1].p, tb.data(), tb.size(), hipMemcpyHostToDevice, st));
-    const size_t tile = (size_t)MT * (Dp / 4 + 4) * 4, keys = (size_t)QB * MT * 2 * 8;
-    const size_t lds = (size_t)QB * (Dp / 4) * 4 + (tile > keys ? tile : keys);
-    VO_REQUIRE(ctx, lds <= 160 * 1024, "match_knn2_ratio: descriptors of %d bytes do not fit the LDS tile", D);
-    VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&knn2_u8_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = (size_t)QB * (Dp / 4) * 4 + (size_t)QB * MT * 2 * 8;
     {
       vo_prof_scope ps(ctx, VO_K_MATCH);
       hipLaunchKernelGGL(knn2_u8_kernel, dim3(vo_cdiv(nq, QB)), dim3(MT), lds, st, (const uint8_t*)s[0].p, nq,
