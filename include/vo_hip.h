@@ -226,7 +226,11 @@ int vo_min_eigen_map(vo_ctx* ctx, const uint8_t* img, int H, int W, int block, f
  * doubled first).  kp: cap*6 float32 (x, y, size, angle, response, octave) in image
  * coordinates, ordered as KeyPointsFilter::removeDuplicatedSorted leaves them; desc:
  * cap*128 float32 (integer-valued 0..255).  If more than `cap` keypoints are found the
- * `cap` strongest by response are kept (the reference itself sets no cap).             */
+ * `cap` strongest by response are kept (KeyPointsFilter::retainBest).  cap <= 0: keep every
+ * keypoint, as the reference does (nfeatures = 0); kp / desc must then hold
+ * vo_sift_capacity(H, W) rows, the library's own list capacity for that image size --
+ * more keypoints than that is VO_ECAPACITY, never a silent truncation.                  */
+int vo_sift_capacity(int H, int W);
 int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp, float* desc,
             int32_t* n);
 

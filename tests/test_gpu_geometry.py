@@ -34,6 +34,17 @@ def test_dlt_matches_reference_golden(ctx):
     assert np.allclose(Xc, g["X_cand"][:, :, 0], rtol=1e-8, atol=1e-8)
 
 
+def test_dlt_candidates_with_per_track_poses_match_reference_golden(ctx):
+    """triangulate_candidates at the per-frame loop's shape: 2000 tracks, each with its own start pose
+    (triangulation.py:38-86; golden from the reference's own code)."""
+    g = np.load(os.path.join(G, "dlt_candidates.npz"))
+    m = g["mask"]
+    P1, P2 = dlt_np.candidate_projections(g["K"], g["start_poses"][g["start_index"]][m], g["current_pose"])
+    X = ctx.triangulate_dlt(g["tracks"][m], g["keypoints"][m], P1, P2)
+    assert X.shape == (2000, 3)
+    assert np.allclose(X, g["X_cand"][:, :, 0], rtol=1e-8, atol=1e-8)
+
+
 @pytest.mark.parametrize("n", [1, 7, 2000, 8000])
 def test_dlt_matches_oracle_seeded(ctx, n):
     rng, K, R, t, X, x2 = scene(n, seed=11 + n)

@@ -126,6 +126,31 @@ def test_full_size_properties(ctx):
     assert np.array_equal(kp, ref_kp)
 
 
+def test_configuration_size_matches_the_reference_itself(ctx):
+    """One 1376x1241 frame, 2000 keypoints (BASELINE.json configs[1]) against what the reference's own
+    extractKeypoints / extractDescriptors produced on it (tests/golden/full_harris.npz)."""
+    from test_oracle_reference_size import full_frame
+    g, img = full_frame()
+    n, r = int(g["num_keypoints"]), int(g["nms_radius"])
+    kp, scores = ctx.harris_keypoints(img, int(g["patch_size"]), float(g["kappa"]), n, r, want_scores=True)
+    assert np.array_equal(_sha(scores), g["scores_sha256"]), "response map not bit-identical to the reference"
+    assert np.array_equal(kp.reshape(n, 2, 1), g["keypoints"]), "keypoints differ from the reference"
+    desc = ctx.patch_descriptors(img, kp, int(g["descriptor_radius"]))
+    assert np.array_equal(_sha(desc.reshape(n, -1, 1)), g["descriptors_sha256"])
+
+
+def test_reference_kitti_fixture(ctx):
+    """Frames 0 and 1 of the reference's own KITTI test data (tests/test_harris.py:126-171), 200 keypoints."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "kitti_harris.npz"))
+    for k in (0, 1):
+        img = g["image%d" % k]
+        kp, scores = ctx.harris_keypoints(img, 9, 0.09, 200, 5, want_scores=True)
+        assert np.array_equal(_sha(scores), g["scores%d_sha256" % k])
+        assert np.array_equal(kp.reshape(200, 2, 1), g["keypoints%d" % k])
+        desc = ctx.patch_descriptors(img, kp, 9)
+        assert np.array_equal(_sha(desc.reshape(200, -1, 1)), g["descriptors%d_sha256" % k])
+
+
 def test_errors_are_reported_not_raised_across_abi(ctx):
     from vo._native import VoError
     img = np.zeros((32, 32), np.uint8)

@@ -306,9 +306,118 @@ def golden_helpers():
     print("helpers: roundtrip", np.abs(np.real(back) - tw).max())
 
 
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def _amd_synthetic():
+    """This repository's synthetic stream generator, loaded by path (the name `vo` belongs to the
+    reference while this script runs)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "amd_synthetic", os.path.join(ROOT, "visual-odometry-project_amd", "vo", "synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def golden_harris_full():
+    """The reference's own extractKeypoints / extractDescriptors on one frame of BASELINE.json
+    configs[1] (1376x1241, 2000 keypoints) -- ~5 s of its 2N-argmax loop.  The frame is frame 0 of
+    vo.synthetic.Stream (regenerated by the test; only its SHA-256 is stored)."""
+    from vo.features.harris import HarrisCornerDetector
+    from vo.primitives import Frame
+    syn = _amd_synthetic()
+    img = syn.Stream(2, 1241, 1376).image(0)
+    det = HarrisCornerDetector(num_keypoints=2000)
+    fr = det.extractDescriptors(det.extractKeypoints(Frame(img.copy())))
+    scores = _reference_scores(det, img)
+    np.savez_compressed(os.path.join(OUT, "full_harris.npz"), image_sha256=_sha(img), H=1241, W=1376,
+                        patch_size=det._patch_size, kappa=det._kappa, num_keypoints=2000,
+                        nms_radius=det._nonmaximum_supression_radius, descriptor_radius=det._descriptor_radius,
+                        keypoints=fr.features.keypoints, descriptors_sha256=_sha(fr.features.descriptors),
+                        scores_sha256=_sha(scores), scores_row600=scores[600].copy())
+    print("harris_full: kp[0..3]=", fr.features.keypoints[:3, :, 0].tolist())
+
+
+def golden_harris_kitti():
+    """tests/test_harris.py:126-171 (frames 0 and 1 of the reference's KITTI fixture, 200 keypoints):
+    the part of featureMatcher that is the reference's own NumPy code (keypoints + descriptors of
+    both frames; the match itself is cv2.BFMatcher and stays unpinned).  The two PNGs are data files
+    of the reference's tests, read with PIL and stored as arrays."""
+    from PIL import Image
+    from vo.features.harris import HarrisCornerDetector
+    from vo.primitives import Frame
+    d = "/root/reference/tests/test_data/kitti/05/image_0"
+    out = {}
+    for k in (0, 1):
+        img = np.array(Image.open(os.path.join(d, "%06d.png" % k)))
+        assert img.dtype == np.uint8 and img.ndim == 2
+        det = HarrisCornerDetector(num_keypoints=200)
+        fr = det.extractDescriptors(det.extractKeypoints(Frame(img.copy())))
+        out["image%d" % k] = img
+        out["keypoints%d" % k] = fr.features.keypoints
+        out["descriptors%d_sha256" % k] = _sha(fr.features.descriptors)
+        out["descriptors%d_head" % k] = fr.features.descriptors[:8]
+        out["scores%d_sha256" % k] = _sha(_reference_scores(det, img))
+    with open("/root/reference/tests/test_data/kitti/05/calib.txt") as f:
+        out["calib_P0"] = np.array(f.readline().split()[1:], dtype=np.float64).reshape(3, 4)
+    out["poses05_head"] = np.loadtxt("/root/reference/tests/test_data/kitti/poses/05.txt", max_rows=6).reshape(-1, 3, 4)
+    np.savez_compressed(os.path.join(OUT, "kitti_harris.npz"), **out)
+    print("harris_kitti:", out["image0"].shape, "kp0[0..3]=", out["keypoints0"][:3, :, 0].tolist())
+
+
+def golden_dlt_candidates():
+    """triangulate_candidates (triangulation.py:38-86) with 2000 tracks, each with its own start pose
+    (proj1[i] = K inv(pose_start_i)[:3]) -- the shape the per-frame loop calls it at (main.py:279-283)."""
+    from vo.landmarks.triangulation import LandmarksTriangulator
+    from vo.primitives import Features
+    c1, c2 = _test_cameras()
+    tri = LandmarksTriangulator(camera1=c1, camera2=c2, use_ransac=False, use_opencv=False)
+    rng = np.random.default_rng(4046)
+    n = 2200
+    K = c1.intrinsic_matrix
+    X = rng.uniform(-3, 3, size=(n, 3, 1))
+    X[:, 2] = X[:, 2] * 4 + 18
+    # 37 distinct start poses (a drive: forward motion + yaw), assigned to tracks at random
+    starts = []
+    for k in range(37):
+        a = 0.01 * np.sin(0.1 * k)
+        T = np.eye(4)
+        T[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        T[:3, 3] = [0.02 * k, 0.0, 0.12 * k]
+        starts.append(T)
+    starts = np.stack(starts)
+    which = rng.integers(0, 37, size=n)
+    poses = starts[which]
+    cur = np.eye(4)
+    a = 0.015
+    cur[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    cur[:3, 3] = [0.9, -0.02, 5.5]
+
+    def proj(T, Xw):
+        Tcw = np.linalg.inv(T)
+        u = K @ (Tcw[:3, :3] @ Xw + Tcw[:3, 3:])
+        return u[:2] / u[2:]
+
+    tracks = np.stack([proj(poses[i], X[i]) for i in range(n)]) + rng.normal(0, 0.3, size=(n, 2, 1))
+    kps = np.stack([proj(cur, X[i]) for i in range(n)]) + rng.normal(0, 0.3, size=(n, 2, 1))
+    feats = Features(keypoints=kps.copy())
+    feats.tracks = tracks
+    feats.poses = poses
+    mask = np.ones(n, dtype=bool)
+    mask[rng.permutation(n)[:200]] = False
+    feats.candidate_mask = mask
+    Xc = tri.triangulate_candidates(feats, cur)
+    np.savez_compressed(os.path.join(OUT, "dlt_candidates.npz"), K=K, keypoints=kps, tracks=tracks,
+                        start_poses=starts, start_index=which, mask=mask, current_pose=cur, X_true=X, X_cand=Xc)
+    print("dlt_candidates:", Xc.shape, "median err", float(np.median(np.abs(Xc - X[mask]))))
+
+
 if __name__ == "__main__":
     _import_reference()
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["harris", "dlt", "ransac", "bookkeeping", "bootstrap", "helpers"]
+    which = sys.argv[1:] or ["harris", "dlt", "ransac", "bookkeeping", "bootstrap", "helpers", "harris_full",
+                             "harris_kitti", "dlt_candidates"]
     for w in which:
         globals()["golden_" + w]()

@@ -458,10 +458,20 @@ bool row_less(const float* a, const float* b) {
 
 extern "C" {
 
+// internal keypoint list capacity for an H x W image: grows with the image (the full 1376x1241 frame of the
+// synthetic stream yields ~9.3k keypoints, one per ~180 pixels); also the row count a caller must provide
+// when it asks for every keypoint (cap <= 0)
+int vo_sift_capacity(int H, int W) {
+  const long long px = (long long)H * W;
+  const long long c = px / 32;
+  return (int)(c < 65536 ? 65536 : (c > (1 << 20) ? (1 << 20) : c));
+}
+
 int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_out, float* desc_out, int32_t* n_out) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, img && kp_out && desc_out && n_out, "sift: null pointer");
-  VO_REQUIRE(ctx, H >= 16 && W >= 16 && cap >= 1, "sift: bad arguments");
+  VO_REQUIRE(ctx, H >= 16 && W >= 16, "sift: bad arguments");
+  if (cap <= 0) cap = vo_sift_capacity(H, W);   // keep every keypoint, as cv2.SIFT_create() (nfeatures = 0) does
   *n_out = 0;
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -488,7 +498,7 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
       h /= 2;
     }
   }
-  const unsigned cap_cand = 1u << 18, cap_kp = 1u << 16;
+  const unsigned cap_kp = (unsigned)vo_sift_capacity(H, W), cap_cand = 4u * cap_kp;
   VO_TRY(vo_ensure(ctx, ctx->img, (size_t)H * W));
   VO_TRY(vo_ensure(ctx, ctx->sift_arena, total * 4));
   VO_TRY(vo_ensure(ctx, ctx->scratch[0], (size_t)cap_cand * 12));

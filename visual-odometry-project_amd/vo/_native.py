@@ -118,6 +118,7 @@ _SIGS = {
     "vo_good_features": (_i, [_vp, _vp, _i, _i, _vp, _i, _d, _d, _i, _vp, _vp]),
     "vo_min_eigen_map": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vo_sift": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "vo_sift_capacity": (_i, [_i, _i]),
     "vo_rng_choice": (_i, [_vp, _i, _i, _i, _vp]),
     "vo_ransac_num_iterations": (C.c_int64, [_d, _d, _i]),
     "vo_ransac_replay": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -308,14 +309,16 @@ class Context:
                                              float(min_distance), int(block_size), _ptr(xy), C.byref(n)))
         return xy[: n.value].copy()
 
-    def sift(self, img, cap=20000):
-        """(kp (n, 6) float32: x, y, size, angle, response, octave; desc (n, 128) float32)."""
+    def sift(self, img, cap=None):
+        """(kp (n, 6) float32: x, y, size, angle, response, octave; desc (n, 128) float32).
+        cap=None keeps every keypoint, as cv2.SIFT_create() does; an integer keeps the strongest `cap`."""
         img = _c(img, np.uint8)
         H, W = img.shape
-        kp = np.empty((cap, 6), np.float32)
-        desc = np.empty((cap, 128), np.float32)
+        rows = int(cap) if cap else self._lib.vo_sift_capacity(H, W)
+        kp = np.empty((rows, 6), np.float32)
+        desc = np.empty((rows, 128), np.float32)
         n = C.c_int32(0)
-        self._chk(self._lib.vo_sift(self._h, _ptr(img), H, W, int(cap), _ptr(kp), _ptr(desc), C.byref(n)))
+        self._chk(self._lib.vo_sift(self._h, _ptr(img), H, W, int(cap) if cap else 0, _ptr(kp), _ptr(desc), C.byref(n)))
         return kp[: n.value].copy(), desc[: n.value].copy()
 
     def min_eigen_map(self, img, block_size=7):
