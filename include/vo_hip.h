@@ -39,7 +39,8 @@ typedef enum vo_status {
   VO_EINVAL = -1,        /* bad argument (shape, range, null pointer)           */
   VO_ENOMEM = -2,        /* host or device allocation failed                    */
   VO_EHIP = -3,          /* HIP runtime error (no device, launch failure, ...)  */
-  VO_ECAPACITY = -4      /* an internal candidate list overflowed its capacity  */
+  VO_ECAPACITY = -4,     /* an internal candidate list overflowed its capacity  */
+  VO_ETRACKING = -5      /* fewer than 4 triangulated tracks survive: no pose   */
 } vo_status;
 
 /* ---- context ---------------------------------------------------------------- */
@@ -86,6 +87,11 @@ enum {
   VO_K_SIFT_DETECT = 19,
   VO_K_SIFT_DESCRIBE = 20,
   VO_K_REFINE = 21,
+  VO_K_STATE_APPEND = 22,
+  VO_K_STATE_REGROUP = 23,
+  VO_K_RANSAC_REPLAY = 24,
+  VO_K_STATE_UPDATE = 25,
+  VO_K_EXPORT = 26,
   VO_K_COUNT = 32
 };
 int vo_prof_enable(vo_ctx* ctx, int kernel_id);
@@ -260,34 +266,56 @@ int vo_ransac_replay(vo_ransac_state* st, const uint8_t* valid, const int32_t* c
                      int idx_offset, int* consumed, int* finished);
 
 /* ---- device-resident frame pipeline ------------------------------------------------
- * One vo_pipeline keeps a synthetic stream (images, per-pixel depth, camera poses)
- * resident in HBM and runs the per-frame front-end of the reference driver
- * [ref: src/main.py:248-286] as one call per frame:
- *   pyramid(next) -> KLT prev->next (klt.py:233-249, keep status & err < thr)
- *   -> Harris response + NMS on next (harris.py:86-158; the detector that feeds the
- *      following step)
- *   -> P3P-RANSAC on (landmark, tracked point) pairs: `hyp` samples drawn with the
- *      reference's generator, solved and scored on the GPU, sequential rule replayed
- *      (p3p.py:123-186 with use_opencv=False, nonlinear refinement excluded)
- *   -> DLT triangulation of the tracked pairs (triangulation.py:352-389).
- * Landmarks of the previous frame's keypoints come from the stream's depth maps
- * (the synthetic stand-in for the map the reference accumulates in State).       */
+ * The steady-state loop of the reference driver [ref: src/main.py:248-286], KLT tracker mode
+ * [ref: src/vo/features/tracker.py:56-57], with everything the reference carries from frame to
+ * frame kept in HBM: the Features arrays (keypoints, state codes, landmarks, track starts, track
+ * start poses, candidate mask) [ref: src/vo/primitives/features.py:4-54], State's current and
+ * previous pose [ref: src/vo/primitives/state.py:9-15], the estimator's RANSAC fields and its
+ * position in the generator's output stream [ref: src/vo/algorithms/ransac.py:42-56], and
+ * KLTTracker._num_features.  The pipeline takes IMAGES ONLY; one step = one frame:
+ *   side streams: pyramid(next); Harris response + greedy NMS on next (the detector whose
+ *                 keypoints the next step appends when too few tracks survive)
+ *   re-detect     [ref: src/vo/features/klt.py:207-230, 117-189]  length < 0.8 * _num_features:
+ *                 the detector's keypoints of `prev` are appended as unmatched features
+ *   KLT           [ref: klt.py:233-249]  every feature prev -> next, keep status & err < thr
+ *   Matches       [ref: src/vo/primitives/matches.py:26-212]  regroup into [triangulated |
+ *                 matched | newly matched], landmarks / track starts / start poses carried over
+ *   estimate_pose [ref: src/vo/pose_estimation/p3p.py:123-186, use_opencv=False]  `hyp` samples
+ *                 drawn with the reference's generator, solved and scored; the sequential
+ *                 accept / adapt rule [ref: ransac.py:90-121] replayed on the device; refinement
+ *                 over the inliers [ref: p3p.py:188-213]
+ *   State         [ref: src/vo/primitives/state.py:38-50, 162-172, 135-160, 174-219]  pose,
+ *                 reset_outliers, compute_candidates (bearing angle >= threshold)
+ *   triangulate_candidates [ref: src/vo/landmarks/triangulation.py:38-86]  one start pose per
+ *                 track; update_with_world_landmarks + _check_landmarks [ref: state.py:69-107]
+ * No stage waits for the host: a step is a chain of launches, its result a record the last
+ * kernel writes to host-visible memory.  The two-view bootstrap [ref: main.py:204-230] runs on
+ * the host (vo/driver.py) and hands its Features / poses over with vo_pipeline_set_state.      */
 typedef struct vo_pipeline vo_pipeline;
 typedef struct vo_pipeline_config {
-  int32_t H, W, n_frames;
-  int32_t n_keypoints, harris_patch, nms_radius;
+  int32_t H, W, n_frames;        /* n_frames: frame store in HBM (vo_pipeline_set_frame slots)   */
+  int32_t n_keypoints, harris_patch, nms_radius;      /* detector: harris.py:16-25               */
   double harris_kappa;
   int32_t klt_win, klt_max_level, klt_max_iter, hyp;
-  double klt_eps, klt_min_eig, klt_err_threshold;
+  double klt_eps, klt_min_eig, klt_err_threshold;      /* klt.py:29-39                            */
   double p3p_thr_sq, ransac_outlier_ratio, ransac_confidence;
-  int64_t ransac_max_iterations;
+  int64_t ransac_max_iterations;                       /* < 0: unbounded                          */
   double K[9];
-  int32_t refine_iters;         /* > 0: refine the accepted pose over its inliers (vo_refine_pose) */
-  int32_t pad;
+  double Kinv[9];                /* inverse intrinsics as the caller computes them (the reference:
+                                    np.linalg.inv, camera.py:88); all zero = computed here        */
+  int32_t refine_iters;          /* > 0: refine the accepted pose over its inliers (vo_refine_pose) */
+  int32_t feature_cap;           /* capacity of the Features arrays; 0 = 2 * n_keypoints          */
+  double bearing_threshold;      /* State(bearing_threshold), state.py:8; 0 = 0.0075             */
+  double redetect_fraction;      /* klt.py:212; 0 = 0.8                                           */
+  int32_t debug_fault_every;     /* test hook: every n-th step takes the host recovery path      */
+  int32_t redetect_start_pose;   /* start pose of re-detected keypoints: 0 = np.eye(4), as the reference's
+                                    update_features writes it (klt.py:148-153) -- away from the origin such
+                                    tracks triangulate against the wrong baseline; 1 = the current pose,
+                                    what State.reset_outliers gives a restarted track (state.py:170-172) */
 } vo_pipeline_config;
 typedef struct vo_step_result {
   double R[9], t[3];            /* world -> camera pose of `next` (best hypothesis)   */
-  int32_t n_tracked;            /* correspondences surviving the KLT filter           */
+  int32_t n_tracked;            /* features of the new frame (survivors of the KLT filter) */
   int32_t n_inliers;            /* inliers of the returned pose                       */
   int32_t best_index;           /* index of the accepted hypothesis                   */
   int32_t hyp_valid;            /* hypotheses with a P3P solution among those scored  */
@@ -296,48 +324,72 @@ typedef struct vo_step_result {
   int32_t refine_iterations;    /* accepted refinement steps; -1: not refined         */
   double R_refined[9], t_refined[3];   /* refined pose (= R, t when not refined)      */
   double refine_cost;           /* sum of squared inlier reprojection errors after it */
+  int32_t n_features_in;        /* features handed to the tracker (after a re-detect) */
+  int32_t redetected;           /* 1: the detector's keypoints were appended          */
+  int32_t n_triangulated;       /* tracked features with a landmark: the P3P population */
+  int32_t n_candidates;         /* tracks that passed the bearing test and were triangulated */
+  int32_t n_dropped;            /* landmarks the cheirality check removed             */
+  int32_t n_landmarks;          /* features in state 2 after the step                 */
+  int32_t fault;                /* internal: reason the step left the device-only path */
+  int32_t recovered;            /* 1: the step was finished through the host path     */
+  uint64_t raw_pos;             /* generator outputs consumed so far (32-bit words)   */
+  double T_wc[12];              /* camera -> world pose after the step, rows 0..2 (State.curr_pose) */
 } vo_step_result;
 int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out);
 void vo_pipeline_destroy(vo_pipeline* p);
-int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img, const float* depth,
-                          const double* T_world_cam /* 4x4 row-major */);
+/* frame store: copies a host image into slot idx of the frame store (synchronous)            */
+int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img);
 int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng);
-int vo_pipeline_prime(vo_pipeline* p, int idx);
+int vo_pipeline_get_rng(vo_pipeline* p, vo_pcg64* rng);      /* estimator generator state after the last collected step */
+/* Hands over the Features of frame idx (the reference's state.curr_frame.features after the
+ * bootstrap) and State's poses: n features -- kp n*2 float32, state n bytes (0/1/2), landmarks
+ * n*3, tracks n*2, poses n*16 (4x4 row-major, camera-to-world; NaN rows where the reference holds
+ * NaN) -- plus curr / prev pose as 4x4 camera-to-world AND world-to-camera matrices (the
+ * reference forms the latter with np.linalg.inv; passing both keeps every later product the
+ * same), and KLTTracker._num_features.  Builds the pyramid and runs the detector on frame idx.  */
+int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const float* kp, const uint8_t* state,
+                          const double* landmarks, const double* tracks, const double* poses,
+                          const double* T_wc, const double* T_cw, const double* T_wc_prev,
+                          const double* T_cw_prev, int num_features);
+/* Downloads the current Features (arrays sized to the capacity vo_pipeline_feature_cap returns;
+ * any pointer may be NULL); n_out: feature count.  Nothing may be in flight.                  */
+int vo_pipeline_feature_cap(vo_pipeline* p);
+int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, float* kp, uint8_t* state, uint8_t* candidate_mask,
+                          double* landmarks, double* tracks, double* poses, double* T_wc, double* T_wc_prev,
+                          vo_ransac_state* rs, int32_t* num_features);
+/* keypoints the detector found on the frame submitted last (n_keypoints*2 float64)              */
+int vo_pipeline_get_detection(vo_pipeline* p, double* kp_xy);
+/* One frame.  submit enqueues all GPU work of the step prev_idx -> next_idx and returns; collect
+ * waits for the oldest submitted step's record.  At most two steps may be in flight (the frame
+ * store and the per-frame buffers rotate over three slots); with submit(k+1) before collect(k)
+ * the host's launches overlap the GPU's work.  step = submit + collect.                        */
 int vo_pipeline_step(vo_pipeline* p, int prev_idx, int next_idx, vo_step_result* out);
-/* vo_pipeline_step in two halves, for a caller that has the next frame before it needs the
- * last pose (a camera stream): submit enqueues all GPU work of the frame and returns;
- * collect waits for it and runs the sequential RANSAC rule (main.py:248-268's
- * estimate_pose).  At most two steps may be in flight, collected in submission order; with
- * one step of look-ahead (submit k+1, then collect k) the host's share of a step overlaps
- * the GPU's.  Results are identical to vo_pipeline_step.                              */
 int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx);
 int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out);
-/* vo_prof_read / vo_prof_reset over both of the pipeline's streams (detection runs on a
- * second stream beside tracking).                                                   */
+/* Test / integration entry: the bookkeeping of one frame with everything the estimators would
+ * produce given by the caller -- Matches(frame1 = current features, frame2 = Features(new_kp),
+ * pairs) [ref: matches.py:11-212], update_with_world_pose(T), outliers[triangulate_inliers] =
+ * ~p3p_inliers, reset_outliers, compute_candidates [phase 1]; triangulate_candidates,
+ * update_with_world_landmarks [phase 2].  phases: 1, 2 or 3.  Synchronous.                     */
+int vo_pipeline_bookkeeping(vo_pipeline* p, int phases, const double* new_kp, int n2, const int32_t* pairs,
+                            int M, const double* T_wc, const double* T_cw, const uint8_t* p3p_inliers);
+/* vo_prof_read / vo_prof_reset over all of the pipeline's streams                              */
 int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64_t* launches);
 int vo_pipeline_prof_reset(vo_pipeline* p);
 /* Shared-map record of the last collected step -> DEVICE memory (async):
- * [T_cw 4x4 row-major (16, the refined pose) | n (1) | n triangulated landmarks x 3,
- * n <= cap], all f64, 17 + 3*cap doubles.  The caller all-gathers records over RCCL
+ * [T_cw 4x4 row-major (16, the refined pose) | n (1) | n landmarks x 3 (the step's P3P
+ * population, n <= cap)], all f64, 17 + 3*cap doubles.  The caller all-gathers records over RCCL
  * (bench.py), one or several frames per collective:
- *   _post  queues the record behind the step's DLT on the pipeline's own stream and
- *          returns at once (no synchronisation; steps in flight are not waited for);
- *   _join  orders the pipeline's stream and `consumer` (hipStream_t; NULL = the
- *          context's stream) both ways: work enqueued on `consumer` after the call sees
- *          every record posted so far, and records posted after the call are written
- *          after everything `consumer` held at the time of the call (an exchange still
- *          reading the buffer);
- *   _dev   = join, post, join: one record, usable immediately.                      */
-int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int cap,
-                                  double* d_record);
+ *   _post  queues the record on the pipeline's stream and returns at once;
+ *   _join  orders the pipeline's stream and `consumer` (hipStream_t; NULL = the context's
+ *          stream) both ways: work enqueued on `consumer` after the call sees every record
+ *          posted so far, and records posted after the call are written after everything
+ *          `consumer` held at the time of the call (an exchange still reading the buffer).   */
+int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record);
 int vo_pipeline_export_state_join(vo_pipeline* p, void* consumer);
-int vo_pipeline_export_state_dev(vo_pipeline* p, const vo_step_result* r, int cap,
-                                 double* d_record, void* consumer);
-/* copies of the last step's device arrays: keypoints of `next` (n_keypoints*2 f64),
- * tracked pairs (n_tracked: prev xy f64, next xy f64, landmark xyz f64), triangulated
- * points (n_tracked*3 f64), inlier mask (n_tracked bytes).  Any pointer may be NULL. */
-int vo_pipeline_fetch(vo_pipeline* p, double* kp_next, double* prev_xy, double* next_xy,
-                      double* landmarks, double* triangulated, uint8_t* inliers);
+/* the ransac.py:58-67 iteration bound through the pipeline's threshold table (what the device
+ * evaluates); equals vo_ransac_num_iterations clipped to max_iterations                         */
+int64_t vo_pipeline_ransac_bound(vo_pipeline* p, double outlier_ratio);
 
 #ifdef __cplusplus
 }

@@ -225,6 +225,22 @@ def test_headless_driver_runs_the_reference_call_sequence(ctx):
     assert err["rms"] < 0.05 * err["path_length"], err
 
 
+def test_headless_driver_on_the_device_pipeline(ctx):
+    """Same bootstrap, steady state as the device-resident pipeline (vo.driver.run_on_device): images in,
+    pose records out, Features / State never leave HBM."""
+    from vo import driver
+    from vo.primitives import Sequence
+    seq = Sequence("synthetic", n_frames=24, height=480, width=640, channels=3)
+    out = driver.run_on_device(seq, n_keypoints=500, context=ctx)
+    assert out["trajectory"].shape[1:] == (4, 4) and len(out["trajectory"]) == 23
+    assert out["n_landmarks"].min() > 30
+    assert all(r.fault == 0 or r.recovered for r in out["results"])
+    err = driver.trajectory_error(out, seq)
+    assert err["rms"] < 0.05 * err["path_length"], err
+    f = out["features"]
+    assert f.length == out["results"][-1].n_tracked and int((f.state == 2).sum()) == out["results"][-1].n_landmarks
+
+
 # ---------------- SIFT ----------------
 @pytest.mark.parametrize("kind,shape,seed", [("smooth", (240, 320), 21), ("blocks", (200, 260), 5), ("smooth", (97, 131), 8)])
 def test_sift_matches_oracle(ctx, kind, shape, seed):

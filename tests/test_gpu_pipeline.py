@@ -1,11 +1,16 @@
-"""-m gpu: the device-resident frame pipeline (vo_pipeline_*) against the same
-stages composed from the CPU oracles, frame by frame."""
+"""-m gpu: the device-resident frame loop (vo_pipeline_*) against the CPU oracle of the same loop
+(tests/pipeline_oracle.py: the reference's call sequence src/main.py:248-286 composed from the pinned
+bookkeeping classes and the CPU oracles), frame by frame, and against the reference's own bookkeeping
+golden (tests/golden/bookkeeping.npz)."""
+import os
+
 import numpy as np
 import pytest
 
-from oracle import dlt_np, harris_np, native, ransac_np
+from pipeline_oracle import OracleLoop, initial_features
 
 pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.fixture(scope="module")
@@ -16,198 +21,350 @@ def ctx():
     c.close()
 
 
-def oracle_step(stream, prev, nxt, kp_prev, rs, cfg):
-    """One frame of the front-end with CPU oracles; rs = persistent oracle Ransac object."""
-    K = stream.K
-    out, status, err = native.klt_track(stream.image(prev), stream.image(nxt), kp_prev.astype(np.float32),
-                                        win=cfg["win"], max_level=cfg["lvl"])
-    keep = status.astype(bool) & (err < 100.0)
-    p_c, n_c = kp_prev[keep], out[keep].astype(np.float64)
-    z = stream.depth(prev)[p_c[:, 1].astype(int), p_c[:, 0].astype(int)].astype(np.float64)
-    xc = (p_c[:, 0] - K[0, 2]) / K[0, 0] * z
-    yc = (p_c[:, 1] - K[1, 2]) / K[1, 1] * z
-    T = stream.T_world_cam(prev)
-    land = np.stack([T[r, 0] * xc + T[r, 1] * yc + T[r, 2] * z + T[r, 3] for r in range(3)], axis=1)
-    sc = harris_np.harris_scores(stream.image(nxt), 9, 0.09)
-    kp_next = harris_np.nms_keypoints_fast(sc, cfg["N"], 5)[:, :, 0]
-    # re-bind the oracle RANSAC to this frame's correspondences (the estimator object persists)
-    rs.model_fn = lambda idx: native.p3p_solve(land[np.asarray(idx).reshape(-1)], n_c[np.asarray(idx).reshape(-1)], K)
-    rs.error_fn = lambda m, pop: native.reproj_errors(land, n_c, K, m[0], m[1])
-    n0 = len(rs.trace)
-    (R, t), inl = rs.find_best_model(np.arange(len(land)))
-    Tcw = np.linalg.inv(T)
-    tri = dlt_np.linear_triangulation(p_c, n_c, K @ Tcw[:3], K @ np.hstack([R, t[:, None]]))
-    return dict(kp_next=kp_next, prev_xy=p_c, next_xy=n_c, landmarks=land, R=R, t=t, inliers=inl, tri=tri,
-                draws=len(rs.trace) - n0, iters=rs.iterations_done)
+def subsample(features, keep):
+    import copy
+    f = copy.deepcopy(features)
+    f.mask(keep)
+    return f
 
 
-@pytest.mark.parametrize("sampler", ["device", "sequential"])
-@pytest.mark.parametrize("H,W,N,hyp", [(240, 320, 300, 256), (480, 640, 500, 1000)])
-def test_pipeline_matches_oracle_composition(ctx, H, W, N, hyp, sampler, monkeypatch):
-    """sampler = "device": sample indices derived in the solve kernel from raw generator outputs;
-    "sequential": the host sampler the pipeline falls back to when a draw may have been rejected
-    (VO_SEQ_SAMPLER forces it).  Both must reproduce the reference's sample stream."""
-    from vo import _native, synthetic
-    if sampler == "sequential":
-        monkeypatch.setenv("VO_SEQ_SAMPLER", "1")
-    else:
-        monkeypatch.delenv("VO_SEQ_SAMPLER", raising=False)
-    F = 4
+def make_pipe(ctx, stream, N, hyp, win=15, lvl=2, refine=20, **kw):
+    from vo import _native
+    pipe = _native.Pipeline(ctx, stream.H, stream.W, stream.n, stream.K, n_keypoints=N, klt_win=win, klt_max_level=lvl,
+                            hyp=hyp, p3p_threshold=1.0, max_iterations=1000, refine_iters=refine, **kw)
+    for i in range(stream.n):
+        pipe.set_frame(i, stream.image(i))
+    return pipe
+
+
+def start_state(stream, N, fraction=1.0):
+    feats, T = initial_features(stream, 0, N)
+    if fraction < 1.0:
+        keep = np.zeros(feats.length, dtype=bool)
+        keep[np.linspace(0, feats.length - 1, int(fraction * feats.length)).astype(int)] = True
+        feats = subsample(feats, keep)
+    return feats, T
+
+
+def check_state(got, ref_feats, ref_pose, tol=1e-7):
+    n = ref_feats.length
+    assert got["n"] == n
+    assert np.array_equal(got["keypoints"], ref_feats.keypoints.astype(np.float32))
+    assert np.array_equal(got["state"], ref_feats.state)
+    assert np.array_equal(got["candidate_mask"], ref_feats.candidate_mask)
+    assert np.array_equal(np.isnan(got["landmarks"]), np.isnan(ref_feats.landmarks))
+    assert np.allclose(got["landmarks"], ref_feats.landmarks, rtol=1e-6, atol=1e-6, equal_nan=True)
+    assert np.array_equal(got["tracks"], ref_feats.tracks, equal_nan=True)
+    assert np.array_equal(np.isnan(got["poses"]), np.isnan(ref_feats.poses))
+    assert np.allclose(got["poses"], ref_feats.poses, atol=tol, equal_nan=True)
+    assert np.allclose(got["curr_pose"], ref_pose, atol=tol)
+
+
+def check_step(r, ref, pipe, gen_ref, tol_refined=1e-7):
+    assert r.fault == 0
+    assert r.n_tracked == ref["n_tracked"] and r.n_triangulated == ref["n_tri"]
+    assert r.draws_consumed == ref["draws"] and r.ransac_iterations == ref["iters"]
+    assert r.n_inliers == ref["n_inliers"]
+    R, t = np.array(r.R).reshape(3, 3), np.array(r.t)
+    assert np.allclose(R, ref["R"], atol=1e-9) and np.allclose(t, ref["t"], atol=1e-9)
+    Rr, tr = np.array(r.R_refined).reshape(3, 3), np.array(r.t_refined)
+    assert np.allclose(Rr, ref["R_ref"], atol=tol_refined) and np.allclose(tr, ref["t_ref"], atol=tol_refined)
+    assert r.n_candidates == ref["n_cand"] and r.n_landmarks == ref["n_landmarks"]
+    st = pipe.get_state()
+    check_state(st, ref["features"], ref["pose"])
+    assert st["n_iterations"] == ref["n_iterations"] and st["outlier_ratio"] == ref["outlier_ratio"]
+    g = np.random.default_rng(0)
+    pipe.rng_state_into(g)
+    assert g.bit_generator.state == gen_ref.bit_generator.state, "estimator generator state differs from the oracle's"
+
+
+@pytest.mark.parametrize("H,W,N,hyp,frac,redetect", [(240, 320, 300, 256, 1.0, "identity"),
+                                                      (480, 640, 500, 1000, 0.83, "identity"),
+                                                      (480, 640, 500, 1000, 0.83, "current")])
+def test_pipeline_matches_oracle_loop(ctx, H, W, N, hyp, frac, redetect):
+    """Every array the reference carries from frame to frame, after every frame: keypoints, states, candidate
+    masks, tracks bit for bit; landmarks and poses to rounding; RANSAC bookkeeping and the generator state
+    exact.  frac < 1 starts below 80 % of the detector's count so the re-detect branch (klt.py:207-230) runs:
+    with the reference's np.eye(4) start pose for the new keypoints ("identity"; their triangulation then uses a
+    wrong baseline and the estimate leaves the ground truth, in the oracle exactly as on the device), and with
+    the pipeline's optional correction ("current")."""
+    from vo import synthetic
+    F = 6
     stream = synthetic.Stream(F, H, W)
-    cfg = dict(win=15, lvl=2, N=N)
-    pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp,
-                            p3p_threshold=1.0, max_iterations=1000)
-    for i in range(F):
-        pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
-    order = stream.order(6)
-    pipe.prime(order[0])
-    kp = harris_np.nms_keypoints_fast(harris_np.harris_scores(stream.image(order[0]), 9, 0.09), N, 5)[:, :, 0]
-    rs = ransac_np.Ransac(4, np.arange(4), None, None, 1.0, 0.9, 0.99, 1000, adaptive=True, p3p=True)
+    feats, T = start_state(stream, N, frac)
+    pipe = make_pipe(ctx, stream, N, hyp, redetect_start_pose=redetect)
+    pipe.set_state(0, feats, T, T)
+    orc = OracleLoop(stream, N, 15, 2, refine_iters=20, redetect_start_pose=redetect)
+    orc.set_state(0, feats, T, T)
+    check_state(pipe.get_state(), feats, T)
+    order = stream.order(7)
+    redetects = 0
     for a, b in zip(order[:-1], order[1:]):
-        ref = oracle_step(stream, a, b, kp, rs, cfg)
+        ref = orc.step(b)
         r = pipe.step(a, b)
-        got = pipe.fetch(r.n_tracked)
-        assert r.n_tracked == len(ref["prev_xy"])
-        assert np.array_equal(got["kp_next"], ref["kp_next"])
-        assert np.array_equal(got["prev_xy"], ref["prev_xy"]) and np.array_equal(got["next_xy"], ref["next_xy"])
-        assert np.allclose(got["landmarks"], ref["landmarks"], rtol=1e-12, atol=1e-12)
-        assert r.draws_consumed == ref["draws"] and r.ransac_iterations == ref["iters"]
-        R, t = np.array(r.R).reshape(3, 3), np.array(r.t)
-        assert np.allclose(R, ref["R"], atol=1e-9) and np.allclose(t, ref["t"], atol=1e-9)
-        assert np.array_equal(got["inliers"], ref["inliers"]) and r.n_inliers == ref["inliers"].sum()
-        assert np.allclose(got["triangulated"], ref["tri"], rtol=1e-6, atol=1e-6)
+        redetects += r.redetected
+        assert r.n_features_in == ref["n_before"] + (N if r.redetected else 0)
+        check_step(r, ref, pipe, orc.rs.rng)
         # against analytic ground truth of the stream
-        Tcw = np.linalg.inv(stream.T_world_cam(b))
-        assert np.abs(R - Tcw[:3, :3]).max() < 5e-3 and np.abs(t - Tcw[:3, 3]).max() < 0.1
-        kp = ref["kp_next"]
+        if redetect == "current" or redetects == 0:
+            Tcw = np.linalg.inv(stream.T_world_cam(b))
+            assert np.abs(np.array(r.R_refined).reshape(3, 3) - Tcw[:3, :3]).max() < 5e-3
+            assert np.abs(np.array(r.t_refined) - Tcw[:3, 3]).max() < 0.1
+    if frac < 1.0:
+        assert redetects >= 1, "the re-detect branch was meant to run"
     pipe.close()
 
 
-@pytest.mark.parametrize("sampler", ["device", "sequential"])
-def test_pipeline_lookahead_matches_step(ctx, sampler, monkeypatch):
-    """submit(k+1) before collect(k) (one frame of look-ahead) must give what step() gives frame by
-    frame: same counts, same RANSAC bookkeeping, same poses -- including the generator hand-over
-    between a collected step and the one already in flight."""
-    from vo import _native, synthetic
-    if sampler == "sequential":
-        monkeypatch.setenv("VO_SEQ_SAMPLER", "1")
+def run_all(pipe, pairs, lookahead):
+    out = []
+    if lookahead:
+        pipe.submit(*pairs[0])
+        for k in range(len(pairs)):
+            if k + 1 < len(pairs):
+                pipe.submit(*pairs[k + 1])
+            out.append(pipe.collect())
     else:
-        monkeypatch.delenv("VO_SEQ_SAMPLER", raising=False)
+        out = [pipe.step(a, b) for a, b in pairs]
+    return out
+
+
+def fields(r):
+    return (r.n_features_in, r.redetected, r.n_tracked, r.n_triangulated, r.n_inliers, r.ransac_iterations,
+            r.draws_consumed, r.n_candidates, r.n_dropped, r.n_landmarks, tuple(r.R), tuple(r.t), tuple(r.R_refined),
+            tuple(r.t_refined), tuple(r.T_wc))
+
+
+def test_pipeline_lookahead_and_host_recovery_match_blocking_steps(ctx):
+    """(i) submit(k+1) before collect(k) gives what step() gives frame by frame; (ii) so does a run in which
+    every third step is forced off the device-only path (debug_fault_every) and finished by the host's
+    sequential sampler (the path a possibly rejected bounded draw or a tiny population takes) -- including
+    steps submitted behind the faulted one, which are re-enqueued."""
+    from vo import synthetic
     H, W, N, hyp, F = 240, 320, 300, 256, 5
     stream = synthetic.Stream(F, H, W)
     order = stream.order(12)
-
-    def make():
-        pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp,
-                                p3p_threshold=1.0, max_iterations=1000)
-        for i in range(F):
-            pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
-        pipe.prime(order[0])
-        return pipe
-
-    def fields(r):
-        return (r.n_tracked, r.n_inliers, r.best_index, r.hyp_valid, r.ransac_iterations, r.draws_consumed,
-                tuple(r.R), tuple(r.t))
-
-    pipe = make()
-    ref = [fields(pipe.step(a, b)) for a, b in zip(order[:-1], order[1:])]
-    pipe.close()
-    pipe = make()
-    got = []
     pairs = list(zip(order[:-1], order[1:]))
-    pipe.submit(*pairs[0])
-    for k in range(len(pairs)):
-        if k + 1 < len(pairs):
-            pipe.submit(*pairs[k + 1])
-        got.append(fields(pipe.collect()))
-    last = pipe.fetch(got[-1][0])            # nothing in flight any more: fetch works again
-    assert last["prev_xy"].shape == (got[-1][0], 2)
+    feats, T = start_state(stream, N, 0.85)
+
+    def run(lookahead, **kw):
+        pipe = make_pipe(ctx, stream, N, hyp, **kw)
+        pipe.set_state(0, feats, T, T)
+        res = run_all(pipe, pairs, lookahead)
+        st = pipe.get_state()
+        g = np.random.default_rng(0)
+        pipe.rng_state_into(g)
+        pipe.close()
+        return res, st, g.bit_generator.state
+
+    ref, st_ref, g_ref = run(False)
+    assert all(r.recovered == 0 for r in ref)
+    for la, kw in ((True, {}), (False, dict(debug_fault_every=3)), (True, dict(debug_fault_every=3))):
+        got, st, g = run(la, **kw)
+        assert [fields(r) for r in got] == [fields(r) for r in ref], (la, kw)
+        if kw:
+            assert sum(r.recovered for r in got) == len(pairs) // 3
+        assert g == g_ref
+        for k in ("keypoints", "state", "candidate_mask", "landmarks", "tracks", "poses", "curr_pose"):
+            assert np.array_equal(st[k], st_ref[k], equal_nan=True), k
+
+
+def test_pipeline_at_configuration_size(ctx):
+    """BASELINE.json configs[1] as a pipeline: 1376x1241, 2000 keypoints, 3-level 15x15 KLT, 1000 hypotheses,
+    look-ahead AND device refinement, against the oracle loop on the same frames."""
+    from vo import synthetic
+    H, W, N, hyp, F = 1241, 1376, 2000, 1000, 4
+    stream = synthetic.Stream(F, H, W)
+    feats, T = start_state(stream, N, 0.81)
+    pipe = make_pipe(ctx, stream, N, hyp)
+    pipe.set_state(0, feats, T, T)
+    orc = OracleLoop(stream, N, 15, 2, refine_iters=20)
+    orc.set_state(0, feats, T, T)
+    order = stream.order(4)
+    pairs = list(zip(order[:-1], order[1:]))
+    refs = [orc.step(b) for _, b in pairs]
+    got = run_all(pipe, pairs, lookahead=True)
+    for r, ref in zip(got, refs):
+        assert r.fault == 0
+        assert (r.n_tracked, r.n_triangulated, r.draws_consumed, r.ransac_iterations, r.n_inliers, r.n_candidates,
+                r.n_landmarks) == (ref["n_tracked"], ref["n_tri"], ref["draws"], ref["iters"], ref["n_inliers"],
+                                   ref["n_cand"], ref["n_landmarks"])
+        assert np.allclose(np.array(r.R).reshape(3, 3), ref["R"], atol=1e-9)
+        assert np.allclose(np.array(r.R_refined).reshape(3, 3), ref["R_ref"], atol=1e-7)
+        assert np.allclose(np.array(r.t_refined), ref["t_ref"], atol=1e-7)
+    check_state(pipe.get_state(), refs[-1]["features"], refs[-1]["pose"])
+    assert sum(r.redetected for r in got) >= 1
     pipe.close()
-    assert got == ref
 
 
 def test_pipeline_stress_configuration_properties(ctx):
-    """BASELINE.json configs[4] (3840x2160, 8000 keypoints, 4-level pyramid, 4000 hypotheses): far
-    beyond what the oracle finishes in seconds, so checked through properties that do not depend
-    on size -- the greedy NMS rule (keypoints in decreasing score order, no two within r, none
-    better left unsuppressed), tracked points near the frame, and the recovered pose against the
-    stream's analytic ground truth."""
-    from vo import _native, synthetic
+    """BASELINE.json configs[4] (3840x2160, 8000 keypoints, 4-level pyramid, 4000 hypotheses): beyond what the
+    oracle finishes in seconds, so checked through properties that do not depend on size -- the greedy NMS rule
+    on the detector's output, the feature groups' invariants, and the recovered pose against the stream's
+    analytic ground truth."""
+    from vo import synthetic
     H, W, N, hyp, F, r = 2160, 3840, 8000, 4000, 3, 5
     stream = synthetic.Stream(F, H, W)
-    pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, klt_win=15, klt_max_level=3, hyp=hyp,
-                            p3p_threshold=1.0, max_iterations=1000)
-    for i in range(F):
-        pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
-    pipe.prime(0)
+    pipe = make_pipe(ctx, stream, N, hyp, lvl=3)
+    kp0 = ctx.harris_keypoints(stream.image(0), 9, 0.09, N, r)
+    from vo.primitives import Features
+    K, T = stream.K, stream.T_world_cam(0)
+    f = Features(keypoints=kp0.reshape(N, 2, 1).astype(np.float32))
+    z = stream.depth(0)[kp0[:, 1].astype(int), kp0[:, 0].astype(int)].astype(np.float64)
+    xc, yc = (kp0[:, 0] - K[0, 2]) / K[0, 0] * z, (kp0[:, 1] - K[1, 2]) / K[1, 1] * z
+    f.landmarks = np.stack([T[q, 0] * xc + T[q, 1] * yc + T[q, 2] * z + T[q, 3] for q in range(3)], axis=1).reshape(N, 3, 1)
+    f.state = 2 * np.ones(N)
+    f.tracks = np.full((N, 2, 1), np.nan)
+    f.poses = np.full((N, 4, 4), np.nan)
+    pipe.set_state(0, f, T, T)
     for a, b in ((0, 1), (1, 2)):
         res = pipe.step(a, b)
-        got = pipe.fetch(res.n_tracked)
-        # pose
         Tcw = np.linalg.inv(stream.T_world_cam(b))
-        R, t = np.array(res.R).reshape(3, 3), np.array(res.t)
-        assert res.n_tracked > 0.8 * N and res.n_inliers > 0.3 * res.n_tracked
-        assert np.abs(R - Tcw[:3, :3]).max() < 5e-3 and np.abs(t - Tcw[:3, 3]).max() < 0.1
-        # (OpenCV's rule keeps a track while its window's corner is within one window of the frame)
-        assert (got["next_xy"] > -15).all() and (got["next_xy"][:, 0] < W + 15).all() and (got["next_xy"][:, 1] < H + 15).all()
+        assert res.fault == 0 and res.n_tracked > 0.7 * res.n_features_in and res.n_inliers > 0.3 * res.n_triangulated
+        assert np.abs(np.array(res.R_refined).reshape(3, 3) - Tcw[:3, :3]).max() < 5e-3
+        assert np.abs(np.array(res.t_refined) - Tcw[:3, 3]).max() < 0.1
+        st = pipe.get_state()
+        s = st["state"]
+        n_tri = int((s == 2).sum())
+        assert st["n"] == res.n_tracked and n_tri == res.n_landmarks
+        assert not np.isnan(st["landmarks"][s == 2]).any()
+        assert not np.isnan(st["tracks"][s != 2]).any() and not np.isnan(st["poses"][s != 2]).any()
+        assert (st["keypoints"] > -15).all() and (st["keypoints"][:, 0] < W + 15).all()
         # NMS of frame b
-        kp = got["kp_next"].astype(np.int64)
+        kp = pipe.get_detection().astype(np.int64)
         sc = ctx.harris_response(stream.image(b), 9, 0.09)
-        s = sc[kp[:, 1], kp[:, 0]]
-        assert (s > 0).all() and (np.diff(s) <= 0).all(), "keypoints are not in decreasing score order"
+        v = sc[kp[:, 1], kp[:, 0]]
+        assert (v > 0).all() and (np.diff(v) <= 0).all(), "keypoints are not in decreasing score order"
         occupied = np.zeros((H, W), bool)
-        for (x, y) in kp:                                   # no pick inside an earlier pick's window
+        for (x, y) in kp:
             assert not occupied[y, x]
             occupied[max(y - r, 0):y + r + 1, max(x - r, 0):x + r + 1] = True
-        # nothing better than the last pick is left outside every window (the greedy rule took the
-        # best remaining pixel each time)
-        left = np.where(occupied, 0.0, sc)
-        assert left.max() <= s[-1]
+        assert np.where(occupied, 0.0, sc).max() <= v[-1]
     pipe.close()
+
+
+def test_device_bookkeeping_matches_reference_golden(ctx):
+    """The scripted 3-frame run of tests/scenarios.py, whose arrays tests/golden/bookkeeping.npz holds as the
+    REFERENCE's own classes produced them: the bootstrap part on the host (as in the driver), the two steady
+    state frames on the device (regroup with an explicit match list, pose, outliers, candidates, candidate
+    triangulation, cheirality).  Copied values (keypoints, states, masks, tracks, landmark NaN pattern) must be
+    bit-identical; computed ones (poses, triangulated landmarks) to rounding."""
+    import types
+    import scenarios
+    import vo.primitives as P
+    from vo import _native
+    from vo.landmarks import LandmarksTriangulator
+    from vo.sensors import Camera
+    g = np.load(os.path.join(G, "bookkeeping.npz"))
+    ns = types.SimpleNamespace(Features=P.Features, Frame=P.Frame, Matches=P.Matches, State=P.State, Camera=Camera,
+                               LandmarksTriangulator=LandmarksTriangulator)
+    # host pass, recording what each steady-state frame is given
+    calls = []
+    real_matches = P.Matches
+
+    class Spy(real_matches):
+        def __init__(self, f1, f2, pairs):
+            calls.append(dict(kp=f2.features.keypoints.copy(), pairs=np.array(pairs)))
+            super().__init__(f1, f2, pairs)
+
+    ns.Matches = Spy
+    host = scenarios.bookkeeping_scenario(ns)
+    for k in g.files:       # (the host classes are pinned: test_api_host.py; here their DLT runs on the GPU)
+        assert np.allclose(host[k], g[k], rtol=1e-9, atol=1e-9, equal_nan=True), k
+    K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+    pipe = _native.Pipeline(ctx, 64, 64, 2, K, n_keypoints=64, hyp=16, bearing_threshold=0.05)
+    boot = P.Features(keypoints=g["boot_keypoints"], landmarks=g["boot_landmarks"].copy())
+    boot.state, boot.tracks, boot.poses = g["boot_state"], g["boot_tracks"], g["boot_poses"]
+    pipe.set_frame(0, np.zeros((64, 64), np.uint8))
+    pipe.set_state(0, boot, g["boot_pose"], np.eye(4))
+    prev_pose = g["boot_pose"]
+    for step, tag in ((1, "s2"), (2, "s3")):
+        c = calls[step]
+        n_tri = int((g[tag + "_m_f2_state"] == 2).sum())
+        inl = np.ones(n_tri, dtype=bool)
+        inl[1] = False
+        pipe.bookkeeping(1, c["kp"], c["pairs"], g[tag + "_pose"], inl)
+        pre = pipe.get_state()
+        for name in ("keypoints", "state", "candidate_mask", "tracks"):
+            assert np.array_equal(pre[name].astype(np.float64), g[tag + "_pre_" + name].astype(np.float64), equal_nan=True), (tag, name)
+        assert np.array_equal(pre["landmarks"], g[tag + "_pre_landmarks"], equal_nan=True)
+        assert np.array_equal(pre["poses"][:, :3], g[tag + "_pre_poses"][:, :3], equal_nan=True)
+        assert np.array_equal(pre["curr_pose"][:3], g[tag + "_pose"][:3]) and np.array_equal(pre["prev_pose"][:3], prev_pose[:3])
+        pipe.bookkeeping(2)
+        post = pipe.get_state()
+        for name in ("keypoints", "state", "candidate_mask", "tracks"):
+            assert np.array_equal(post[name].astype(np.float64), g[tag + "_post_" + name].astype(np.float64), equal_nan=True), (tag, name)
+        assert np.array_equal(np.isnan(post["landmarks"]), np.isnan(g[tag + "_post_landmarks"]))
+        assert np.allclose(post["landmarks"], g[tag + "_post_landmarks"], rtol=1e-9, atol=1e-9, equal_nan=True)
+        assert np.array_equal(post["poses"][:, :3], g[tag + "_post_poses"][:, :3], equal_nan=True)
+        prev_pose = g[tag + "_pose"]
+    pipe.close()
+
+
+def test_device_ransac_bound_equals_the_reference_formula(ctx):
+    """The device evaluates ransac.py:58-67 through a threshold table built from the host's libm; it must return
+    the formula's value for every (inlier count, population) the loop can produce."""
+    from oracle import ransac_np
+    from vo import _native
+    K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+    for conf, max_it, hyp in ((0.99, 1000, 1000), (0.9999, 10000, 4000)):
+        pipe = _native.Pipeline(ctx, 64, 64, 2, K, n_keypoints=64, hyp=hyp, confidence=conf, max_iterations=max_it)
+        rng = np.random.default_rng(5)
+        pops = np.unique(np.concatenate([np.arange(8, 200), rng.integers(200, 16000, size=120)]))
+        bad = 0
+        for N in pops:
+            c = np.arange(0, N + 1) if N < 200 else np.unique(rng.integers(0, N + 1, size=300))
+            orat = np.minimum(np.maximum(1 - c / N, 0.01), 0.99)
+            for o in orat:
+                want = ransac_np.num_iterations(conf, float(o), 4)
+                got = pipe.ransac_bound(float(o))
+                if want <= hyp:
+                    bad += int(got != min(max_it, want))
+                else:
+                    bad += int(got <= hyp and got != max_it)
+        pipe.close()
+        assert bad == 0
 
 
 def test_pipeline_records_for_the_shared_map(ctx):
     """vo_pipeline_export_state_post / _join with a step in flight: the record of every collected step
-    [T_cw | n | landmarks] equals the refined pose of its result and what fetch() returns for the same step
-    run blocking (the per-GPU record that is all-gathered)."""
-    from vo import _native, sharding, synthetic
+    [T_cw | n | landmarks] holds the refined pose of its result and the landmarks of the step's P3P population
+    (the per-GPU record that is all-gathered)."""
+    from vo import sharding, synthetic
     H, W, N, hyp, F = 240, 320, 300, 256, 5
     stream = synthetic.Stream(F, H, W)
     order = stream.order(8)
     pairs = list(zip(order[:-1], order[1:]))
+    feats, T = start_state(stream, N)
 
-    def make():
-        pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp,
-                                p3p_threshold=1.0, max_iterations=1000, refine_iters=10)
-        for i in range(F):
-            pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
-        pipe.prime(order[0])
-        return pipe
-
-    pipe = make()
+    pipe = make_pipe(ctx, stream, N, hyp, refine=10)
+    pipe.set_state(0, feats, T, T)
     ref = []
     for a, b in pairs:
         r = pipe.step(a, b)
-        ref.append((np.array(r.R_refined).reshape(3, 3), np.array(r.t_refined), pipe.fetch(r.n_tracked)["triangulated"]))
+        st = pipe.get_state()
+        ref.append((np.array(r.R_refined).reshape(3, 3), np.array(r.t_refined), st["landmarks"][: r.n_triangulated, :, 0], r))
     pipe.close()
 
     cap = N
     L = sharding.record_length(cap)
     recs = ctx.to_device(np.zeros(len(pairs) * L))
-    pipe = make()
+    pipe = make_pipe(ctx, stream, N, hyp, refine=10)
+    pipe.set_state(0, feats, T, T)
     pipe.submit(*pairs[0])
     for k in range(len(pairs)):
         if k + 1 < len(pairs):
             pipe.submit(*pairs[k + 1])
         r = pipe.collect()
         pipe.export_state_post(r, cap, recs + k * L * 8)
-    pipe.export_state_join()                 # consumer = the context's stream, which the download uses
+    pipe.export_state_join()
+    ctx.sync()
     host = ctx.download(recs, (len(pairs) * L,), np.float64)
     pipe.close()
     ctx.free(recs)
     got = sharding.unpack_records(host, len(pairs), cap)
-    for (T, lm), (R, t, tri) in zip(got, ref):
-        np.testing.assert_array_equal(T[:3, :3], R)
-        np.testing.assert_array_equal(T[:3, 3], t)
-        np.testing.assert_array_equal(T[3], [0, 0, 0, 1])
-        np.testing.assert_array_equal(lm, tri[:cap])
+    for (Tm, lm), (R, t, land, r) in zip(got, ref):
+        np.testing.assert_array_equal(Tm[:3, :3], R)
+        np.testing.assert_array_equal(Tm[:3, 3], t)
+        np.testing.assert_array_equal(Tm[3], [0, 0, 0, 1])
+        assert len(lm) == min(r.n_triangulated, cap)
+        np.testing.assert_array_equal(lm, land[: len(lm)])       # (NaN where the cheirality check dropped one)

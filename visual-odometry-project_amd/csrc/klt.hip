@@ -312,12 +312,13 @@ __device__ __forceinline__ void wave_sync() {
 
 // WIN_T > 0: window side known at compile time (index arithmetic folds, loops unroll)
 template <int WIN_T>
-__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, int win_arg,
+__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, int win_arg,
                                                        int max_iter, double eps2, float min_eig_thr,
                                                        float* __restrict__ next_xy, uint8_t* __restrict__ status,
                                                        float* __restrict__ err, int lds_per_wave) {
   extern __shared__ __align__(16) unsigned char smem_all[];
   const int i = blockIdx.x * KLT_WAVES + (threadIdx.x >> 6);
+  if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
   if (i >= N) return;                                  // whole wave leaves together
   unsigned char* smem = smem_all + (size_t)(threadIdx.x >> 6) * lds_per_wave;
   const int lane = threadIdx.x & 63;
@@ -627,7 +628,7 @@ __device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pit
 }
 
 template <int WIN, int LPK>
-__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, int max_iter,
+__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, int max_iter,
                                                          double eps2, float min_eig_thr, float* __restrict__ next_xy,
                                                          uint8_t* __restrict__ status, float* __restrict__ err) {
   typedef klt_rows<WIN> G;
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   __shared__ __align__(16) uint8_t smem[KPW * G::SLICE + 16];
   const int lane = threadIdx.x;
   const int i = blockIdx.x * KPW + lane / LPK;
+  if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
   if (i >= N) return;                                  // all lanes of a keypoint leave together
   const int r = lane & (LPK - 1);                      // window row of this lane (row WIN only feeds row WIN-1's derivatives)
   uint8_t* s_reg = smem + (lane / LPK) * G::SLICE;
@@ -958,6 +960,17 @@ int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_
 int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
                      const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N, int win,
                      int max_iter, double eps, double min_eig, float* d_next_xy, uint8_t* d_status, float* d_err) {
+  return vo_klt_track_ndev(ctx, d_prev, d_prev_pyr, d_next, d_next_pyr, H, W, n_levels, d_prev_xy, N, nullptr, win,
+                           max_iter, eps, min_eig, d_next_xy, d_status, d_err);
+}
+
+}  // extern "C"
+
+// Pipeline-internal form: at most N keypoints, the actual count is read from *d_n when the kernel runs.
+int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
+                      const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N,
+                      const int32_t* d_n, int win, int max_iter, double eps, double min_eig, float* d_next_xy,
+                      uint8_t* d_status, float* d_err) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, N >= 0, "klt_track: bad N");
   if (N == 0) return VO_OK;
@@ -999,24 +1012,26 @@ int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_p
     const dim3 kgrid(vo_cdiv(N, KLT_WAVES)), kblock(64 * KLT_WAVES);
     switch (win) {
       case 15:
-        hipLaunchKernelGGL((klt_track16_kernel<15, 16>), dim3(vo_cdiv(N, 4)), dim3(64), 0, st, P, d_prev_xy, N, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<15, 16>), dim3(vo_cdiv(N, 4)), dim3(64), 0, st, P, d_prev_xy, N, d_n, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 17:   // the reference's default window (klt.py:29)
-        hipLaunchKernelGGL((klt_track16_kernel<17, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<17, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, d_n, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 21:
-        hipLaunchKernelGGL((klt_track16_kernel<21, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<21, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, d_n, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       default:
-        hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, win, max_iter, eps * eps,
+        hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, d_n, win, max_iter, eps * eps,
                            me, d_next_xy, d_status, d_err, lds_wave);
     }
   }
   return vo_check_launch(ctx, "klt_track_kernel");
 }
+
+extern "C" {
 
 int vo_klt_track(vo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int H, int W, const float* prev_xy, int N,
                  int win, int max_level, int max_iter, double eps, double min_eig, float* next_xy, uint8_t* status,

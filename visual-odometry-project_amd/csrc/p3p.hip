@@ -244,6 +244,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
                                                        const int* __restrict__ samples,
                                                        const unsigned* __restrict__ raws,
                                                        const unsigned* __restrict__ rawctl, unsigned raw_tag,
+                                                       const unsigned long long* __restrict__ d_rawpos, unsigned raw_mask,
                                                        const int* __restrict__ d_n, unsigned* __restrict__ flag,
                                                        int Hyp, double fx,
                                                        double fy, double cx, double cy, double* __restrict__ Rout,
@@ -341,8 +342,12 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
     __syncthreads();
     raws += s_pos;
   }
+  // (device-resident frame state: the position in the generator's output stream is a word the previous
+  //  step's replay kernel left in HBM, the outputs live in a power-of-two ring)
+  const unsigned ring_pos = (RAW && d_rawpos) ? (unsigned)(*d_rawpos) : 0u;
   if (h >= Hyp) return;                 // whole quads leave together
   int sidx[4];
+  bool risky = false;                   // a draw of this sample could have been rejected: valid[h] bit 1
   if (RAW) {
     const int n = own_tracks ? n_tracks : *d_n;
     if (n < 8) {
@@ -356,8 +361,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
     }
     unsigned rw[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) rw[k] = raws[7 * h + k];
-    bool risky = false;
+    for (int k = 0; k < 7; ++k) rw[k] = raws[(ring_pos + 7u * (unsigned)h + (unsigned)k) & raw_mask];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const unsigned j = (unsigned)(n - 4 + k);
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
         if (q == j) sidx[q] = vi;
       sidx[i] = vj;
     }
-    if (risky && sub == 0) atomicOr(flag, 1u);
+    if (risky && sub == 0 && !d_rawpos) atomicOr(flag, 1u);
   } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) sidx[k] = samples[4 * h + k];
@@ -528,12 +532,12 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
       if (sub == 0) {
         for (int k = 0; k < 9; ++k) Rout[9 * h + k] = 0.0;
         for (int k = 0; k < 3; ++k) tout[3 * h + k] = 0.0;
-        valid[h] = 0;
+        valid[h] = risky ? 2 : 0;
       }
     } else if (ki == sub) {
       for (int k = 0; k < 9; ++k) Rout[9 * h + k] = bestR[k];
       for (int k = 0; k < 3; ++k) tout[3 * h + k] = bestt[k];
-      valid[h] = 1;
+      valid[h] = risky ? 3 : 1;
       if (Rhost) {
         for (int k = 0; k < 9; ++k) Rhost[9 * h + k] = bestR[k];
         for (int k = 0; k < 3; ++k) thost[3 * h + k] = bestt[k];
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(SC_T) void p3p_score_kernel(const double* __restric
   for (int k = 0; k < 9; ++k) R[k] = Rall[9 * h + k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = tall[3 * h + k];
-  const bool ok = valid[h] != 0;
+  const bool ok = (valid[h] & 1) != 0;   // (bit 1: see p3p_solve_kernel)
   int cnt = 0;
   for (int base = 0; base < words_n * 64; base += SC_T) {
     const int i = base + tid;
@@ -611,7 +615,7 @@ int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x,
                               const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
                               int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
                               uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t,
-                              const vo_track_source* tracks) {
+                              const vo_track_source* tracks, const uint64_t* d_rawpos, uint32_t raw_mask) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, d_X && d_x && d_n && K && d_raws && d_R && d_t && d_valid && d_counts && d_flag,
              "p3p_hypotheses_raw: null pointer");
@@ -639,8 +643,8 @@ int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x,
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<true>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
-                       (const int*)nullptr, d_raws, d_rawctl, raw_tag, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t,
-                       d_valid, m_R, m_t, T);
+                       (const int*)nullptr, d_raws, d_rawctl, raw_tag, (const unsigned long long*)d_rawpos,
+                       d_rawpos ? raw_mask : 0xffffffffu, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid, m_R, m_t, T);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   {
@@ -665,8 +669,8 @@ int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<false>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
-                       d_samples, (const unsigned*)nullptr, (const unsigned*)nullptr, 0u, (const int*)nullptr,
-                       (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid, (double*)nullptr, (double*)nullptr,
+                       d_samples, (const unsigned*)nullptr, (const unsigned*)nullptr, 0u,
+                       (const unsigned long long*)nullptr, 0xffffffffu, (const int*)nullptr, (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid, (double*)nullptr, (double*)nullptr,
                        p3p_tracks());
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));

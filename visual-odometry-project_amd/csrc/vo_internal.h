@@ -118,7 +118,11 @@ int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x,
                               const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
                               int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
                               uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t,
-                              const vo_track_source* tracks);
+                              const vo_track_source* tracks, const uint64_t* d_rawpos = nullptr,
+                              uint32_t raw_mask = 0xffffffffu);
+// d_rawpos (optional, device memory): absolute position of the step's first generator output; the outputs are
+// then read from the ring d_raws[(pos + k) & raw_mask], and a possibly rejected draw marks its own hypothesis
+// (valid[h] bit 1) instead of raising the batch-wide flag.
 // m_R / m_t (optional, mapped host memory): every pose is also written there.
 // tracks (optional): d_X / d_x / *d_n are then OUTPUTS too -- the kernel compacts the tracked keypoints itself.
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
@@ -130,3 +134,8 @@ int vo_triangulate_dlt_ndev(vo_ctx* ctx, const double* d_x1, const double* d_x2,
 int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const int32_t* d_n, const double* K,
                         const uint8_t* d_mask8, const uint64_t* d_mask_bits, const double* d_Rt0, int max_iter,
                         double* d_out14, unsigned tag);
+// KLT with a device-resident keypoint count (klt.hip)
+int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
+                      const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N,
+                      const int32_t* d_n, int win, int max_iter, double eps, double min_eig, float* d_next_xy,
+                      uint8_t* d_status, float* d_err);

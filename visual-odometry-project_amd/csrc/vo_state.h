@@ -1,0 +1,84 @@
+// Device-resident frame state shared by state.hip (kernels) and pipeline.hip (orchestration).
+//
+// One sequence keeps, in HBM, what the reference keeps in Python objects between frames:
+//   Features  (src/vo/primitives/features.py:4-54): keypoints, state codes, landmarks, track starts,
+//             track start poses, candidate mask -- as structure-of-arrays with a fixed capacity;
+//   State     (src/vo/primitives/state.py:9-15): current / previous pose;
+//   RANSAC    (src/vo/algorithms/ransac.py:42-56): the fields that persist on the estimator object
+//             between find_best_model calls (n_iterations, outlier_ratio) and the position in the
+//             generator's output stream;
+//   KLTTracker._num_features (src/vo/features/klt.py:113).
+#pragma once
+#include "vo_internal.h"
+
+struct vo_feat {
+  float* kp;         // cap x 2, float32 as cv2.calcOpticalFlowPyrLK returns them (klt.py:233-241)
+  double* kp64;      // cap x 2, the same values as float64: what P3P / DLT / the bearing test read
+  uint8_t* state;    // cap: 0 unmatched, 1 matched, 2 triangulated (features.py:41-43)
+  uint8_t* cand;     // cap: candidate_mask (features.py:54)
+  double* land;      // cap x 3, NaN = unknown
+  double* track;     // cap x 2, keypoint at which the track started
+  double* pose;      // cap x 12, rows 0..2 of the 4x4 camera-to-world pose at the track's start (NaN = none)
+};
+
+enum {
+  VO_FAULT_FEW_LANDMARKS = 1,   // fewer than 8 triangulated tracks: the device-side sampler does not apply
+  VO_FAULT_RISKY_DRAW = 2,      // a bounded draw inside the consumed prefix could have been rejected by NumPy
+  VO_FAULT_UNFINISHED = 4,      // the sequential rule is not done after `hyp` samples
+  VO_FAULT_CAPACITY = 8,        // appending the detector's keypoints would exceed the feature capacity
+  VO_FAULT_FORCED = 16          // test hook (vo_pipeline_config.debug_fault_every)
+};
+
+struct vo_seq_ctl {
+  // ---- Features / tracker bookkeeping ----
+  int32_t n;               // features of the current frame
+  int32_t num_features;    // KLTTracker._num_features
+  int32_t n_in;            // features handed to the tracker (after a possible re-detect)
+  int32_t redetected;
+  int32_t n2, n_tri, n_mat, n_new;   // new frame: total, and the sizes of its first three groups
+  int32_t n_p3p;           // population the hypothesis kernels see: n_tri, or 0 when the step must not run
+  int32_t fault;           // sticky: every later kernel of this and the following steps leaves the state alone
+  int32_t step;            // steps completed
+  int32_t solve_flag;      // raised by the solve kernel (population < 8)
+  // ---- RANSAC: persists across frames like the reference's estimator object ----
+  int64_t n_iterations;
+  double outlier_ratio;
+  uint64_t raw_pos;        // absolute index of the next unread 32-bit generator output
+  // ---- this step ----
+  int32_t best_idx, best_count, consumed, hyp_valid;
+  int64_t n_done;
+  int32_t n_cand, n_dropped, n_land, pad1;
+  double best_pose[12];    // R (9, row-major) then t (3) of the accepted hypothesis
+  double refined[16];      // refine_pose_kernel's output: R, t, accepted steps, cost (+ tag)
+  // 3x4 row-major, world->camera and camera->world: State.curr_pose / State.prev_pose (state.py:9-15), and a
+  // pose handed in by the host (vo_pipeline_bookkeeping)
+  double T_cw[12], T_wc[12], T_cw_prev[12], T_wc_prev[12], T_in_cw[12], T_in_wc[12];
+};
+
+struct vo_cam {
+  double K[9], Kinv[9];
+};
+
+// ---- launches (state.hip); all asynchronous on ctx->stream ----
+// klt.py:207-230: when fewer than frac * _num_features survive, the detector's keypoints of the old
+// frame are appended as new, unmatched features (update_features, klt.py:117-189)
+int vo_state_append(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat F, const double* d_det_kp, int n_det, double frac, int cap,
+                    int debug_fault_every, int pose_mode);
+// klt.py:244-278 + matches.py:26-212: keep status & err < thr, then the 4-group regroup of the new frame
+int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const float* d_next_xy,
+                         const uint8_t* d_status, const float* d_err, float err_thr, int cap);
+// matches.py:26-212 for an explicit match list (harris / sift trackers, tests)
+int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const int32_t* d_pairs, int M,
+                           const double* d_new_kp, int n2_in, int cap);
+// ransac.py:90-121 replayed over (valid, count) of the hypothesis batch; thr_table: see pipeline.hip
+int vo_state_ransac_replay(vo_ctx* ctx, vo_seq_ctl* ctl, const uint8_t* d_valid, const int32_t* d_counts,
+                           const double* d_R, const double* d_t, const uint64_t* d_masks, int words, int hyp,
+                           const double* d_thr_table, int table_len, int64_t max_iterations, uint64_t* d_best_mask);
+// main.py:261-286 + state.py:38-50, 90-107, 135-219 + triangulation.py:38-86.  phases: bit 0 = pose, outliers,
+// candidates; bit 1 = candidate triangulation, landmark insertion, cheirality check, step bookkeeping.
+int vo_state_update(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
+                    double bearing_thr, int use_refined, int phases, int cap, vo_step_result* m_result,
+                    unsigned* m_seq, unsigned seq);
+// n_iterations for an outlier ratio through the threshold table (host copy of the device lookup; tests)
+int64_t vo_ransac_table_lookup(const double* table, int table_len, int64_t max_iterations, double outlier_ratio);
+void vo_ransac_build_table(double confidence, int s, int table_len, double* table);

@@ -6,6 +6,7 @@ context is created, the caller gets an exception, never a silent slow path.
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -65,14 +66,24 @@ class PipelineConfig(C.Structure):
                 ("klt_eps", C.c_double), ("klt_min_eig", C.c_double), ("klt_err_threshold", C.c_double),
                 ("p3p_thr_sq", C.c_double), ("ransac_outlier_ratio", C.c_double), ("ransac_confidence", C.c_double),
                 ("ransac_max_iterations", C.c_int64),
-                ("K", C.c_double * 9), ("refine_iters", C.c_int32), ("pad", C.c_int32)]
+                ("K", C.c_double * 9), ("Kinv", C.c_double * 9), ("refine_iters", C.c_int32), ("feature_cap", C.c_int32),
+                ("bearing_threshold", C.c_double), ("redetect_fraction", C.c_double),
+                ("debug_fault_every", C.c_int32), ("redetect_start_pose", C.c_int32)]
 
 
 class StepResult(C.Structure):
     _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("n_tracked", C.c_int32), ("n_inliers", C.c_int32),
                 ("best_index", C.c_int32), ("hyp_valid", C.c_int32), ("ransac_iterations", C.c_int64),
                 ("draws_consumed", C.c_int32), ("refine_iterations", C.c_int32),
-                ("R_refined", C.c_double * 9), ("t_refined", C.c_double * 3), ("refine_cost", C.c_double)]
+                ("R_refined", C.c_double * 9), ("t_refined", C.c_double * 3), ("refine_cost", C.c_double),
+                ("n_features_in", C.c_int32), ("redetected", C.c_int32), ("n_triangulated", C.c_int32),
+                ("n_candidates", C.c_int32), ("n_dropped", C.c_int32), ("n_landmarks", C.c_int32),
+                ("fault", C.c_int32), ("recovered", C.c_int32), ("raw_pos", C.c_uint64), ("T_wc", C.c_double * 12)]
+
+    def pose_world_cam(self):
+        """State.curr_pose after the step: camera-to-world, 4x4."""
+        return np.vstack([np.array(self.T_wc).reshape(3, 4), [0.0, 0.0, 0.0, 1.0]])
+
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 _SIGS = {
@@ -124,18 +135,22 @@ _SIGS = {
     "vo_ransac_replay": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "vo_pipeline_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "vo_pipeline_destroy": (None, [_vp]),
-    "vo_pipeline_set_frame": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "vo_pipeline_set_frame": (_i, [_vp, _i, _vp]),
     "vo_pipeline_seed": (_i, [_vp, _vp]),
-    "vo_pipeline_prime": (_i, [_vp, _i]),
+    "vo_pipeline_get_rng": (_i, [_vp, _vp]),
+    "vo_pipeline_set_state": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "vo_pipeline_feature_cap": (_i, [_vp]),
+    "vo_pipeline_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vo_pipeline_get_detection": (_i, [_vp, _vp]),
     "vo_pipeline_step": (_i, [_vp, _i, _i, _vp]),
     "vo_pipeline_submit": (_i, [_vp, _i, _i]),
     "vo_pipeline_collect": (_i, [_vp, _vp]),
-    "vo_pipeline_fetch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vo_pipeline_export_state_dev": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "vo_pipeline_bookkeeping": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "vo_pipeline_export_state_post": (_i, [_vp, _vp, _i, _vp]),
     "vo_pipeline_export_state_join": (_i, [_vp, _vp]),
     "vo_pipeline_prof_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_int64)]),
     "vo_pipeline_prof_reset": (_i, [_vp]),
+    "vo_pipeline_ransac_bound": (C.c_int64, [_vp, _d]),
 }
 
 
@@ -181,9 +196,12 @@ class Context:
             raise VoError(rc, "vo_create(device=%d) failed: no usable MI355X/HIP device (no CPU fallback)" % device)
         self._h = h
         self.device = device
+        self._pipelines = weakref.WeakSet()      # pipelines built on this context: closed before it is
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in list(self._pipelines):
+                p.close()
             self._lib.vo_destroy(self._h)
             self._h = None
 
@@ -470,95 +488,7 @@ def ransac_num_iterations(confidence, outlier_ratio, s):
     return int(load().vo_ransac_num_iterations(float(confidence), float(outlier_ratio), int(s)))
 
 
-class Pipeline:
-    """Device-resident frame pipeline (vo_pipeline_*)."""
-
-    def __init__(self, ctx, H, W, n_frames, K, n_keypoints=2000, harris_patch=9, harris_kappa=0.09, nms_radius=5,
-                 klt_win=15, klt_max_level=2, klt_max_iter=10, klt_eps=0.03, klt_min_eig=1e-4,
-                 klt_err_threshold=100.0, hyp=1000, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99,
-                 max_iterations=1000, seed=2023, refine_iters=0):
-        self.ctx = ctx
-        self.cfg = PipelineConfig()
-        c = self.cfg
-        c.H, c.W, c.n_frames = H, W, n_frames
-        c.n_keypoints, c.harris_patch, c.nms_radius, c.harris_kappa = n_keypoints, harris_patch, nms_radius, harris_kappa
-        c.klt_win, c.klt_max_level, c.klt_max_iter, c.hyp = klt_win, klt_max_level, klt_max_iter, hyp
-        c.klt_eps, c.klt_min_eig, c.klt_err_threshold = klt_eps, klt_min_eig, klt_err_threshold
-        c.p3p_thr_sq = p3p_threshold
-        c.ransac_outlier_ratio, c.ransac_confidence = outlier_ratio, confidence
-        c.ransac_max_iterations = -1 if max_iterations is None or max_iterations == np.inf else int(max_iterations)
-        c.refine_iters = int(refine_iters)
-        for i, v in enumerate(np.asarray(K, np.float64).reshape(9)):
-            c.K[i] = v
-        h = C.c_void_p()
-        ctx._chk(ctx._lib.vo_pipeline_create(ctx._h, C.byref(c), C.byref(h)))
-        self._h = h
-        pcg = Pcg64.from_generator(np.random.default_rng(seed))
-        ctx._chk(ctx._lib.vo_pipeline_seed(self._h, C.byref(pcg)))
-
-    def close(self):
-        if getattr(self, "_h", None):
-            self.ctx._lib.vo_pipeline_destroy(self._h)
-            self._h = None
-
-    def set_frame(self, idx, img, depth, T_world_cam):
-        img = _c(img, np.uint8)
-        depth = _c(depth, np.float32)
-        T = _c(T_world_cam, np.float64).reshape(4, 4)
-        assert img.shape == (self.cfg.H, self.cfg.W) and depth.shape == img.shape
-        self.ctx._chk(self.ctx._lib.vo_pipeline_set_frame(self._h, int(idx), _ptr(img), _ptr(depth), _ptr(T)))
-
-    def prime(self, idx):
-        self.ctx._chk(self.ctx._lib.vo_pipeline_prime(self._h, int(idx)))
-
-    def step(self, prev_idx, next_idx):
-        r = StepResult()
-        self.ctx._chk(self.ctx._lib.vo_pipeline_step(self._h, int(prev_idx), int(next_idx), C.byref(r)))
-        return r
-
-    def submit(self, prev_idx, next_idx):
-        """First half of step(): enqueue the frame's GPU work and return (at most two in flight)."""
-        self.ctx._chk(self.ctx._lib.vo_pipeline_submit(self._h, int(prev_idx), int(next_idx)))
-
-    def collect(self):
-        """Second half of step(): wait for the oldest submitted frame, replay the RANSAC rule."""
-        r = StepResult()
-        self.ctx._chk(self.ctx._lib.vo_pipeline_collect(self._h, C.byref(r)))
-        return r
-
-    def prof_read(self, kernel_id):
-        ms, n = C.c_double(), C.c_int64()
-        self.ctx._chk(self.ctx._lib.vo_pipeline_prof_read(self._h, int(kernel_id), C.byref(ms), C.byref(n)))
-        return ms.value, n.value
-
-    def prof_reset(self):
-        self.ctx._chk(self.ctx._lib.vo_pipeline_prof_reset(self._h))
-
-    def export_state_dev(self, result, cap, d_record, consumer_stream=None):
-        """Record of the last collected step -> device memory at d_record; `consumer_stream` (raw hipStream_t,
-        default the context's) is the stream the exchange of the record is enqueued on."""
-        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_dev(self._h, C.byref(result), int(cap), C.c_void_p(d_record),
-                                                                 C.c_void_p(consumer_stream or 0)))
-
-    def export_state_post(self, result, cap, d_record):
-        """Queues the record of the last collected step behind its DLT (no synchronisation)."""
-        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_post(self._h, C.byref(result), int(cap), C.c_void_p(d_record)))
-
-    def export_state_join(self, consumer_stream=None):
-        """Orders the records posted so far before later work of `consumer_stream`, and later records after
-        what that stream holds now."""
-        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_join(self._h, C.c_void_p(consumer_stream or 0)))
-
-    def fetch(self, n_tracked, want_inliers=True):
-        N = self.cfg.n_keypoints
-        kp = np.empty((N, 2))
-        prev_xy, next_xy = np.empty((n_tracked, 2)), np.empty((n_tracked, 2))
-        land, tri = np.empty((n_tracked, 3)), np.empty((n_tracked, 3))
-        inl = np.empty(n_tracked, np.uint8) if want_inliers else None
-        self.ctx._chk(self.ctx._lib.vo_pipeline_fetch(self._h, _ptr(kp), _ptr(prev_xy), _ptr(next_xy), _ptr(land),
-                                                      _ptr(tri), _ptr(inl)))
-        return dict(kp_next=kp, prev_xy=prev_xy, next_xy=next_xy, landmarks=land, triangulated=tri,
-                    inliers=None if inl is None else inl.astype(bool))
+from vo._pipeline import Pipeline  # noqa: E402,F401  (device-resident frame loop, vo_pipeline_*)
 
 
 _default_ctx = None

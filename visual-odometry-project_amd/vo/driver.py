@@ -23,19 +23,27 @@ from vo.pose_estimation import P3PPoseEstimator
 from vo.primitives import Features, Sequence, State
 
 
-def run(sequence: Sequence, tracker_mode: str = "klt", max_frames: int = None, verbose: bool = False):
-    """Returns dict(trajectory (n, 4, 4) camera-to-world, n_landmarks, frame_seconds)."""
-    camera = sequence.get_camera()
+def make_estimators(camera):
+    """The triangulator and pose estimator as src/main.py:185-201 configures them."""
     triangulator = LandmarksTriangulator(camera1=camera, camera2=camera, use_ransac=True, use_opencv=True,
                                          outlier_ratio=0.9, ransac_threshold=0.25, ransac_confidence=0.999)
     pose_estimator = P3PPoseEstimator(use_opencv=True, intrinsic_matrix=camera.intrinsic_matrix,
                                       inlier_threshold=1.25, outlier_ratio=0.9, confidence=0.9999,
                                       nonlinear_refinement=True)
-    # ---- bootstrap ----
+    return triangulator, pose_estimator
+
+
+def bootstrap(sequence: Sequence, tracker_mode: str = "klt", tracker_setup=None):
+    """main.py:204-230: frames 0 and 2 -> (state, tracker, triangulator, pose_estimator).  Runs on the host
+    (8-point RANSAC, essential-matrix decomposition, cheirality) with the DLT passes on the GPU."""
+    camera = sequence.get_camera()
+    triangulator, pose_estimator = make_estimators(camera)
     init_frame = next(sequence)
     state = State(init_frame)
     next(sequence)                                                       # frame 1 is skipped
     new_frame = next(sequence)
+    if tracker_setup is not None:
+        tracker_setup()
     tracker = Tracker(init_frame, mode=tracker_mode)
     matches = tracker.trackFeatures(state.curr_frame, new_frame)
     state.update_from_matches(matches)
@@ -48,6 +56,13 @@ def run(sequence: Sequence, tracker_mode: str = "klt", max_frames: int = None, v
     inliers_mask[f2.matched_candidate_inliers] = inliers
     state.update_with_local_landmarks(landmarks[inliers], inliers_mask)
     state.reset_outliers(outliers)
+    return state, tracker, triangulator, pose_estimator
+
+
+def run(sequence: Sequence, tracker_mode: str = "klt", max_frames: int = None, verbose: bool = False):
+    """The reference's loop through the drop-in classes, one call per stage (host bookkeeping, host <-> device
+    copies around every kernel).  Returns dict(trajectory (n, 4, 4) camera-to-world, n_landmarks, frame_seconds)."""
+    state, tracker, triangulator, pose_estimator = bootstrap(sequence, tracker_mode)
     trajectory = [np.eye(4), state.get_pose()]
     n_landmarks = [len(state.curr_frame.features.triangulated_inliers_landmarks)]
     seconds = []
@@ -81,6 +96,77 @@ def run(sequence: Sequence, tracker_mode: str = "klt", max_frames: int = None, v
     return dict(trajectory=np.array(trajectory), n_landmarks=np.array(n_landmarks), frame_seconds=np.array(seconds))
 
 
+def _gray(image):
+    from vo.features.klt import _gray as g
+    return g(image)
+
+
+def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int = 2000, klt_win: int = 17,
+                  klt_max_level: int = 2, hyp: int = 1000, context=None, verbose: bool = False):
+    """Same loop, same bootstrap, but the steady state runs as the device-resident pipeline (vo_pipeline_*):
+    after the host bootstrap the Features / State arrays are handed to the GPU once, every later frame costs one
+    image upload and one call, and nothing but the pose record comes back.  KLT tracker mode with the Harris
+    detector (BASELINE.json configs[1]); P3P-RANSAC as main.py:194-201 configures it (1.25 px, confidence 0.9999)
+    with `hyp` hypotheses solved and scored per frame."""
+    from vo import _native
+    from vo.features.klt import KLTTracker
+    ctx = context or _native.default_context()
+    saved = (KLTTracker._detector, dict(KLTTracker._harris_params), dict(KLTTracker._lk_params))
+
+    def setup():
+        KLTTracker._detector = "harris"
+        KLTTracker._harris_params = dict(patch_size=9, kappa=0.09, num_keypoints=n_keypoints, nonmaximum_supression_radius=5)
+        KLTTracker._lk_params = dict(saved[2], winSize=(klt_win, klt_win), maxLevel=klt_max_level)
+
+    try:
+        state, tracker, _, _ = bootstrap(sequence, "klt", tracker_setup=setup)
+    finally:
+        KLTTracker._detector, KLTTracker._harris_params, KLTTracker._lk_params = saved
+    frame = state.curr_frame
+    img = _gray(frame.image)
+    H, W = img.shape
+    K = np.asarray(sequence.get_camera().intrinsic_matrix, np.float64)
+    pipe = _native.Pipeline(ctx, H, W, 3, K, n_keypoints=n_keypoints, klt_win=klt_win, klt_max_level=klt_max_level,
+                            hyp=hyp, p3p_threshold=1.25 ** 2, outlier_ratio=0.9, confidence=0.9999, max_iterations=10000,
+                            refine_iters=20, bearing_threshold=state._bearing_threshold)
+    pipe.set_frame(0, img)
+    pipe.set_state(0, frame.features, state.curr_pose, state.prev_pose, num_features=tracker._tracker._num_features)
+    trajectory = [np.eye(4), state.get_pose()]
+    n_landmarks = [len(frame.features.triangulated_inliers_landmarks)]
+    seconds, results = [], []
+    slot = 0
+    # one frame of look-ahead, as a camera delivers them: frame k+1 is uploaded and submitted before the pose of
+    # frame k is read back
+    pending = 0
+    for k, new_frame in enumerate(sequence):
+        if max_frames is not None and k >= max_frames:
+            break
+        t0 = time.perf_counter()
+        nxt = (slot + 1) % 3
+        if pending == 2:
+            results.append(pipe.collect())
+            pending -= 1
+        pipe.set_frame(nxt, _gray(new_frame.image))
+        pipe.submit(slot, nxt)
+        pending += 1
+        slot = nxt
+        seconds.append(time.perf_counter() - t0)
+    while pending:
+        results.append(pipe.collect())
+        pending -= 1
+    for r in results:
+        trajectory.append(r.pose_world_cam())
+        n_landmarks.append(r.n_landmarks)
+        if verbose:
+            print("%4d in, %4d tracked, %4d landmarks, %4d inliers, %3d candidates%s" % (
+                r.n_features_in, r.n_tracked, r.n_landmarks, r.n_inliers, r.n_candidates,
+                ", re-detected" if r.redetected else ""))
+    features = pipe.get_features()
+    pipe.close()
+    return dict(trajectory=np.array(trajectory), n_landmarks=np.array(n_landmarks), frame_seconds=np.array(seconds),
+                results=results, features=features)
+
+
 def trajectory_error(result, sequence: Sequence):
     """RMS position error against the analytic ground truth after fitting the one free scale
     of the monocular bootstrap.  Trajectory index 0 is frame 0, index i >= 1 is frame i + 1."""
@@ -96,4 +182,7 @@ def trajectory_error(result, sequence: Sequence):
 if __name__ == "__main__":
     seq = Sequence("synthetic", n_frames=30, height=480, width=640, channels=3)
     out = run(seq, "klt", verbose=True)
+    print(trajectory_error(out, seq), "mean ms/frame", 1e3 * out["frame_seconds"].mean())
+    seq = Sequence("synthetic", n_frames=30, height=480, width=640, channels=3)
+    out = run_on_device(seq, n_keypoints=500, verbose=True)
     print(trajectory_error(out, seq), "mean ms/frame", 1e3 * out["frame_seconds"].mean())

@@ -25,6 +25,11 @@ class KLTTracker:
     _lk_params = dict(winSize=(17, 17), maxLevel=2, criteria=(TERM_CRITERIA_EPS | TERM_CRITERIA_COUNT, 10, 0.03))
     # points are kept only below this tracking error (klt.py:39)
     _error_threshold = 100
+    # Extension for BASELINE.json configs[1] ("Harris+NMS -> KLT"): which detector find_corners runs.
+    # "shi-tomasi" is the reference's cv2.goodFeaturesToTrack (klt.py:98); "harris" is the reference's own
+    # HarrisCornerDetector.extractKeypoints (harris.py:86-158) with _harris_params.
+    _detector = "shi-tomasi"
+    _harris_params = dict(patch_size=9, kappa=0.09, num_keypoints=2000, nonmaximum_supression_radius=5)
 
     def __init__(self, frame, context=None):
         self._ctx = context
@@ -74,9 +79,14 @@ class KLTTracker:
         if not use_goodFeaturesToTrack:
             raise NotImplementedError("the cornerHarris + cornerSubPix branch (klt.py:99-110) is not on the "
                                       "front-end path and is not provided")
-        p = self._feature_params
-        pts = self._context().good_features(_gray(frame.image), mask, p["maxCorners"], p["qualityLevel"],
-                                            p["minDistance"], p["blockSize"])
+        if self._detector == "harris":
+            h = self._harris_params
+            pts = self._context().harris_keypoints(_gray(frame.image), h["patch_size"], h["kappa"], h["num_keypoints"],
+                                                   h["nonmaximum_supression_radius"]).astype(np.float32)
+        else:
+            p = self._feature_params
+            pts = self._context().good_features(_gray(frame.image), mask, p["maxCorners"], p["qualityLevel"],
+                                                p["minDistance"], p["blockSize"])
         pts = pts.reshape((-1, 2, 1))
         self._num_features = pts.shape[0]
         return pts
