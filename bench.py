@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
-"""Benchmark: VO front-end frames/s on the BASELINE.json config-2 workload.
+"""Benchmark: VO frames/s on the BASELINE.json config-2 workload, through the device-resident frame loop.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  (N > 1: one rank per GPU under torch.distributed.run; started that way by the driver, or by this script
+   itself when it is called directly with --gpus N)
 
-One "step" = the whole per-frame front-end on one 1376x1241 frame that is already
-resident in HBM: pyramid -> KLT (3 levels, 15x15) of 2000 keypoints -> Harris
-response + exact NMS (2000 keypoints) on the new frame -> P3P-RANSAC (1000
-hypotheses solved + scored on the GPU, reference-exact sampler and accept rule)
--> DLT triangulation.  Each rank runs its own synthetic sequence (weak scaling,
-frame streams shard at sequence granularity); with N > 1 every step all-gathers the
-ranks' {pose, landmarks} records over RCCL on a side stream.  Rank 0 prints ONE
-JSON line.
+One "step" = one frame of the reference's steady-state loop (src/main.py:248-286, KLT tracker mode with the
+Harris detector) on a 1376x1241 frame that is already resident in HBM, everything on the GPU:
+  pyramid(next) | Harris response + exact greedy NMS (2000 keypoints) on next | re-detect append when fewer than
+  80 % of the tracks survive -> KLT (3 levels, 15x15) of every feature -> Matches regroup -> P3P-RANSAC (1000
+  hypotheses solved + scored, reference-exact sampler, sequential accept rule replayed on the device) -> pose
+  refinement over the inliers -> State bookkeeping (reset_outliers, bearing-angle candidates) -> DLT of the
+  candidates with one start pose per track -> landmark insertion + cheirality check.
+The Features / State / RANSAC bookkeeping never leaves HBM; the landmarks every pose is estimated from are the
+ones the loop itself triangulated (after a real two-view bootstrap on the host, untimed).  Each rank runs its own
+synthetic sequence (weak scaling, frame streams shard at sequence granularity); with N > 1 the ranks' {pose,
+landmarks} records are all-gathered over RCCL on a side stream.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,79 +34,193 @@ import numpy as np  # noqa: E402
 H, W, N_KP, HYP, WIN, MAX_LEVEL = 1241, 1376, 2000, 1000, 15, 2
 N_FRAMES = 8
 REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
-EXCHANGE_EVERY = int(os.environ.get("VO_BENCH_EXCHANGE_EVERY", "16"))   # frames per all-gather of {pose, landmarks} records (multi-GPU / --exchange)
+EXCHANGE_EVERY = int(os.environ.get("VO_BENCH_EXCHANGE_EVERY", "16"))   # frames per all-gather of {pose, landmarks} records
+REDETECT_POSE = os.environ.get("VO_BENCH_REDETECT_POSE", "current")   # see vo_pipeline_config.redetect_start_pose
 PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+PROFILE_TAG = "r02"
 
 
-def algorithmic_bytes(kernel_name, n_tracked):
-    """Compulsory HBM traffic per launch (DESIGN.md 'Kernels')."""
+def algorithmic_bytes(kernel_name, n_in, n_tracked, n_tri):
+    """Compulsory HBM traffic per launch (DESIGN.md 'Kernels'): every input read once,
+    every required output written once, at the feature counts the run actually had."""
     px = H * W
     levels = MAX_LEVEL + 1
+    feat = 8 + 16 + 2 + 24 + 16 + 96                          # one Features row: kp f32, kp f64, state, cand, landmark, track, pose
     table = {
         "harris_response": px * 1 + px * 8,                   # image read once, fp64 map written once
         "nms_candidates": px * 8,                             # fp64 map read once
-        "nms_compact": N_KP * 12,                             # the N selected strict maxima
-        "nms_round": N_KP * 4 * 2,                            # state words of the picks (list traffic is not compulsory)
+        "nms_compact": N_KP * 12,
+        "nms_round": N_KP * 4 * 2,
         "nms_rank": N_KP * 12,
-        "nms_select": N_KP * 16,                              # keypoints written
-        "pyr_down": 2 * px + px // 4 + px // 16,              # one launch: frame read, bordered copy of level 0, levels 1 and 2 written
-        "klt_track": N_KP * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + N_KP * (8 + 8 + 1 + 4),
-        # (flags of all keypoints per workgroup are re-reads, not compulsory) selection of the tracked keypoints
-        # + compacted arrays, then samples, poses, valid flags
-        "p3p_solve": N_KP * (1 + 4 + 8 + 16 + 24) + n_tracked * (16 + 16 + 24) + HYP * (28 + 4 * 32 + 96 + 1),
-        "p3p_score": n_tracked * 40 + HYP * (96 + 1 + 4 + ((n_tracked + 63) // 64) * 8),
-        "dlt_triangulate": n_tracked * (16 + 16 + 24) + 192,
-        "refine_pose": n_tracked * 40 + ((n_tracked + 63) // 64) * 8 + 96 + 120,   # points + mask row once, pose in / out
+        "nms_select": N_KP * 16,
+        "pyr_down": 2 * px + px // 4 + px // 16,              # frame read, bordered copy of level 0, levels 1 and 2 written
+        "klt_track": n_in * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + n_in * (8 + 8 + 1 + 4),
+        "state_append": N_KP * (16 + feat),
+        "state_regroup": n_in * (8 + 1 + 4 + 1) + n_tracked * 2 * feat,
+        "p3p_solve": HYP * (28 + 4 * 40 + 96 + 1),
+        "p3p_score": n_tri * 40 + HYP * (96 + 1 + 4 + ((n_tri + 63) // 64) * 8),
+        "ransac_replay": HYP * 5 + 96 + ((n_tri + 63) // 64) * 16,
+        "refine_pose": n_tri * 40 + ((n_tri + 63) // 64) * 8 + 96 + 120,
+        "state_update": n_tracked * (feat + 24) + ((n_tri + 63) // 64) * 8,
     }
     return table.get(kernel_name)
 
 
+ROCPROF_NAMES = {"klt_track": "klt_track16_kernel<15, 16>", "nms_round": "nms_round_kernel<5, true>",
+                 "nms_candidates": "nms_candidates_kernel<5>", "harris_response": "harris_response_kernel<9>",
+                 "p3p_solve": "p3p_solve_kernel<true>", "p3p_score": "p3p_score_kernel", "nms_compact": "nms_compact_kernel",
+                 "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel", "refine_pose": "refine_pose_kernel",
+                 "pyr_down": "pyramid3_kernel", "state_append": "state_append_kernel",
+                 "state_regroup": "state_regroup_kernel<false>", "ransac_replay": "ransac_replay_kernel",
+                 "state_update": "state_update_kernel"}
+
+
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this
-    same command, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes); None if the
-    file or the kernel is missing.  bench.py itself cannot run under the counters."""
-    names = {"klt_track": "klt_track16_kernel<15, 16>", "nms_round": "nms_round_kernel<5, true>",
-             "nms_candidates": "nms_candidates_kernel<5>", "harris_response": "harris_response_kernel<9>",
-             "p3p_solve": "p3p_solve_kernel<true>", "p3p_score": "p3p_score_kernel", "dlt_triangulate": "dlt_kernel",
-             "nms_compact": "nms_compact_kernel", "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel",
-             "track_gather": "gather_tracks_kernel", "refine_pose": "refine_pose_kernel", "pyr_down": "pyramid3_kernel"}
+    """HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/<tag>_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command, FETCH_SIZE doubled for gfx950 as
+    MI355X_MICROARCH.md prescribes); None if the file or the kernel is missing.  bench.py itself cannot run under
+    the counters."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_traffic.json")) as f:
             table = json.load(f)
-        return int(table[names[kernel_name]]["hbm_bytes_corrected"])
+        return int(table[ROCPROF_NAMES[kernel_name]]["hbm_bytes_corrected"])
     except (OSError, KeyError, ValueError):
         return None
 
 
-def cpu_baseline(stream, frames=3):
-    """The oracle (CPU restatement of the reference path) timed on this host, 1 thread."""
-    from oracle import dlt_np, harris_np, native, ransac_np
-    K = stream.K
-    kp = harris_np.nms_keypoints_fast(harris_np.harris_scores(stream.image(0), 9, 0.09), N_KP, 5)[:, :, 0]
-    rs = ransac_np.Ransac(4, np.arange(4), None, None, 1.0, 0.9, 0.99, 1000, adaptive=True, p3p=True)
-    order = stream.order(frames)
+class ResidentSequence:
+    """The frames of a synthetic.Stream as the iterator vo.driver.bootstrap expects (Sequence surface)."""
+
+    def __init__(self, stream):
+        from vo.sensors import Camera
+        self.stream, self.idx = stream, 0
+        self.camera = Camera(intrinsic_matrix=stream.K)
+
+    def get_camera(self):
+        return self.camera
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        from vo.primitives import Frame
+        if self.idx >= self.stream.n:
+            raise StopIteration
+        f = Frame(self.stream.image(self.idx), sensor=self.camera, intrinsics=self.stream.K)
+        f.frame_id = self.idx
+        self.idx += 1
+        return f
+
+
+def walk(start, n, steps):
+    """Frame indices from `start`, back and forth over 0..n-1 (consecutive frames are always neighbours)."""
+    idx, d, out = start, 1, [start]
+    for _ in range(steps):
+        if idx + d < 0 or idx + d >= n:
+            d = -d
+        idx += d
+        out.append(idx)
+    return out
+
+
+def bootstrap_state(stream):
+    """main.py:204-230 on frames 0 and 2 of the stream, on the host (untimed): Shi-Tomasi corners (as many as the
+    detector keeps per frame), KLT, 8-point RANSAC, essential matrix, cheirality, DLT."""
+    from vo import driver
+    from vo.features.klt import KLTTracker
+    saved = (dict(KLTTracker._feature_params), dict(KLTTracker._lk_params))
+
+    def setup():
+        KLTTracker._feature_params = dict(saved[0], maxCorners=N_KP)
+        KLTTracker._lk_params = dict(saved[1], winSize=(WIN, WIN), maxLevel=MAX_LEVEL)
+
+    try:
+        state, tracker, _, _ = driver.bootstrap(ResidentSequence(stream), "klt", tracker_setup=setup)
+    finally:
+        KLTTracker._feature_params, KLTTracker._lk_params = saved
+    return state
+
+
+def oracle_leg(stream, state, gpu_results, gpu_state, frames):
+    """The CPU oracle of the same loop (tests/pipeline_oracle.py: pinned bookkeeping classes + CPU oracles) on the
+    first `frames` frames: (i) parity of the GPU results against it, (ii) its time = the CPU baseline ("port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import harris_np
+    from pipeline_oracle import OracleLoop
+    orc = OracleLoop(stream, N_KP, WIN, MAX_LEVEL, refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE)
+    orc.set_state(2, state.curr_frame.features, state.curr_pose, state.prev_pose)
+    order = walk(2, stream.n, frames)
+    dR = dt = 0.0
+    exact = True
     t0 = time.perf_counter()
-    for a, b in zip(order[:-1], order[1:]):
-        out, status, err = native.klt_track(stream.image(a), stream.image(b), kp.astype(np.float32), win=WIN,
-                                            max_level=MAX_LEVEL)
-        keep = status.astype(bool) & (err < 100.0)
-        p_c, n_c = kp[keep], out[keep].astype(np.float64)
-        z = stream.depth(a)[p_c[:, 1].astype(int), p_c[:, 0].astype(int)].astype(np.float64)
-        T = stream.T_world_cam(a)
-        xc, yc = (p_c[:, 0] - K[0, 2]) / K[0, 0] * z, (p_c[:, 1] - K[1, 2]) / K[1, 1] * z
-        land = np.stack([T[r, 0] * xc + T[r, 1] * yc + T[r, 2] * z + T[r, 3] for r in range(3)], axis=1)
-        # the reference's own NMS loop: 2*N full-map argmax passes (harris.py:148-152)
-        kp = harris_np.nms_keypoints(harris_np.harris_scores(stream.image(b), 9, 0.09), N_KP, 5)[:, :, 0]
-        rs.model_fn = lambda idx: native.p3p_solve(land[np.asarray(idx).reshape(-1)], n_c[np.asarray(idx).reshape(-1)], K)
-        rs.error_fn = lambda m, pop: native.reproj_errors(land, n_c, K, m[0], m[1])
-        (R, t), inl = rs.find_best_model(np.arange(len(land)))
-        dlt_np.linear_triangulation(p_c, n_c, K @ np.linalg.inv(T)[:3], K @ np.hstack([R, t[:, None]]))
-    dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same 1376x1241 stream through oracle/ (NumPy Harris + the reference's "
-                      "2N-argmax NMS loop, C KLT/P3P, NumPy RANSAC/DLT), single thread" % frames}
+    refs = []
+    for b in order[1:]:
+        refs.append(orc.step(b))
+        # the GPU step also runs the detector on every new frame (the keypoints the next step may append)
+        harris_np.nms_keypoints_fast(harris_np.harris_scores(stream.image(b), 9, 0.09), N_KP, 5)
+    cpu_s = time.perf_counter() - t0
+    for ref, r in zip(refs, gpu_results):
+        Rr, tr = np.array(r.R_refined).reshape(3, 3), np.array(r.t_refined)
+        dR = max(dR, float(np.abs(Rr - ref["R_ref"]).max()))
+        dt = max(dt, float(np.abs(tr - ref["t_ref"]).max() / max(1.0, np.linalg.norm(ref["t_ref"]))))
+        exact &= (r.n_tracked, r.n_triangulated, r.n_inliers, r.draws_consumed, r.ransac_iterations, r.n_candidates,
+                  r.n_landmarks) == (ref["n_tracked"], ref["n_tri"], ref["n_inliers"], ref["draws"], ref["iters"],
+                                     ref["n_cand"], ref["n_landmarks"])
+    f = refs[-1]["features"]
+    exact &= bool(np.array_equal(gpu_state["keypoints"], f.keypoints.astype(np.float64)) and
+                  np.array_equal(gpu_state["state"], f.state) and
+                  np.array_equal(gpu_state["candidate_mask"], f.candidate_mask) and
+                  np.array_equal(gpu_state["tracks"], f.tracks, equal_nan=True))
+    with np.errstate(invalid="ignore"):
+        d = np.abs(gpu_state["landmarks"] - f.landmarks)[:, :, 0].max(axis=1)
+        lm = float(np.nanmax(d / np.maximum(1.0, np.linalg.norm(f.landmarks[:, :, 0], axis=1)))) if f.length else 0.0
+    parity = {"frames": frames, "max_abs_dR": dR, "max_rel_dt": dt, "max_rel_dlandmark": lm,
+              "counts_masks_keypoints_states_tracks_exact": bool(exact),
+              "note": "refined pose / landmarks vs the CPU oracle of the same loop on the same frames (tolerance of the "
+                      "metric: 1e-4 rel.); integer and index results must be identical"}
+    base = {"value": frames / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same 1376x1241 stream through the CPU oracle of the loop (tests/pipeline_oracle.py: "
+                      "C KLT / P3P, NumPy RANSAC / refinement / DLT / bookkeeping) plus NumPy Harris + the oracle's fast "
+                      "exact NMS walk per frame, single thread" % frames}
+    return parity, base
+
+
+def api_leg(ctx):
+    """Frames/s through the Python drop-in API at the same frame size: (a) the reference-shaped classes, one call per
+    stage with host bookkeeping (vo.driver.run); (b) the same loop on the device pipeline with one image upload per
+    frame (vo.driver.run_on_device)."""
+    from vo import driver
+    from vo.primitives import Sequence
+    out = {}
+    try:
+        seq = Sequence("synthetic", n_frames=9, height=H, width=W, channels=1)
+        r = driver.run(seq, "klt")
+        out["drop_in_classes_frames_per_s"] = round(float(1.0 / np.median(r["frame_seconds"])), 1)
+        seq = Sequence("synthetic", n_frames=9, height=H, width=W, channels=1)
+        t0 = time.perf_counter()
+        r = driver.run_on_device(seq, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL, hyp=HYP, context=ctx)
+        out["device_pipeline_with_upload_frames_per_s"] = round(float(1.0 / np.median(r["frame_seconds"])), 1)
+        out["note"] = ("640x480-independent: both at 1376x1241; (a) vo.driver.run = reference call order through Tracker / "
+                       "P3PPoseEstimator / LandmarksTriangulator / State with host arrays between stages, Shi-Tomasi 500 "
+                       "corners as the reference configures KLT; (b) vo.driver.run_on_device = host bootstrap, then one "
+                       "1.7 MB image upload + one submit per frame, 2000 keypoints, 1000 hypotheses")
+    except Exception as e:                                   # the headline must not depend on this leg
+        out["error"] = repr(e)
+    return out
+
+
+def spawn_ranks(args):
+    """Called with --gpus N > 1 outside torch.distributed.run: start the N ranks as children (before anything
+    touches the GPU in this process) and relay rank 0's line."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd).returncode)
 
 
 def main():
@@ -110,36 +229,43 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the drop-in API frames/s leg")
     ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
                     help="one blocking vo_pipeline_step per frame instead of submitting frame k+1 before "
                          "collecting frame k (vo_pipeline_submit / _collect)")
     ap.add_argument("--exchange", action="store_true",
-                    help="run the per-frame all-gather of {pose, landmarks} records even on one GPU "
-                         "(always on for --gpus > 1); rehearses the multi-GPU step on a single device")
+                    help="run the all-gather of {pose, landmarks} records even on one GPU (always on for --gpus > 1)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
+    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node=%d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
-    exchange = False                     # switched on below, once the pipeline's streams exist and have run
+    exchange = False
     want_exchange = world > 1 or args.exchange
 
     from vo import _native, sharding, synthetic
     comp = torch.cuda.Stream()
     comm = torch.cuda.Stream()
+    os.environ["VO_DEVICE"] = str(local)
     ctx = _native.Context(local, stream=comp.cuda_stream)
     stream = synthetic.Stream(N_FRAMES, H, W, seed=2023 + rank)
+    state = bootstrap_state(stream)
     pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
                             hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
-                            refine_iters=REFINE_ITERS)
+                            refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE)
     for i in range(N_FRAMES):
-        pipe.set_frame(i, stream.image(i), stream.depth(i), stream.T_world_cam(i))
+        pipe.set_frame(i, stream.image(i))
+    pipe.set_state(2, state.curr_frame.features, state.curr_pose, state.prev_pose, num_features=N_KP)
+    n_boot = int((state.curr_frame.features.state == 2).sum())
 
     cap = N_KP
     rec_len = sharding.record_length(cap)
@@ -147,36 +273,32 @@ def main():
     gathered = [torch.zeros(world * EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
     batch_fill, batch_buf = 0, 0
 
-    order = stream.order(args.warmup + args.steps + 64)
-    pipe.prime(order[0])
+    order = walk(2, N_FRAMES, args.warmup + args.steps + 96)
     pos = 0
-    stats = {"tracked": [], "inliers": [], "rot_err": [], "trans_err": [], "iters": [], "tri_err": [],
-             "rot_err_ref": [], "trans_err_ref": [], "ref_iters": []}
+    log = []
 
-    def run(n, record=False):
-        # Default: one frame of look-ahead, as a camera stream gives it -- frame k+1 is submitted (all of
-        # its GPU work enqueued) before the pose of frame k is collected, so the host's share of a step
-        # (launches, sequential RANSAC replay) overlaps the GPU's.  Every frame is processed in full
-        # and the results are those of the blocking call (tests/test_gpu_pipeline.py).
-        # --no-lookahead: the reference's order, one blocking vo_pipeline_step per frame.
-        nonlocal pos
-        if args.lookahead:
+    def run(n, record=False, lookahead=None):
+        # Default: one frame of look-ahead, as a camera stream gives it -- frame k+1 is submitted (all of its GPU
+        # work enqueued) before the record of frame k is read.  Every frame is processed in full and the results
+        # are those of the blocking call (tests/test_gpu_pipeline.py).  --no-lookahead: one blocking step per frame.
+        nonlocal pos, batch_fill, batch_buf
+        la = args.lookahead if lookahead is None else lookahead
+        out = []
+        if la:
             pipe.submit(order[pos], order[pos + 1])
         for k in range(n):
             a, b = order[pos], order[pos + 1]
             pos += 1
-            if args.lookahead:
+            if la:
                 if k + 1 < n:
                     pipe.submit(order[pos], order[pos + 1])
                 r = pipe.collect()
             else:
                 r = pipe.step(a, b)
             if exchange:
-                # The record of every collected step is written behind its DLT on the pipeline's own stream
-                # (no host synchronisation); every EXCHANGE_EVERY frames the records gathered so far go to
-                # all ranks in ONE all-gather on the side stream (fewer, larger collectives: the per-call
-                # host cost of a collective is ~45 us, a third of a step).
-                nonlocal batch_fill, batch_buf
+                # The record of every collected step is queued on the pipeline's stream (no host synchronisation);
+                # every EXCHANGE_EVERY frames the records gathered so far go to all ranks in ONE all-gather on the
+                # side stream (fewer, larger collectives: issuing one costs the host ~45 us, a third of a step).
                 pipe.export_state_post(r, cap, recs[batch_buf].data_ptr() + batch_fill * rec_len * 8)
                 batch_fill += 1
                 if batch_fill == EXCHANGE_EVERY or k == n - 1:
@@ -185,17 +307,8 @@ def main():
                     batch_buf ^= 1
                     batch_fill = 0
             if record:
-                Tcw = np.linalg.inv(stream.T_world_cam(b))
-                R, t = np.array(r.R).reshape(3, 3), np.array(r.t)
-                Rr, tr = np.array(r.R_refined).reshape(3, 3), np.array(r.t_refined)
-                stats["rot_err_ref"].append(float(np.linalg.norm(Rr - Tcw[:3, :3])))
-                stats["trans_err_ref"].append(float(np.linalg.norm(tr - Tcw[:3, 3])))
-                stats["ref_iters"].append(r.refine_iterations)
-                stats["tracked"].append(r.n_tracked)
-                stats["inliers"].append(r.n_inliers)
-                stats["iters"].append(r.ransac_iterations)
-                stats["rot_err"].append(float(np.linalg.norm(R - Tcw[:3, :3])))
-                stats["trans_err"].append(float(np.linalg.norm(t - Tcw[:3, 3])))
+                out.append((b, r))
+        return out
 
     def fence():
         if exchange:
@@ -203,12 +316,14 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
-    # The process group comes up only now.  HIP spreads streams over four hardware queues in the order they
-    # first run; the pipeline's tracking stream must not end up sharing a queue with a detection stream
-    # (kernels of one hardware queue run in order: measured 8.5k -> 6k frames/s when RCCL's streams were
-    # created first and shifted that assignment), so the pipeline runs a few steps before RCCL exists.
-    run(4)
+    # ---- untimed: the first frames, blocking, kept for the parity / CPU-baseline leg ----
+    ORACLE_FRAMES = 4
+    first = run(ORACLE_FRAMES, record=True, lookahead=False)
+    first_state = pipe.get_state()
+    early = first + run(12, record=True, lookahead=False)     # ground-truth comparison: the frames right after the bootstrap
     ctx.sync()
+    # The process group comes up only now: HIP spreads streams over its hardware queues in the order they first run,
+    # and the pipeline's main stream should not end up sharing a queue with RCCL's (measured in round 1).
     if want_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -220,7 +335,7 @@ def main():
     run(args.warmup)
     ctx.prof_enable(-1)
     pipe.prof_reset()
-    run(8)
+    prof_steps = run(16, record=True)
     per_kernel = {}
     for kid in range(_native.K_COUNT):
         ms, n = pipe.prof_read(kid)
@@ -230,26 +345,19 @@ def main():
     dom_name = max(per_kernel, key=lambda k: per_kernel[k][0])
     dom_id = [k for k in range(_native.K_COUNT) if ctx.kernel_name(k) == dom_name][0]
 
-    # timed region: exactly K steps, events only around the dominant kernel
+    # timed region: exactly K steps, events only around the dominant kernel (every PROF_EVERY-th launch: an event
+    # pair costs the stream ~5 us, bracketing every launch would slow the step it measures)
     pipe.prof_reset()
-    # (every PROF_EVERY-th launch is bracketed: an event pair costs the stream ~5 us, and bracketing
-    #  all of them made the step 4 % slower than it is)
     ctx.prof_set_sampling(PROF_EVERY)
     ctx.prof_enable(dom_id)
     fence()
     t0 = time.perf_counter()
-    run(args.steps, record=False)
+    timed = run(args.steps, record=True)
     fence()
     dt = time.perf_counter() - t0
     dom_ms, dom_n = pipe.prof_read(dom_id)
     ctx.prof_disable()
     ctx.prof_set_sampling(1)
-
-    # untimed: accuracy against the analytic ground truth of the stream
-    run(16, record=True)
-    fence()
-    last = pipe.step(order[pos], order[pos + 1])
-    ntr = last.n_tracked
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -257,8 +365,12 @@ def main():
     dt_max = float(dt_t.item())
 
     if rank == 0:
+        res = [r for _, r in timed]
+        n_in = int(np.median([r.n_features_in for r in res]))
+        n_trk = int(np.median([r.n_tracked for r in res]))
+        n_tri = int(np.median([r.n_triangulated for r in res]))
         avg_us = dom_ms / max(dom_n, 1) * 1e3
-        ab = algorithmic_bytes(dom_name, ntr)
+        ab = algorithmic_bytes(dom_name, n_in, n_trk, n_tri)
         roof = {"bound": "hbm", "kernel": dom_name, "avg_launch_us": round(avg_us, 3), "launches": dom_n,
                 "algorithmic_bytes_per_launch": ab, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "traffic": pmc_traffic(dom_name)}
@@ -269,6 +381,18 @@ def main():
         else:
             roof["achieved"] = None
             roof["frac"] = None
+
+        def us(k):
+            return per_kernel[k][0] / per_kernel[k][1] * 1e3
+
+        # pose against the analytic ground truth of the stream: the bootstrap fixes the unit of length (|t| = 1 between
+        # frames 0 and 2, 1.6 m apart), positions compared after that one scale
+        scale = 2 * synthetic.STEP_Z / max(np.linalg.norm(state.curr_pose[:3, 3]), 1e-12)
+        gt_err = []
+        for b, r in early:
+            Twc = r.pose_world_cam()
+            gt = np.linalg.inv(stream.T_world_cam(0)) @ stream.T_world_cam(b)
+            gt_err.append((float(np.linalg.norm(Twc[:3, :3] - gt[:3, :3])), float(np.linalg.norm(scale * Twc[:3, 3] - gt[:3, 3]))))
         out = {
             "metric": "VO frames/sec at 1376x1241, 2k keypoints; pose err vs reference",
             "value": round(world * args.steps / dt_max, 2),
@@ -282,31 +406,45 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "cfg-2: 1376x1241 KITTI-shaped synthetic stream, Harris+NMS 2000 kp -> KLT 3-level "
-                                   "15x15 -> P3P-RANSAC 1000 hyps -> DLT; one independent sequence per GPU",
-                       "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP,
-                       "frame_lookahead": 1 if args.lookahead else 0,
+            "config": {"workload": "cfg-2: 1376x1241 KITTI-shaped synthetic stream, per frame: Harris+NMS 2000 kp, re-detect "
+                                   "append, KLT 3-level 15x15 of all tracks, Matches regroup, P3P-RANSAC 1000 hyps + device "
+                                   "replay of the sequential rule, pose refinement, State bookkeeping, per-track-pose "
+                                   "candidate DLT, cheirality; one independent sequence per GPU",
+                       "step_contains": "all of the above, device-resident (Features/State/RANSAC never leave HBM); "
+                                        "landmarks are the loop's own triangulations after a host two-view bootstrap",
+                       "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP, "sequences_per_gpu": 1,
+                       "frame_lookahead": 1 if args.lookahead else 0, "redetect_start_pose": REDETECT_POSE,
+                       "rccl_world_size": dist.get_world_size() if exchange else 1,
                        "parallelism": "sequence-sharded x%d%s" % (world, ", RCCL all-gather of the {pose, landmarks} records of %d frames every %d frames" % (EXCHANGE_EVERY, EXCHANGE_EVERY) if exchange else "")},
             "roofline": roof,
             # the image-wide (streaming) kernels against the same HBM peak, from the untimed all-kernel event pass
-            "roofline_streaming": {k: {"avg_launch_us": round(per_kernel[k][0] / per_kernel[k][1] * 1e3, 2),
-                                       "algorithmic_bytes_per_launch": algorithmic_bytes(k, ntr),
-                                       "achieved": round(algorithmic_bytes(k, ntr) / (per_kernel[k][0] / per_kernel[k][1] * 1e-3) / 1e9, 1),
-                                       "frac": round(algorithmic_bytes(k, ntr) / (per_kernel[k][0] / per_kernel[k][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            "roofline_streaming": {k: {"avg_launch_us": round(us(k), 2),
+                                       "algorithmic_bytes_per_launch": algorithmic_bytes(k, n_in, n_trk, n_tri),
+                                       "achieved": round(algorithmic_bytes(k, n_in, n_trk, n_tri) / (us(k) * 1e-6) / 1e9, 1),
+                                       "frac": round(algorithmic_bytes(k, n_in, n_trk, n_tri) / (us(k) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                                    for k in ("harris_response", "nms_candidates", "pyr_down") if k in per_kernel},
-            "per_kernel_us": {k: round(v[0] / v[1] * 1e3, 2) for k, v in sorted(per_kernel.items())},
-            "pose_err": {"rot_fro_median": float(np.median(stats["rot_err"])), "trans_m_median": float(np.median(stats["trans_err"])),
-                         "tracked_median": float(np.median(stats["tracked"])), "inliers_median": float(np.median(stats["inliers"])),
-                         "ransac_iters_median": float(np.median(stats["iters"])),
-                         "refined_rot_fro_median": float(np.median(stats["rot_err_ref"])),
-                         "refined_trans_m_median": float(np.median(stats["trans_err_ref"])),
-                         "refine_steps_median": float(np.median(stats["ref_iters"])),
-                         "note": "vs analytic ground truth of the synthetic stream; rot/trans: best RANSAC hypothesis, "
-                                 "refined_*: after the Gauss-Newton refinement over its inliers (inside the timed step "
-                                 "when refine_steps >= 0)"},
+            "per_kernel_us": {k: round(us(k), 2) for k in sorted(per_kernel)},
+            "loop": {"features_in_median": n_in, "tracked_median": n_trk, "landmarks_p3p_median": n_tri,
+                     "inliers_median": float(np.median([r.n_inliers for r in res])),
+                     "candidates_median": float(np.median([r.n_candidates for r in res])),
+                     "ransac_iters_median": float(np.median([r.ransac_iterations for r in res])),
+                     "redetect_fraction_of_steps": float(np.mean([r.redetected for r in res])),
+                     "steps_finished_by_host_path": int(sum(r.recovered for r in res)),
+                     "refine_steps_median": float(np.median([r.refine_iterations for r in res])),
+                     "bootstrap_landmarks": n_boot},
+            "pose_err_vs_ground_truth": {"rot_fro_median": float(np.median([e[0] for e in gt_err])),
+                                         "trans_m_median": float(np.median([e[1] for e in gt_err])),
+                                         "trans_m_per_frame": [round(e[1], 3) for e in gt_err],
+                                         "frames": len(gt_err),
+                                         "note": "first frames of the run vs the analytic poses of the synthetic stream, "
+                                                 "monocular scale fixed once by the bootstrap baseline"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(stream)
+            parity, base = oracle_leg(stream, state, [r for _, r in first], first_state, ORACLE_FRAMES)
+            out["pose_vs_oracle"] = parity
+            out["cpu_baseline"] = base
+        if world == 1 and not args.no_api:
+            out["api"] = api_leg(ctx)
         print(json.dumps(out), flush=True)
     pipe.close()
     ctx.close()

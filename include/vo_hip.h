@@ -342,19 +342,20 @@ int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img);
 int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng);
 int vo_pipeline_get_rng(vo_pipeline* p, vo_pcg64* rng);      /* estimator generator state after the last collected step */
 /* Hands over the Features of frame idx (the reference's state.curr_frame.features after the
- * bootstrap) and State's poses: n features -- kp n*2 float32, state n bytes (0/1/2), landmarks
+ * bootstrap) and State's poses: n features -- kp n*2 float64 (the tracker reads them rounded to
+ * float32, as cv2.calcOpticalFlowPyrLK takes them), state n bytes (0/1/2), landmarks
  * n*3, tracks n*2, poses n*16 (4x4 row-major, camera-to-world; NaN rows where the reference holds
  * NaN) -- plus curr / prev pose as 4x4 camera-to-world AND world-to-camera matrices (the
  * reference forms the latter with np.linalg.inv; passing both keeps every later product the
  * same), and KLTTracker._num_features.  Builds the pyramid and runs the detector on frame idx.  */
-int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const float* kp, const uint8_t* state,
+int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, const uint8_t* state,
                           const double* landmarks, const double* tracks, const double* poses,
                           const double* T_wc, const double* T_cw, const double* T_wc_prev,
                           const double* T_cw_prev, int num_features);
 /* Downloads the current Features (arrays sized to the capacity vo_pipeline_feature_cap returns;
  * any pointer may be NULL); n_out: feature count.  Nothing may be in flight.                  */
 int vo_pipeline_feature_cap(vo_pipeline* p);
-int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, float* kp, uint8_t* state, uint8_t* candidate_mask,
+int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, double* kp, uint8_t* state, uint8_t* candidate_mask,
                           double* landmarks, double* tracks, double* poses, double* T_wc, double* T_wc_prev,
                           vo_ransac_state* rs, int32_t* num_features);
 /* keypoints the detector found on the frame submitted last (n_keypoints*2 float64)              */

@@ -423,7 +423,7 @@ static int enqueue_main(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fir
   return VO_OK;
 }
 
-int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const float* kp, const uint8_t* state,
+int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, const uint8_t* state,
                           const double* landmarks, const double* tracks, const double* poses, const double* T_wc,
                           const double* T_cw, const double* T_wc_prev, const double* T_cw_prev, int num_features) {
   if (!p) return VO_EINVAL;
@@ -437,13 +437,14 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const float* kp, const
   hipStream_t st = ctx->stream;
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   const vo_feat& F = p->F[p->cur];
-  std::vector<double> kp64((size_t)n * 2), pose12((size_t)n * 12);
+  std::vector<double> pose12((size_t)n * 12);
+  std::vector<float> kp32((size_t)n * 2);
   std::vector<uint8_t> zeros((size_t)n, 0);
-  for (int i = 0; i < 2 * n; ++i) kp64[i] = (double)kp[i];
+  for (int i = 0; i < 2 * n; ++i) kp32[i] = (float)kp[i];
   for (int i = 0; i < n; ++i) memcpy(&pose12[(size_t)12 * i], poses + (size_t)16 * i, 96);
   if (n > 0) {
-    VO_HIP_TRY(ctx, hipMemcpy(F.kp, kp, (size_t)n * 8, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, hipMemcpy(F.kp64, kp64.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, hipMemcpy(F.kp, kp32.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, hipMemcpy(F.kp64, kp, (size_t)n * 16, hipMemcpyHostToDevice));
     VO_HIP_TRY(ctx, hipMemcpy(F.state, state, (size_t)n, hipMemcpyHostToDevice));
     VO_HIP_TRY(ctx, hipMemcpy(F.cand, zeros.data(), (size_t)n, hipMemcpyHostToDevice));
     VO_HIP_TRY(ctx, hipMemcpy(F.land, landmarks, (size_t)n * 24, hipMemcpyHostToDevice));
@@ -486,7 +487,7 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const float* kp, const
   return VO_OK;
 }
 
-int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, float* kp, uint8_t* state, uint8_t* candidate_mask,
+int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, double* kp, uint8_t* state, uint8_t* candidate_mask,
                           double* landmarks, double* tracks, double* poses, double* T_wc, double* T_wc_prev,
                           vo_ransac_state* rs, int32_t* num_features) {
   if (!p) return VO_EINVAL;
@@ -501,7 +502,7 @@ int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, float* kp, uint8_t* st
   if (n_out) *n_out = n;
   if (num_features) *num_features = h.num_features;
   if (n > 0) {
-    if (kp) VO_HIP_TRY(ctx, hipMemcpy(kp, F.kp, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (kp) VO_HIP_TRY(ctx, hipMemcpy(kp, F.kp64, (size_t)n * 16, hipMemcpyDeviceToHost));
     if (state) VO_HIP_TRY(ctx, hipMemcpy(state, F.state, (size_t)n, hipMemcpyDeviceToHost));
     if (candidate_mask) VO_HIP_TRY(ctx, hipMemcpy(candidate_mask, F.cand, (size_t)n, hipMemcpyDeviceToHost));
     if (landmarks) VO_HIP_TRY(ctx, hipMemcpy(landmarks, F.land, (size_t)n * 24, hipMemcpyDeviceToHost));

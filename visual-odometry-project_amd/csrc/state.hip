@@ -93,12 +93,12 @@ __device__ __forceinline__ unsigned long long block_scan_excl(unsigned long long
   return r;
 }
 
-__device__ __forceinline__ void write_group(const vo_feat& A, const vo_feat& B, int g, int src, int dst, float x,
-                                            float y) {
-  B.kp[2 * dst] = x;
-  B.kp[2 * dst + 1] = y;
-  B.kp64[2 * dst] = (double)x;
-  B.kp64[2 * dst + 1] = (double)y;
+__device__ __forceinline__ void write_group(const vo_feat& A, const vo_feat& B, int g, int src, int dst, double x,
+                                            double y) {
+  B.kp[2 * dst] = (float)x;
+  B.kp[2 * dst + 1] = (float)y;
+  B.kp64[2 * dst] = x;
+  B.kp64[2 * dst + 1] = y;
   B.cand[dst] = 0;
   const double nan = dnan();
   if (g == 0) {            // triangulated: the landmark travels, the track data is over (matches.py:146-201)
@@ -173,16 +173,16 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
     const int key = (int)((keys >> (2 * (j - j0))) & 3ull);
     if (key == 3) continue;
     int src;
-    float x, y;
+    double x, y;
     if (PAIRS) {
       src = pairs[2 * j];
       const int i2 = pairs[2 * j + 1];
-      x = (float)new_kp[2 * i2];
-      y = (float)new_kp[2 * i2 + 1];
+      x = new_kp[2 * i2];
+      y = new_kp[2 * i2 + 1];
     } else {
       src = j;
-      x = next_xy[2 * j];
-      y = next_xy[2 * j + 1];
+      x = (double)next_xy[2 * j];
+      y = (double)next_xy[2 * j + 1];
     }
     write_group(A, B, key, src, pos[key]++, x, y);
   }
@@ -198,16 +198,16 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
     const double nan = dnan();
     for (int k = k0; k < k1; ++k) {
       if ((s_matched[k >> 5] >> (k & 31)) & 1u) continue;
-      const float x = (float)new_kp[2 * k], y = (float)new_kp[2 * k + 1];
-      B.kp[2 * p] = x;
-      B.kp[2 * p + 1] = y;
-      B.kp64[2 * p] = (double)x;
-      B.kp64[2 * p + 1] = (double)y;
+      const double x = new_kp[2 * k], y = new_kp[2 * k + 1];
+      B.kp[2 * p] = (float)x;
+      B.kp[2 * p + 1] = (float)y;
+      B.kp64[2 * p] = x;
+      B.kp64[2 * p + 1] = y;
       B.state[p] = 0;
       B.cand[p] = 0;
       B.land[3 * p] = B.land[3 * p + 1] = B.land[3 * p + 2] = nan;
-      B.track[2 * p] = (double)x;
-      B.track[2 * p + 1] = (double)y;
+      B.track[2 * p] = x;
+      B.track[2 * p + 1] = y;
 #pragma unroll
       for (int q = 0; q < 12; ++q) B.pose[12 * p + q] = nan;
       ++p;

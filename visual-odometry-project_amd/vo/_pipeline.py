@@ -93,7 +93,7 @@ class Pipeline:
         """Hands over `features` (a vo.primitives.Features: the current frame's, e.g. after the bootstrap) and
         State's poses (4x4 camera-to-world) for frame slot `idx`."""
         n = features.length
-        kp = _c(np.asarray(features.keypoints).reshape(n, 2), np.float32)
+        kp = _c(np.asarray(features.keypoints).reshape(n, 2), np.float64)
         state = _c(np.asarray(features.state).reshape(n), np.uint8)
         land = _c(np.asarray(features.landmarks).reshape(n, 3), np.float64)
         tracks = _c(np.asarray(features.tracks).reshape(n, 2), np.float64)
@@ -114,7 +114,7 @@ class Pipeline:
         cap = self.cap
         n = C.c_int32()
         nf = C.c_int32()
-        kp = np.empty((cap, 2), np.float32)
+        kp = np.empty((cap, 2), np.float64)
         state = np.empty(cap, np.uint8)
         cand = np.empty(cap, np.uint8)
         land = np.empty((cap, 3), np.float64)

@@ -102,33 +102,39 @@ def _gray(image):
 
 
 def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int = 2000, klt_win: int = 17,
-                  klt_max_level: int = 2, hyp: int = 1000, context=None, verbose: bool = False):
+                  klt_max_level: int = 2, hyp: int = 1000, context=None, verbose: bool = False,
+                  redetect_start_pose: str = "current"):
     """Same loop, same bootstrap, but the steady state runs as the device-resident pipeline (vo_pipeline_*):
     after the host bootstrap the Features / State arrays are handed to the GPU once, every later frame costs one
     image upload and one call, and nothing but the pose record comes back.  KLT tracker mode with the Harris
     detector (BASELINE.json configs[1]); P3P-RANSAC as main.py:194-201 configures it (1.25 px, confidence 0.9999)
-    with `hyp` hypotheses solved and scored per frame."""
+    with `hyp` hypotheses solved and scored per frame.  redetect_start_pose: "identity" is the reference's
+    update_features (klt.py:148-153: re-detected keypoints start their track at np.eye(4), so away from the origin
+    they triangulate against a wrong baseline and can take the estimate with them); "current" starts them at the
+    pose of the frame they were found on."""
     from vo import _native
     from vo.features.klt import KLTTracker
     ctx = context or _native.default_context()
-    saved = (KLTTracker._detector, dict(KLTTracker._harris_params), dict(KLTTracker._lk_params))
+    saved = (dict(KLTTracker._feature_params), dict(KLTTracker._lk_params))
 
     def setup():
-        KLTTracker._detector = "harris"
-        KLTTracker._harris_params = dict(patch_size=9, kappa=0.09, num_keypoints=n_keypoints, nonmaximum_supression_radius=5)
-        KLTTracker._lk_params = dict(saved[2], winSize=(klt_win, klt_win), maxLevel=klt_max_level)
+        # the bootstrap tracks Shi-Tomasi corners (the reference's find_corners, klt.py:98), as many as the
+        # pipeline's detector keeps per frame
+        KLTTracker._feature_params = dict(saved[0], maxCorners=n_keypoints)
+        KLTTracker._lk_params = dict(saved[1], winSize=(klt_win, klt_win), maxLevel=klt_max_level)
 
     try:
         state, tracker, _, _ = bootstrap(sequence, "klt", tracker_setup=setup)
     finally:
-        KLTTracker._detector, KLTTracker._harris_params, KLTTracker._lk_params = saved
+        KLTTracker._feature_params, KLTTracker._lk_params = saved
     frame = state.curr_frame
     img = _gray(frame.image)
     H, W = img.shape
     K = np.asarray(sequence.get_camera().intrinsic_matrix, np.float64)
     pipe = _native.Pipeline(ctx, H, W, 3, K, n_keypoints=n_keypoints, klt_win=klt_win, klt_max_level=klt_max_level,
                             hyp=hyp, p3p_threshold=1.25 ** 2, outlier_ratio=0.9, confidence=0.9999, max_iterations=10000,
-                            refine_iters=20, bearing_threshold=state._bearing_threshold)
+                            refine_iters=20, bearing_threshold=state._bearing_threshold,
+                            redetect_start_pose=redetect_start_pose)
     pipe.set_frame(0, img)
     pipe.set_state(0, frame.features, state.curr_pose, state.prev_pose, num_features=tracker._tracker._num_features)
     trajectory = [np.eye(4), state.get_pose()]
