@@ -56,13 +56,13 @@ def algorithmic_bytes(kernel_name, n_in, n_tracked, n_tri):
         "nms_select": N_KP * 16,
         "pyr_down": 2 * px + px // 4 + px // 16,              # frame read, bordered copy of level 0, levels 1 and 2 written
         "klt_track": n_in * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + n_in * (8 + 8 + 1 + 4),
-        "state_append": N_KP * (16 + feat),
         "state_regroup": n_in * (8 + 1 + 4 + 1) + n_tracked * 2 * feat,
         "p3p_solve": HYP * (28 + 4 * 40 + 96 + 1),
         "p3p_score": n_tri * 40 + HYP * (96 + 1 + 4 + ((n_tri + 63) // 64) * 8),
         "ransac_replay": HYP * 5 + 96 + ((n_tri + 63) // 64) * 16,
         "refine_pose": n_tri * 40 + ((n_tri + 63) // 64) * 8 + 96 + 120,
-        "state_update": n_tracked * (feat + 24) + ((n_tri + 63) // 64) * 8,
+        "state_candidates": n_tracked * (16 + 1 + 16 + 96 + 1) + ((n_tri + 63) // 64) * 8,
+        "state_landmarks": n_tracked * (1 + 1 + 24 + 16 + 96 + 24),
     }
     return table.get(kernel_name)
 
@@ -71,9 +71,9 @@ ROCPROF_NAMES = {"klt_track": "klt_track16_kernel<15, 16>", "nms_round": "nms_ro
                  "nms_candidates": "nms_candidates_kernel<5>", "harris_response": "harris_response_kernel<9>",
                  "p3p_solve": "p3p_solve_kernel<true>", "p3p_score": "p3p_score_kernel", "nms_compact": "nms_compact_kernel",
                  "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel", "refine_pose": "refine_pose_kernel",
-                 "pyr_down": "pyramid3_kernel", "state_append": "state_append_kernel",
-                 "state_regroup": "state_regroup_kernel<false>", "ransac_replay": "ransac_replay_kernel",
-                 "state_update": "state_update_kernel"}
+                 "pyr_down": "pyramid3_kernel", "state_regroup": "state_regroup_klt_kernel",
+                 "ransac_replay": "ransac_replay_kernel", "state_candidates": "state_candidates_kernel",
+                 "state_landmarks": "state_landmarks_kernel"}
 
 
 def pmc_traffic(kernel_name):
@@ -126,17 +126,20 @@ def walk(start, n, steps):
 
 def bootstrap_state(stream):
     """main.py:204-230 on frames 0 and 2 of the stream, on the host (untimed): Shi-Tomasi corners (as many as the
-    detector keeps per frame), KLT, 8-point RANSAC, essential matrix, cheirality, DLT."""
+    detector keeps per frame), KLT, 8-point RANSAC, essential matrix, cheirality, DLT.  Two settings differ from
+    the per-frame loop because frames 0 and 2 are two steps apart at this resolution (measured, tools/dev/boot_dbg.py:
+    with the loop's 15x15 / 3-level tracker and the reference's 0.25 px epipolar threshold the 8-point RANSAC settles
+    on a wrong model, 114 landmarks, 3 m off): the bootstrap tracks with 21x21 / 4 levels and accepts 1 px."""
     from vo import driver
     from vo.features.klt import KLTTracker
     saved = (dict(KLTTracker._feature_params), dict(KLTTracker._lk_params))
 
     def setup():
         KLTTracker._feature_params = dict(saved[0], maxCorners=N_KP)
-        KLTTracker._lk_params = dict(saved[1], winSize=(WIN, WIN), maxLevel=MAX_LEVEL)
+        KLTTracker._lk_params = dict(saved[1], winSize=(21, 21), maxLevel=3)
 
     try:
-        state, tracker, _, _ = driver.bootstrap(ResidentSequence(stream), "klt", tracker_setup=setup)
+        state, tracker, _, _ = driver.bootstrap(ResidentSequence(stream), "klt", tracker_setup=setup, ransac_threshold=1.0)
     finally:
         KLTTracker._feature_params, KLTTracker._lk_params = saved
     return state

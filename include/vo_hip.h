@@ -87,10 +87,10 @@ enum {
   VO_K_SIFT_DETECT = 19,
   VO_K_SIFT_DESCRIBE = 20,
   VO_K_REFINE = 21,
-  VO_K_STATE_APPEND = 22,
+  VO_K_STATE_CANDIDATES = 22,
   VO_K_STATE_REGROUP = 23,
   VO_K_RANSAC_REPLAY = 24,
-  VO_K_STATE_UPDATE = 25,
+  VO_K_STATE_LANDMARKS = 25,
   VO_K_EXPORT = 26,
   VO_K_COUNT = 32
 };

@@ -312,13 +312,19 @@ __device__ __forceinline__ void wave_sync() {
 
 // WIN_T > 0: window side known at compile time (index arithmetic folds, loops unroll)
 template <int WIN_T>
-__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, int win_arg,
+__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, int win_arg,
                                                        int max_iter, double eps2, float min_eig_thr,
                                                        float* __restrict__ next_xy, uint8_t* __restrict__ status,
                                                        float* __restrict__ err, int lds_per_wave) {
   extern __shared__ __align__(16) unsigned char smem_all[];
   const int i = blockIdx.x * KLT_WAVES + (threadIdx.x >> 6);
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
+  int n_own = N;                                       // points 0 .. n_own-1 are prev_xy's, the rest the detector's
+  if (src.n) {
+    n_own = *src.n;
+    const bool redetect = (double)n_own < (double)*src.num_features * src.frac;
+    N = min(N, n_own + (redetect ? src.n_det : 0));
+  }
   if (i >= N) return;                                  // whole wave leaves together
   unsigned char* smem = smem_all + (size_t)(threadIdx.x >> 6) * lds_per_wave;
   const int lane = threadIdx.x & 63;
@@ -333,7 +339,8 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
 
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
-  const float p0x = prev_xy[2 * i], p0y = prev_xy[2 * i + 1];
+  const float p0x = i < n_own ? prev_xy[2 * i] : (float)src.det_kp[2 * (i - n_own)];
+  const float p0y = i < n_own ? prev_xy[2 * i + 1] : (float)src.det_kp[2 * (i - n_own) + 1];
   bool ok = true;
   float e_out = 0.f;
   float nx = 0.f, ny = 0.f;
@@ -628,7 +635,7 @@ __device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pit
 }
 
 template <int WIN, int LPK>
-__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, int max_iter,
+__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, int max_iter,
                                                          double eps2, float min_eig_thr, float* __restrict__ next_xy,
                                                          uint8_t* __restrict__ status, float* __restrict__ err) {
   typedef klt_rows<WIN> G;
@@ -639,6 +646,12 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   const int lane = threadIdx.x;
   const int i = blockIdx.x * KPW + lane / LPK;
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
+  int n_own = N;                                       // points 0 .. n_own-1 are prev_xy's, the rest the detector's
+  if (src.n) {
+    n_own = *src.n;
+    const bool redetect = (double)n_own < (double)*src.num_features * src.frac;
+    N = min(N, n_own + (redetect ? src.n_det : 0));
+  }
   if (i >= N) return;                                  // all lanes of a keypoint leave together
   const int r = lane & (LPK - 1);                      // window row of this lane (row WIN only feeds row WIN-1's derivatives)
   uint8_t* s_reg = smem + (lane / LPK) * G::SLICE;
@@ -648,7 +661,8 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
 
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
-  const float p0x = prev_xy[2 * i], p0y = prev_xy[2 * i + 1];
+  const float p0x = i < n_own ? prev_xy[2 * i] : (float)src.det_kp[2 * (i - n_own)];
+  const float p0y = i < n_own ? prev_xy[2 * i + 1] : (float)src.det_kp[2 * (i - n_own) + 1];
   bool ok = true;
   float e_out = 0.f;
   float nx = 0.f, ny = 0.f;
@@ -970,8 +984,9 @@ int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_p
 int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
                       const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N,
                       const int32_t* d_n, int win, int max_iter, double eps, double min_eig, float* d_next_xy,
-                      uint8_t* d_status, float* d_err) {
+                      uint8_t* d_status, float* d_err, const vo_klt_source* src_in) {
   if (!ctx) return VO_EINVAL;
+  const vo_klt_source src = src_in ? *src_in : vo_klt_source();
   VO_REQUIRE(ctx, N >= 0, "klt_track: bad N");
   if (N == 0) return VO_OK;
   VO_REQUIRE(ctx, d_prev && d_next && d_prev_xy && d_next_xy && d_status && d_err, "klt_track: null pointer");
@@ -1012,19 +1027,19 @@ int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_
     const dim3 kgrid(vo_cdiv(N, KLT_WAVES)), kblock(64 * KLT_WAVES);
     switch (win) {
       case 15:
-        hipLaunchKernelGGL((klt_track16_kernel<15, 16>), dim3(vo_cdiv(N, 4)), dim3(64), 0, st, P, d_prev_xy, N, d_n, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<15, 16>), dim3(vo_cdiv(N, 4)), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 17:   // the reference's default window (klt.py:29)
-        hipLaunchKernelGGL((klt_track16_kernel<17, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, d_n, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<17, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 21:
-        hipLaunchKernelGGL((klt_track16_kernel<21, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, d_n, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<21, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       default:
-        hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, d_n, win, max_iter, eps * eps,
+        hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, d_n, src, win, max_iter, eps * eps,
                            me, d_next_xy, d_status, d_err, lds_wave);
     }
   }

@@ -401,13 +401,23 @@ static int enqueue_main(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fir
   const vo_pipeline_config& c = p->cfg;
   const vo_feat A = p->F[f.fcur], B = p->F[1 - f.fcur];
   if (hipEventQuery(p->evDet[f.a]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[f.a], 0));
-  VO_TRY(vo_state_append(ctx, p->d_ctl, A, p->d_kp[f.a], c.n_keypoints, c.redetect_fraction, p->cap, debug_fault_every,
-                         c.redetect_start_pose));
   if (hipEventQuery(p->evPyr[f.b]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evPyr[f.b], 0));
+  vo_klt_source src;
+  src.n = &p->d_ctl->n;
+  src.num_features = &p->d_ctl->num_features;
+  src.frac = c.redetect_fraction;
+  src.det_kp = p->d_kp[f.a];
+  src.n_det = c.n_keypoints;
   VO_TRY(vo_klt_track_ndev(ctx, p->d_img[f.prev_idx], p->d_pyr[f.a], p->d_img[f.next_idx], p->d_pyr[f.b], c.H, c.W,
-                           p->n_levels, A.kp, p->cap, &p->d_ctl->n_in, c.klt_win, c.klt_max_iter, c.klt_eps,
-                           c.klt_min_eig, p->d_next, p->d_status, p->d_err));
-  VO_TRY(vo_state_regroup_klt(ctx, p->d_ctl, A, B, p->d_next, p->d_status, p->d_err, (float)c.klt_err_threshold, p->cap));
+                           p->n_levels, A.kp, p->cap, nullptr, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
+                           p->d_next, p->d_status, p->d_err, &src));
+  vo_append ap;
+  ap.det_kp = p->d_kp[f.a];
+  ap.n_det = c.n_keypoints;
+  ap.frac = c.redetect_fraction;
+  ap.pose_mode = c.redetect_start_pose;
+  ap.debug_fault_every = debug_fault_every;
+  VO_TRY(vo_state_regroup_klt(ctx, p->d_ctl, A, B, p->d_next, p->d_status, p->d_err, (float)c.klt_err_threshold, ap, p->cap));
   if (first_half_only) return VO_OK;
   VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, B.land, B.kp64, &p->d_ctl->n_p3p, p->cap, c.K, p->d_raws, nullptr, 0u, c.hyp,
                                    c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks,
@@ -418,8 +428,10 @@ static int enqueue_main(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fir
   if (c.refine_iters > 0)
     VO_TRY(vo_refine_pose_ndev(ctx, B.land, B.kp64, p->cap, &p->d_ctl->n_p3p, c.K, nullptr, p->d_best_mask,
                                p->d_ctl->best_pose, c.refine_iters, p->d_ctl->refined, 0u));
-  VO_TRY(vo_state_update(ctx, p->d_ctl, B, p->d_best_mask, p->cam, c.bearing_threshold, c.refine_iters > 0 ? 1 : 0, 3,
-                         p->cap, p->m_res + f.rslot, p->m_seq + f.rslot, f.seq));
+  VO_TRY(vo_state_candidates(ctx, p->d_ctl, B, p->d_best_mask, p->cam, c.bearing_threshold, c.refine_iters > 0 ? 1 : 0,
+                             p->cap));
+  VO_TRY(vo_state_landmarks(ctx, p->d_ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + f.rslot,
+                            p->m_seq + f.rslot, f.seq));
   return VO_OK;
 }
 
@@ -663,14 +675,17 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
   h.consumed = total_consumed;
   h.hyp_valid = hyp_valid;
   h.n_done = n_done;
+  h.n_cand = h.n_dropped = h.n_land = h.done = 0;
   memcpy(h.best_pose, best_pose, 96);
   VO_HIP_TRY(ctx, hipMemcpy(p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
   const unsigned seq = ++p->seq;
   if (c.refine_iters > 0)
     VO_TRY(vo_refine_pose_ndev(ctx, B.land, B.kp64, p->cap, &p->d_ctl->n_p3p, c.K, nullptr, p->d_best_mask,
                                p->d_ctl->best_pose, c.refine_iters, p->d_ctl->refined, 0u));
-  VO_TRY(vo_state_update(ctx, p->d_ctl, B, p->d_best_mask, p->cam, c.bearing_threshold, c.refine_iters > 0 ? 1 : 0, 3,
-                         p->cap, p->m_res + f.rslot, p->m_seq + f.rslot, seq));
+  VO_TRY(vo_state_candidates(ctx, p->d_ctl, B, p->d_best_mask, p->cam, c.bearing_threshold, c.refine_iters > 0 ? 1 : 0,
+                             p->cap));
+  VO_TRY(vo_state_landmarks(ctx, p->d_ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + f.rslot,
+                            p->m_seq + f.rslot, seq));
   VO_TRY(wait_record(p, f.rslot, seq));
   *out = p->h_res[f.rslot];
   out->recovered = 1;
@@ -744,6 +759,7 @@ int vo_pipeline_bookkeeping(vo_pipeline* p, int phases, const double* new_kp, in
     VO_HIP_TRY(ctx, hipMemcpy(&h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
     memcpy(h.T_in_wc, T_wc, 96);
     memcpy(h.T_in_cw, T_cw, 96);
+    h.n_cand = h.n_dropped = h.n_land = h.done = 0;
     VO_HIP_TRY(ctx, hipMemcpy(p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     std::vector<uint64_t> bits((size_t)p->words, ~0ull);
     if (p3p_inliers)
@@ -751,8 +767,10 @@ int vo_pipeline_bookkeeping(vo_pipeline* p, int phases, const double* new_kp, in
         if (!p3p_inliers[i]) bits[i >> 6] &= ~(1ull << (i & 63));
     VO_HIP_TRY(ctx, hipMemcpy(p->d_best_mask, bits.data(), bits.size() * 8, hipMemcpyHostToDevice));
   }
-  VO_TRY(vo_state_update(ctx, p->d_ctl, p->F[p->cur], p->d_best_mask, p->cam, p->cfg.bearing_threshold, -1, phases,
-                         p->cap, nullptr, nullptr, 0u));
+  if (phases & 1)
+    VO_TRY(vo_state_candidates(ctx, p->d_ctl, p->F[p->cur], p->d_best_mask, p->cam, p->cfg.bearing_threshold, -1, p->cap));
+  if (phases & 2)
+    VO_TRY(vo_state_landmarks(ctx, p->d_ctl, p->F[p->cur], p->cam, -1, p->cap, nullptr, nullptr, 0u));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   return VO_OK;
 }

@@ -22,45 +22,9 @@
 namespace {
 
 constexpr int RG_T = 1024;   // regroup: threads
-constexpr int UP_T = 512;    // update: threads
+
 
 __device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000ll); }
-
-// ---------------------------------------------------------------------------------------------
-// klt.py:207-230 -> update_features (klt.py:117-189)
-__global__ __launch_bounds__(256) void state_append_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat F,
-                                                           const double* __restrict__ det_kp, int n_det, double frac,
-                                                           int cap, int debug_fault_every, int pose_mode) {
-  const int n = ctl->n;
-  int fault = ctl->fault;
-  if (debug_fault_every > 0 && (ctl->step % debug_fault_every) == debug_fault_every - 1) fault |= VO_FAULT_FORCED;
-  // `length < self._num_features * 0.8` (klt.py:208-212)
-  const bool redetect = !fault && (double)n < (double)ctl->num_features * frac;
-  if (redetect && n + n_det > cap) fault |= VO_FAULT_CAPACITY;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (redetect && !fault && i < n_det) {
-    const int j = n + i;
-    const double x = det_kp[2 * i], y = det_kp[2 * i + 1];
-    F.kp[2 * j] = (float)x;
-    F.kp[2 * j + 1] = (float)y;
-    F.kp64[2 * j] = (double)(float)x;
-    F.kp64[2 * j + 1] = (double)(float)y;
-    F.state[j] = 0;
-    F.cand[j] = 0;
-    F.land[3 * j] = F.land[3 * j + 1] = F.land[3 * j + 2] = dnan();
-    F.track[2 * j] = (double)(float)x;          // "tracks are extended with the new keypoints"
-    F.track[2 * j + 1] = (double)(float)y;
-#pragma unroll
-    for (int k = 0; k < 12; ++k)   // np.eye(4) (klt.py:148-153), or the pose of the frame the keypoints were found on
-      F.pose[12 * j + k] = pose_mode ? ctl->T_wc[k] : ((k == 0 || k == 5 || k == 10) ? 1.0 : 0.0);
-  }
-  if (i == 0) {
-    // (n and num_features are only read by this kernel; what it decides goes to words of its own)
-    ctl->n_in = fault ? 0 : (redetect ? n + n_det : n);
-    ctl->redetected = (redetect && !fault) ? 1 : 0;
-    ctl->fault = fault;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Block-wide exclusive scan of three counters packed into one 64-bit word (21 bits each).
@@ -241,10 +205,144 @@ __host__ __device__ inline long long table_lookup(const double* table, int len, 
   return (max_it >= 0 && max_it < k) ? max_it : k;
 }
 
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rigid_inverse_3x4(const double* T, double* Ti) {
+  // [R t] -> [R^T  -R^T t]
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Ti[4 * r + c] = T[4 * c + r];
+    Ti[4 * r + 3] = -(T[r] * T[3] + T[4 + r] * T[7] + T[8 + r] * T[11]);
+  }
+}
+
+__device__ __forceinline__ void k_times(const double* K, const double* T, double* C) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) C[4 * r + c] = K[3 * r] * T[c] + K[3 * r + 1] * T[4 + c] + K[3 * r + 2] * T[8 + c];
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// klt.py:191-280 behind the tracker + Matches.__init__ (matches.py:26-212) for identity matches, many workgroups,
+// none of which waits for another: every workgroup of 256 items counts the group sizes of ALL items itself (a few
+// KB of flags, coalesced, from L2) and the sizes before its own first item, so an item's place in the new frame
+//     base(group) + #(same group before the workgroup) + #(same group before it inside the workgroup)
+// needs no communication.  The re-detect branch (klt.py:207-230 -> update_features, klt.py:117-189) is not a
+// copy: when fewer than frac * _num_features features are left, items n .. n + n_det - 1 ARE the detector's
+// keypoints of the old frame (state 0, landmark NaN, track start = the keypoint, start pose np.eye(4)) -- the
+// tracker kernel read its points the same way (vo_klt_source).
+__global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat A, vo_feat B,
+                                                                const float* __restrict__ next_xy,
+                                                                const uint8_t* __restrict__ status,
+                                                                const float* __restrict__ err, float err_thr,
+                                                                vo_append ap, int cap) {
+  __shared__ unsigned long long s_red[2][4];
+  __shared__ int s_wcnt[3][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int fault = ctl->fault;
+  const int n = ctl->n;
+  if (ap.debug_fault_every > 0 && (ctl->step % ap.debug_fault_every) == ap.debug_fault_every - 1) fault |= VO_FAULT_FORCED;
+  // `length < self._num_features * 0.8` (klt.py:208-212)
+  const bool redetect = !fault && (double)n < (double)ctl->num_features * ap.frac;
+  if (redetect && n + ap.n_det > cap) fault |= VO_FAULT_CAPACITY;
+  if (fault) {
+    if (blockIdx.x == 0 && tid == 0) {
+      ctl->fault = fault;
+      ctl->n_in = 0;
+      ctl->n_p3p = 0;
+      ctl->redetected = 0;
+    }
+    return;
+  }
+  const int n_in = n + (redetect ? ap.n_det : 0);
+  const int start = blockIdx.x * 256;
+  if (start >= n_in && blockIdx.x != 0) return;
+  auto key_of = [&](int j) -> int {      // 0 triangulated, 1 matched, 2 newly matched, 3 dropped
+    if (j >= n_in) return 3;
+    const bool keep = status[j] != 0 && err[j] < err_thr;
+    const int st = j < n ? (int)A.state[j] : 0;
+    return keep ? (st == 2 ? 0 : (st == 1 ? 1 : 2)) : 3;
+  };
+  unsigned long long c_all = 0ull, c_before = 0ull;
+  int my_key = 3;
+  for (int base = 0; base < n_in; base += 256) {
+    const int j = base + tid;
+    const int key = key_of(j);
+    if (base == start) my_key = key;
+    if (key < 3) {
+      const unsigned long long one = 1ull << (21 * key);
+      c_all += one;
+      if (base < start) c_before += one;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    c_all += __shfl_xor(c_all, off);
+    c_before += __shfl_xor(c_before, off);
+  }
+  // ranks inside the workgroup: one ballot per group
+  int rank = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned long long m = __ballot(my_key == k);
+    if (my_key == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wcnt[k][wv] = __popcll(m);
+  }
+  if (lane == 0) {
+    s_red[0][wv] = c_all;
+    s_red[1][wv] = c_before;
+  }
+  __syncthreads();
+  const unsigned long long total = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+  const unsigned long long before = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+  const int T0 = (int)(total & 0x1fffff), T1 = (int)((total >> 21) & 0x1fffff), T2 = (int)((total >> 42) & 0x1fffff);
+  const int j = start + tid;
+  if (my_key < 3) {
+    int dst = (int)((before >> (21 * my_key)) & 0x1fffff) + rank;
+    for (int w = 0; w < wv; ++w) dst += s_wcnt[my_key][w];
+    dst += my_key == 0 ? 0 : (my_key == 1 ? T0 : T0 + T1);
+    const double x = (double)next_xy[2 * j], y = (double)next_xy[2 * j + 1];
+    if (j < n) {
+      write_group(A, B, my_key, j, dst, x, y);
+    } else {
+      // a keypoint the detector found on the old frame, tracked: "newly matched" (matches.py:62-110)
+      const int d = j - n;
+      B.kp[2 * dst] = (float)x;
+      B.kp[2 * dst + 1] = (float)y;
+      B.kp64[2 * dst] = x;
+      B.kp64[2 * dst + 1] = y;
+      B.cand[dst] = 0;
+      B.state[dst] = 1;
+      B.land[3 * dst] = B.land[3 * dst + 1] = B.land[3 * dst + 2] = dnan();
+      B.track[2 * dst] = (double)(float)ap.det_kp[2 * d];
+      B.track[2 * dst + 1] = (double)(float)ap.det_kp[2 * d + 1];
+#pragma unroll
+      for (int k = 0; k < 12; ++k)   // np.eye(4) (klt.py:148-153), or the pose of the frame the keypoints were found on
+        B.pose[12 * dst + k] = ap.pose_mode ? ctl->T_wc[k] : ((k == 0 || k == 5 || k == 10) ? 1.0 : 0.0);
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    ctl->n_in = n_in;
+    ctl->redetected = redetect ? 1 : 0;
+    ctl->n2 = T0 + T1 + T2;
+    ctl->n_tri = T0;
+    ctl->n_mat = T1;
+    ctl->n_new = T2;
+    const int few = T0 < 8 ? VO_FAULT_FEW_LANDMARKS : 0;   // (population below what the device-side sampler handles)
+    ctl->n_p3p = few ? 0 : T0;
+    if (few) ctl->fault = few;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // One wave walks the batch of hypotheses through the reference's loop (ransac.py:90-121):
 //     while n < n_iterations: draw; model None -> continue; count; strictly better -> keep, adapt; n += 1
 // 64 hypotheses per round: a prefix maximum finds the hypotheses that improve on everything before them,
 // and between two such events n_iterations is constant, so the place where the loop ends is a ballot.
+// The flags and counts of 16 rounds are requested together, the threshold table sits in LDS.
+constexpr int RP_TABLE_LDS = 4097;
 __global__ __launch_bounds__(64) void ransac_replay_kernel(vo_seq_ctl* __restrict__ ctl,
                                                            const uint8_t* __restrict__ valid,
                                                            const int* __restrict__ counts,
@@ -254,74 +352,92 @@ __global__ __launch_bounds__(64) void ransac_replay_kernel(vo_seq_ctl* __restric
                                                            int hyp, const double* __restrict__ table, int table_len,
                                                            long long max_it,
                                                            unsigned long long* __restrict__ best_mask) {
+  __shared__ double s_table[RP_TABLE_LDS];
   if (ctl->fault) return;
   const int lane = threadIdx.x;
+  if (lane == 0) {            // counters the bookkeeping kernels of this step add to
+    ctl->n_cand = 0;
+    ctl->n_dropped = 0;
+    ctl->n_land = 0;
+    ctl->done = 0;
+  }
+  const bool lds_table = table_len + 1 <= RP_TABLE_LDS;
+  if (lds_table)
+    for (int k = lane; k < table_len + 1; k += 64) s_table[k] = table[k];
+  const double* tb = lds_table ? s_table : table;
   const int N = ctl->n_p3p;
   long long n_it = ctl->n_iterations;
   double orat = ctl->outlier_ratio;
   long long n = 0;
   int best = -1, best_idx = -1, consumed = -1, hyp_valid = 0;
   bool risky_seen = false;
-  int next_base = 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int base = 0; base < hyp && consumed < 0; base += 64) {
-    next_base = base + 64;
-    const int h = base + lane;
-    const int vb = h < hyp ? valid[h] : 0;
-    const bool v = (vb & 1) != 0;
-    const int c = v ? counts[h] : -1;
-    const unsigned long long vmask = __ballot(v), rmask = __ballot((vb & 2) != 0);
-    int pm = c;                                   // inclusive prefix maximum
+  __syncthreads();
+  for (int sbase = 0; sbase < hyp; sbase += 1024) {
+    int vbs[16], cs[16];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(pm, off);
-      if (lane >= off) pm = max(pm, o);
+    for (int q = 0; q < 16; ++q) {
+      const int h = min(sbase + 64 * q + lane, hyp - 1);
+      vbs[q] = valid[h];
+      cs[q] = counts[h];
     }
-    int epm = __shfl_up(pm, 1);
-    if (lane == 0) epm = -1;
-    epm = max(epm, best);
-    const unsigned long long imask = __ballot(v && c > epm);
-    const long long n_here = n + __popcll(vmask & lt);       // iterations counted before this lane's draw
-    int cur = 0;
-    for (;;) {
-      const unsigned long long ge = cur >= 64 ? 0ull : ~((1ull << cur) - 1ull);
-      const unsigned long long smask = __ballot(n_here >= n_it) & ge;   // the `while` test fails before this draw
-      const unsigned long long emask = imask & ge;
-      const int sp = smask ? __ffsll((long long)smask) - 1 : 64;
-      const int ep = emask ? __ffsll((long long)emask) - 1 : 64;
-      if (sp <= ep && sp < 64) {
-        consumed = base + sp;
-        n = __shfl(n_here, sp);
-        risky_seen |= (rmask & ((1ull << sp) - 1ull)) != 0ull;
-        break;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int base = sbase + 64 * q;
+      if (base >= hyp) break;
+      const int h = base + lane;
+      const int vb = h < hyp ? vbs[q] : 0;
+      const bool v = (vb & 1) != 0;
+      const unsigned long long vmask = __ballot(v);
+      hyp_valid += __popcll(vmask);
+      if (consumed >= 0) continue;                // (the loop has ended; only the statistics go on)
+      const int c = v ? cs[q] : -1;
+      const unsigned long long rmask = __ballot((vb & 2) != 0);
+      int pm = c;                                   // inclusive prefix maximum
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(pm, off);
+        if (lane >= off) pm = max(pm, o);
       }
-      if (ep == 64) {
-        n += __popcll(vmask);
-        risky_seen |= rmask != 0ull;
-        break;
+      int epm = __shfl_up(pm, 1);
+      if (lane == 0) epm = -1;
+      epm = max(epm, best);
+      const unsigned long long imask = __ballot(v && c > epm);
+      const long long n_here = n + __popcll(vmask & lt);       // iterations counted before this lane's draw
+      int cur = 0;
+      for (;;) {
+        const unsigned long long ge = cur >= 64 ? 0ull : ~((1ull << cur) - 1ull);
+        const unsigned long long smask = __ballot(n_here >= n_it) & ge;   // the `while` test fails before this draw
+        const unsigned long long emask = imask & ge;
+        const int sp = smask ? __ffsll((long long)smask) - 1 : 64;
+        const int ep = emask ? __ffsll((long long)emask) - 1 : 64;
+        if (sp <= ep && sp < 64) {
+          consumed = base + sp;
+          n = __shfl(n_here, sp);
+          risky_seen |= (rmask & ((1ull << sp) - 1ull)) != 0ull;
+          break;
+        }
+        if (ep == 64) {
+          n += __popcll(vmask);
+          risky_seen |= rmask != 0ull;
+          break;
+        }
+        best = __shfl(c, ep);
+        best_idx = base + ep;
+        {   // ransac.py:113-120
+          double o = 1.0 - (double)best / (double)N;
+          o = fmin(fmax(o, 0.01), 0.99);
+          orat = o;
+          n_it = table_lookup(tb, table_len, max_it, o);
+        }
+        cur = ep + 1;
       }
-      best = __shfl(c, ep);
-      best_idx = base + ep;
-      {   // ransac.py:113-120
-        double o = 1.0 - (double)best / (double)N;
-        o = fmin(fmax(o, 0.01), 0.99);
-        orat = o;
-        n_it = table_lookup(table, table_len, max_it, o);
-      }
-      cur = ep + 1;
     }
-    hyp_valid += __popcll(vmask);
   }
   int fault = 0;
   if (consumed < 0) {
     if (n >= n_it) consumed = hyp;                // the loop ends exactly behind the last sample of the batch
     else fault |= VO_FAULT_UNFINISHED;            // (also: no hypothesis had a solution)
-  }
-  // (valid hypotheses behind the point where the loop ended are not part of hyp_valid's meaning for the
-  //  reference; the count over the whole batch is reported for diagnostics only)
-  for (int base = next_base; base < hyp; base += 64) {
-    const int h = base + lane;
-    hyp_valid += __popcll(__ballot(h < hyp && (valid[h] & 1)));
   }
   if (risky_seen) fault |= VO_FAULT_RISKY_DRAW;
   if (!fault && best_idx < 0) fault |= VO_FAULT_UNFINISHED;
@@ -349,39 +465,105 @@ __global__ __launch_bounds__(64) void ransac_replay_kernel(vo_seq_ctl* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rigid_inverse_3x4(const double* T, double* Ti) {
-  // [R t] -> [R^T  -R^T t]
+// main.py:261-268 on the new frame's features, one feature per work item:
+//   outliers[triangulate_inliers] = ~inliers; update_from_matches + update_with_world_pose (state.py:17-50);
+//   reset_outliers (state.py:162-172); compute_candidates (state.py:135-160, 174-219: bearing angle between the
+//   rays through the track's first and last keypoint >= threshold, among state == 1).
+// use_refined: 1 the refinement's pose, 0 the accepted hypothesis, -1 the pose the host put into ctl->T_in_*.
+__global__ __launch_bounds__(256) void state_candidates_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat B,
+                                                               const unsigned long long* __restrict__ best_mask,
+                                                               vo_cam cam, double bearing_thr, int use_refined) {
+  if (ctl->fault) return;
+  const int tid = threadIdx.x;
+  const int n2 = ctl->n2, n_tri = ctl->n_tri;
+  double Tcw[12], Twc[12];
+  if (use_refined < 0) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 12; ++k) Tcw[k] = ctl->T_in_cw[k];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Ti[4 * r + c] = T[4 * c + r];
-    Ti[4 * r + 3] = -(T[r] * T[3] + T[4 + r] * T[7] + T[8 + r] * T[11]);
+    for (int k = 0; k < 12; ++k) Twc[k] = ctl->T_in_wc[k];
+  } else {
+    // world -> camera as estimated, camera -> world = its inverse (update_with_world_pose, state.py:38-50)
+    const double* src = use_refined ? ctl->refined : ctl->best_pose;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      Tcw[4 * r] = src[3 * r];
+      Tcw[4 * r + 1] = src[3 * r + 1];
+      Tcw[4 * r + 2] = src[3 * r + 2];
+      Tcw[4 * r + 3] = src[9 + r];
+    }
+    rigid_inverse_3x4(Tcw, Twc);
+  }
+  const int i = blockIdx.x * 256 + tid;
+  int cand = 0;
+  if (i < n2) {
+    int st = B.state[i];
+    const int st0 = st;
+    const double u = B.kp64[2 * i], v = B.kp64[2 * i + 1];
+    bool reset = st == 0;                                     // set_pose_for_new_tracks (features.py:224-237)
+    if (i < n_tri && !((best_mask[i >> 6] >> (i & 63)) & 1ull)) {   // P3P outlier (main.py:261-262)
+      st = 0;
+      reset = true;
+    }
+    if (reset) {
+      if (st0 != 0) {                                         // reset_outliers (state.py:162-172)
+        B.track[2 * i] = u;
+        B.track[2 * i + 1] = v;
+        B.state[i] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) B.pose[12 * i + k] = Twc[k];
+    } else if (st == 1) {
+      const double* P = B.pose + 12 * i;
+      const double a = B.track[2 * i], b = B.track[2 * i + 1];
+      const double* Ki = cam.Kinv;
+      const double n1x = Ki[0] * a + Ki[1] * b + Ki[2], n1y = Ki[3] * a + Ki[4] * b + Ki[5],
+                   n1z = Ki[6] * a + Ki[7] * b + Ki[8];
+      const double n2x = Ki[0] * u + Ki[1] * v + Ki[2], n2y = Ki[3] * u + Ki[4] * v + Ki[5],
+                   n2z = Ki[6] * u + Ki[7] * v + Ki[8];
+      const double r1x = P[0] * n1x + P[1] * n1y + P[2] * n1z, r1y = P[4] * n1x + P[5] * n1y + P[6] * n1z,
+                   r1z = P[8] * n1x + P[9] * n1y + P[10] * n1z;
+      const double r2x = Twc[0] * n2x + Twc[1] * n2y + Twc[2] * n2z, r2y = Twc[4] * n2x + Twc[5] * n2y + Twc[6] * n2z,
+                   r2z = Twc[8] * n2x + Twc[9] * n2y + Twc[10] * n2z;
+      const double dot = r1x * r2x + r1y * r2y + r1z * r2z;
+      const double l1 = sqrt(r1x * r1x + r1y * r1y + r1z * r1z), l2 = sqrt(r2x * r2x + r2y * r2y + r2z * r2z);
+      const double ang = acos(dot / (l1 * l2));
+      cand = ang >= bearing_thr ? 1 : 0;                      // (NaN compares false, as in NumPy)
+    }
+    B.cand[i] = (uint8_t)cand;
+  }
+  const unsigned long long cm = __ballot(cand != 0);
+  if ((tid & 63) == 0 && cm) atomicAdd(&ctl->n_cand, __popcll(cm));
+  if (blockIdx.x == 0) {
+    if (tid < 12) {          // update_from_matches (state.py:17-22): what was current becomes previous
+      const double ocw = ctl->T_cw[tid], owc = ctl->T_wc[tid];
+      double ncw = 0.0, nwc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        ncw = tid == k ? Tcw[k] : ncw;
+        nwc = tid == k ? Twc[k] : nwc;
+      }
+      ctl->T_cw_prev[tid] = ocw;
+      ctl->T_wc_prev[tid] = owc;
+      ctl->T_cw[tid] = ncw;
+      ctl->T_wc[tid] = nwc;
+    }
+    if (tid == 0) ctl->n = n2;       // the new frame is the current one from here on
   }
 }
 
-__device__ __forceinline__ void k_times(const double* K, const double* T, double* C) {
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) C[4 * r + c] = K[3 * r] * T[c] + K[3 * r + 1] * T[4 + c] + K[3 * r + 2] * T[8 + c];
-}
-
-// main.py:261-286 on the new frame's features (B), one workgroup:
-//   phase bit 0: outliers[triangulate_inliers] = ~inliers; update_with_world_pose; reset_outliers;
-//                compute_candidates (bearing angle >= threshold among state == 1)
-//   phase bit 1: triangulate_candidates (one start pose per track) -> update_with_world_landmarks ->
-//                _check_landmarks; step bookkeeping and the result record
-__global__ __launch_bounds__(UP_T) void state_update_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat B,
-                                                            const unsigned long long* __restrict__ best_mask,
-                                                            vo_cam cam, double bearing_thr, int use_refined, int phases,
-                                                            vo_step_result* __restrict__ res,
-                                                            unsigned* __restrict__ seq_word, unsigned seq) {
-  __shared__ int s_list[UP_T];
-  __shared__ int s_n, s_cnt[4];
+// main.py:279-286: triangulate_candidates (triangulation.py:38-86, one start pose per track) ->
+// update_with_world_landmarks (state.py:69-88) -> _check_landmarks (state.py:90-107, only when there was a
+// candidate); the workgroup that finishes last closes the step and writes its result record.
+__global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat B, vo_cam cam,
+                                                              int use_refined, vo_step_result* __restrict__ res,
+                                                              unsigned* __restrict__ seq_word, unsigned seq) {
+  __shared__ int s_cnt[2];
+  __shared__ int s_last;
   const int tid = threadIdx.x;
   const int fault = ctl->fault;
   if (fault) {
-    if (res && tid == 0) {
+    if (res && blockIdx.x == 0 && tid == 0) {
       res->fault = fault;
       res->n_features_in = ctl->n_in;
       res->n_tracked = ctl->n2;
@@ -392,132 +574,40 @@ __global__ __launch_bounds__(UP_T) void state_update_kernel(vo_seq_ctl* __restri
     }
     return;
   }
-  const int n2 = ctl->n2, n_tri = ctl->n_tri;
-  if (tid < 4) s_cnt[tid] = 0;
-  if (tid == 0) s_n = 0;
-  double Tcw[12], Twc[12], Tp[12];   // pose of the new frame both ways; world->camera pose of the frame being left
-  if (phases & 1) {
-    // update_from_matches (state.py:17-22): what was current becomes previous
+  const int n2 = ctl->n2, n_cand = ctl->n_cand;
+  if (tid < 2) s_cnt[tid] = 0;
+  double Tcw[12], Twc[12], Tp[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) Tp[k] = ctl->T_cw[k];
-    if (use_refined < 0) {          // given by the host (bookkeeping entry point), both directions
+  for (int k = 0; k < 12; ++k) Tcw[k] = ctl->T_cw[k];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) Tcw[k] = ctl->T_in_cw[k];
+  for (int k = 0; k < 12; ++k) Twc[k] = ctl->T_wc[k];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) Twc[k] = ctl->T_in_wc[k];
-    } else {
-      // world -> camera as estimated, camera -> world = its inverse (update_with_world_pose, state.py:38-50)
-      const double* src = use_refined ? ctl->refined : ctl->best_pose;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        Tcw[4 * r] = src[3 * r];
-        Tcw[4 * r + 1] = src[3 * r + 1];
-        Tcw[4 * r + 2] = src[3 * r + 2];
-        Tcw[4 * r + 3] = src[9 + r];
-      }
-      rigid_inverse_3x4(Tcw, Twc);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Tcw[k] = ctl->T_cw[k];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Twc[k] = ctl->T_wc[k];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Tp[k] = ctl->T_cw_prev[k];
-  }
+  for (int k = 0; k < 12; ++k) Tp[k] = ctl->T_cw_prev[k];
   __syncthreads();
-  if (phases & 1) {
-    for (int i = tid; i < n2; i += UP_T) {
-      int st = B.state[i];
-      const double u = B.kp64[2 * i], v = B.kp64[2 * i + 1];
-      bool reset = false;
-      if (st == 0) reset = true;                              // set_pose_for_new_tracks (features.py:224-237)
-      if (i < n_tri && !((best_mask[i >> 6] >> (i & 63)) & 1ull)) {   // P3P outlier (main.py:261-262)
-        st = 0;
-        reset = true;
-      }
-      int cand = 0;
-      if (reset) {
-        if (st == 0 && B.state[i] != 0) {                     // reset_outliers (state.py:162-172)
-          B.track[2 * i] = u;
-          B.track[2 * i + 1] = v;
-        }
+  const int i = blockIdx.x * 256 + tid;
+  int dropped = 0, land = 0;
+  if (i < n2) {
+    int st = B.state[i];
+    double X[3] = {B.land[3 * i], B.land[3 * i + 1], B.land[3 * i + 2]};
+    if (B.cand[i]) {
+      // proj1 = K inv(pose_start)[:3], proj2 = K inv(current_pose)[:3] (triangulation.py:53-57)
+      double Ts[12], Ti[12], C1[12], C2[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) B.pose[12 * i + k] = Twc[k];
-        B.state[i] = 0;
-      } else if (st == 1) {
-        // _calculate_bearing_angle (state.py:174-219): rays through the track's first and last keypoint
-        const double* P = B.pose + 12 * i;
-        const double a = B.track[2 * i], b = B.track[2 * i + 1];
-        const double* Ki = cam.Kinv;
-        const double n1x = Ki[0] * a + Ki[1] * b + Ki[2], n1y = Ki[3] * a + Ki[4] * b + Ki[5],
-                     n1z = Ki[6] * a + Ki[7] * b + Ki[8];
-        const double n2x = Ki[0] * u + Ki[1] * v + Ki[2], n2y = Ki[3] * u + Ki[4] * v + Ki[5],
-                     n2z = Ki[6] * u + Ki[7] * v + Ki[8];
-        const double r1x = P[0] * n1x + P[1] * n1y + P[2] * n1z, r1y = P[4] * n1x + P[5] * n1y + P[6] * n1z,
-                     r1z = P[8] * n1x + P[9] * n1y + P[10] * n1z;
-        const double r2x = Twc[0] * n2x + Twc[1] * n2y + Twc[2] * n2z, r2y = Twc[4] * n2x + Twc[5] * n2y + Twc[6] * n2z,
-                     r2z = Twc[8] * n2x + Twc[9] * n2y + Twc[10] * n2z;
-        const double dot = r1x * r2x + r1y * r2y + r1z * r2z;
-        const double l1 = sqrt(r1x * r1x + r1y * r1y + r1z * r1z), l2 = sqrt(r2x * r2x + r2y * r2y + r2z * r2z);
-        const double ang = acos(dot / (l1 * l2));
-        cand = ang >= bearing_thr ? 1 : 0;                    // (NaN compares false, as in NumPy)
-      }
-      B.cand[i] = (uint8_t)cand;
-    }
-    __syncthreads();                 // (every thread has read the old pose)
-    if (tid < 12) {
-      ctl->T_cw_prev[tid] = Tp[tid];
-      ctl->T_wc_prev[tid] = ctl->T_wc[tid];
-    }
-    __syncthreads();
-    if (tid < 12) {
-      ctl->T_cw[tid] = Tcw[tid];
-      ctl->T_wc[tid] = Twc[tid];
-    }
-    if (tid == 0) ctl->n = n2;       // the new frame is the current one from here on
-  }
-  if (!(phases & 2)) return;
-  __syncthreads();
-  // ---- candidates -> list (any order: every candidate writes its own slot) ----
-  double C2[12];
-  k_times(cam.K, Tcw, C2);
-  int n_cand_total = 0;
-  for (int base = 0; base < n2; base += UP_T) {
-    const int i = base + tid;
-    const bool c = i < n2 && B.cand[i] != 0;
-    if (c) s_list[atomicAdd(&s_n, 1)] = i;
-    __syncthreads();
-    const int m = s_n;
-    n_cand_total += m;
-    if (tid < m) {
-      const int k = s_list[tid];
-      // proj1 = K inv(pose_start)[:3] (triangulation.py:53-56)
-      double Ts[12], Ti[12], C1[12], X[3];
-#pragma unroll
-      for (int q = 0; q < 12; ++q) Ts[q] = B.pose[12 * k + q];
+      for (int q = 0; q < 12; ++q) Ts[q] = B.pose[12 * i + q];
       rigid_inverse_3x4(Ts, Ti);
       k_times(cam.K, Ti, C1);
-      vo_dlt::triangulate_point(C1, B.track[2 * k], B.track[2 * k + 1], C2, B.kp64[2 * k], B.kp64[2 * k + 1], X);
-      B.land[3 * k] = X[0];                                    // update_with_world_landmarks (state.py:69-88)
-      B.land[3 * k + 1] = X[1];
-      B.land[3 * k + 2] = X[2];
-      B.state[k] = 2;
+      k_times(cam.K, Tcw, C2);
+      vo_dlt::triangulate_point(C1, B.track[2 * i], B.track[2 * i + 1], C2, B.kp64[2 * i], B.kp64[2 * i + 1], X);
+      B.land[3 * i] = X[0];
+      B.land[3 * i + 1] = X[1];
+      B.land[3 * i + 2] = X[2];
+      st = 2;
+      B.state[i] = 2;
     }
-    __syncthreads();
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-  }
-  // ---- _check_landmarks (state.py:90-107) runs inside update_with_world_landmarks, i.e. only when there
-  //      was a candidate (main.py:279-284) ----
-  int dropped = 0, nland = 0;
-  for (int i = tid; i < n2; i += UP_T) {
-    int st = B.state[i];
-    if (n_cand_total > 0) {
-      const double x = B.land[3 * i], y = B.land[3 * i + 1], z = B.land[3 * i + 2];
-      const double zc = Tcw[8] * x + Tcw[9] * y + Tcw[10] * z + Tcw[11];
-      const double zp = Tp[8] * x + Tp[9] * y + Tp[10] * z + Tp[11];
-      if (zc < 0.0 || zp < 0.0) {                              // (NaN landmarks compare false)
+    if (n_cand > 0) {
+      const double zc = Tcw[8] * X[0] + Tcw[9] * X[1] + Tcw[10] * X[2] + Tcw[11];
+      const double zp = Tp[8] * X[0] + Tp[9] * X[1] + Tp[10] * X[2] + Tp[11];
+      if (zc < 0.0 || zp < 0.0) {                              // behind a camera (NaN landmarks compare false)
         const double nan = dnan();
         B.land[3 * i] = B.land[3 * i + 1] = B.land[3 * i + 2] = nan;
         B.state[i] = 0;
@@ -526,80 +616,77 @@ __global__ __launch_bounds__(UP_T) void state_update_kernel(vo_seq_ctl* __restri
         B.track[2 * i + 1] = B.kp64[2 * i + 1];
 #pragma unroll
         for (int k = 0; k < 12; ++k) B.pose[12 * i + k] = Twc[k];
-        ++dropped;
+        dropped = 1;
       }
     }
-    nland += st == 2 ? 1 : 0;
+    land = st == 2 ? 1 : 0;
   }
-  atomicAdd(&s_cnt[0], dropped);
-  atomicAdd(&s_cnt[1], nland);
+  {
+    const int d = __popcll(__ballot(dropped != 0)), l = __popcll(__ballot(land != 0));
+    if ((tid & 63) == 0) {
+      if (d) atomicAdd(&s_cnt[0], d);
+      if (l) atomicAdd(&s_cnt[1], l);
+    }
+  }
   __syncthreads();
   if (tid == 0) {
-    ctl->n = n2;
-    ctl->n_cand = n_cand_total;
-    ctl->n_dropped = s_cnt[0];
-    ctl->n_land = s_cnt[1];
-    ctl->step += 1;
+    if (s_cnt[0]) atomicAdd(&ctl->n_dropped, s_cnt[0]);
+    if (s_cnt[1]) atomicAdd(&ctl->n_land, s_cnt[1]);
+    __threadfence();
+    s_last = atomicAdd(&ctl->done, 1) == (int)gridDim.x - 1 ? 1 : 0;
   }
-  if (res) {
-    if (tid < 9) {
-      res->R[tid] = ctl->best_pose[tid];
-      res->R_refined[tid] = use_refined > 0 ? ctl->refined[tid] : ctl->best_pose[tid];
-    }
-    if (tid < 3) {
-      res->t[tid] = ctl->best_pose[9 + tid];
-      res->t_refined[tid] = use_refined > 0 ? ctl->refined[9 + tid] : ctl->best_pose[9 + tid];
-    }
-    if (tid < 12) res->T_wc[tid] = Twc[tid];
-    if (tid == 0) {
-      res->n_tracked = n2;
-      res->n_inliers = ctl->best_count;
-      res->best_index = ctl->best_idx;
-      res->hyp_valid = ctl->hyp_valid;
-      res->ransac_iterations = ctl->n_done;
-      res->draws_consumed = ctl->consumed;
-      res->refine_iterations = use_refined > 0 ? (int)ctl->refined[12] : -1;
-      res->refine_cost = use_refined > 0 ? ctl->refined[13] : 0.0;
-      res->n_features_in = ctl->n_in;
-      res->redetected = ctl->redetected;
-      res->n_triangulated = n_tri;
-      res->n_candidates = n_cand_total;
-      res->n_dropped = s_cnt[0];
-      res->n_landmarks = s_cnt[1];
-      res->fault = 0;
-      res->recovered = 0;
-      res->raw_pos = ctl->raw_pos;
-    }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last workgroup: every other one's counts are in ----
+  const int n_dropped = atomicAdd(&ctl->n_dropped, 0), n_land = atomicAdd(&ctl->n_land, 0);
+  if (tid == 0) ctl->step += 1;
+  if (!res) return;
+  if (tid < 9) {
+    res->R[tid] = ctl->best_pose[tid];
+    res->R_refined[tid] = use_refined > 0 ? ctl->refined[tid] : ctl->best_pose[tid];
+  }
+  if (tid < 3) {
+    res->t[tid] = ctl->best_pose[9 + tid];
+    res->t_refined[tid] = use_refined > 0 ? ctl->refined[9 + tid] : ctl->best_pose[9 + tid];
+  }
+  if (tid < 12) res->T_wc[tid] = ctl->T_wc[tid];
+  if (tid == 0) {
+    res->n_tracked = n2;
+    res->n_inliers = ctl->best_count;
+    res->best_index = ctl->best_idx;
+    res->hyp_valid = ctl->hyp_valid;
+    res->ransac_iterations = ctl->n_done;
+    res->draws_consumed = ctl->consumed;
+    res->refine_iterations = use_refined > 0 ? (int)ctl->refined[12] : -1;
+    res->refine_cost = use_refined > 0 ? ctl->refined[13] : 0.0;
+    res->n_features_in = ctl->n_in;
+    res->redetected = ctl->redetected;
+    res->n_triangulated = ctl->n_tri;
+    res->n_candidates = n_cand;
+    res->n_dropped = n_dropped;
+    res->n_landmarks = n_land;
+    res->fault = 0;
+    res->recovered = 0;
+    res->raw_pos = ctl->raw_pos;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
     __threadfence_system();
-    __syncthreads();
-    if (tid == 0) {
-      __threadfence_system();
-      *seq_word = seq;
-    }
+    *seq_word = seq;
   }
 }
 
 }  // namespace
 
-int vo_state_append(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat F, const double* d_det_kp, int n_det, double frac, int cap,
-                    int debug_fault_every, int pose_mode) {
-  {
-    vo_prof_scope ps(ctx, VO_K_STATE_APPEND);
-    hipLaunchKernelGGL(state_append_kernel, dim3(vo_cdiv(n_det > 0 ? n_det : 1, 256)), dim3(256), 0, ctx->stream, ctl, F,
-                       d_det_kp, n_det, frac, cap, debug_fault_every, pose_mode);
-  }
-  return vo_check_launch(ctx, "state_append_kernel");
-}
-
 int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const float* d_next_xy,
-                         const uint8_t* d_status, const float* d_err, float err_thr, int cap) {
-  VO_REQUIRE(ctx, cap <= RG_T * RG_MAX_PER, "state_regroup: capacity %d above %d", cap, RG_T * RG_MAX_PER);
+                         const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap) {
   {
     vo_prof_scope ps(ctx, VO_K_STATE_REGROUP);
-    hipLaunchKernelGGL(state_regroup_kernel<false>, dim3(1), dim3(RG_T), 0, ctx->stream, ctl, A, B, d_next_xy, d_status,
-                       d_err, err_thr, (const int*)nullptr, 0, (const double*)nullptr, 0, cap);
+    hipLaunchKernelGGL(state_regroup_klt_kernel, dim3(vo_cdiv(cap, 256)), dim3(256), 0, ctx->stream, ctl, A, B, d_next_xy,
+                       d_status, d_err, err_thr, ap, cap);
   }
-  return vo_check_launch(ctx, "state_regroup_kernel");
+  return vo_check_launch(ctx, "state_regroup_klt_kernel");
 }
 
 int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const int32_t* d_pairs, int M,
@@ -625,16 +712,24 @@ int vo_state_ransac_replay(vo_ctx* ctx, vo_seq_ctl* ctl, const uint8_t* d_valid,
   return vo_check_launch(ctx, "ransac_replay_kernel");
 }
 
-int vo_state_update(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
-                    double bearing_thr, int use_refined, int phases, int cap, vo_step_result* m_result,
-                    unsigned* m_seq, unsigned seq) {
+int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
+                        double bearing_thr, int use_refined, int cap) {
   {
-    vo_prof_scope ps(ctx, VO_K_STATE_UPDATE);
-    hipLaunchKernelGGL(state_update_kernel, dim3(1), dim3(UP_T), 0, ctx->stream, ctl, B,
-                       (const unsigned long long*)d_best_mask, cam, bearing_thr, use_refined, phases, m_result, m_seq,
-                       seq);
+    vo_prof_scope ps(ctx, VO_K_STATE_CANDIDATES);
+    hipLaunchKernelGGL(state_candidates_kernel, dim3(vo_cdiv(cap, 256)), dim3(256), 0, ctx->stream, ctl, B,
+                       (const unsigned long long*)d_best_mask, cam, bearing_thr, use_refined);
   }
-  return vo_check_launch(ctx, "state_update_kernel");
+  return vo_check_launch(ctx, "state_candidates_kernel");
+}
+
+int vo_state_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, vo_cam cam, int use_refined, int cap,
+                       vo_step_result* m_result, unsigned* m_seq, unsigned seq) {
+  {
+    vo_prof_scope ps(ctx, VO_K_STATE_LANDMARKS);
+    hipLaunchKernelGGL(state_landmarks_kernel, dim3(vo_cdiv(cap, 256)), dim3(256), 0, ctx->stream, ctl, B, cam,
+                       use_refined, m_result, m_seq, seq);
+  }
+  return vo_check_launch(ctx, "state_landmarks_kernel");
 }
 
 int64_t vo_ransac_table_lookup(const double* table, int table_len, int64_t max_iterations, double outlier_ratio) {

@@ -148,7 +148,7 @@ static const char* const k_names[VO_K_COUNT] = {
     "harris_response", "nms_candidates", "nms_threshold", "nms_compact", "nms_select",
     "patch_descriptors", "pyr_down", "klt_track", "dlt_triangulate", "p3p_solve",
     "p3p_score", "reproj_inliers", "match_knn2", "track_gather", "nms_round", "nms_collect", "nms_rank", "nms_emit", "sift_scale_space", "sift_detect", "sift_describe", "refine_pose",
-    "state_append", "state_regroup", "ransac_replay", "state_update", "export_state"};
+    "state_candidates", "state_regroup", "ransac_replay", "state_landmarks", "export_state"};
 
 const char* vo_kernel_name(int k) {
   if (k < 0 || k >= VO_K_COUNT || !k_names[k]) return "";

@@ -134,8 +134,17 @@ int vo_triangulate_dlt_ndev(vo_ctx* ctx, const double* d_x1, const double* d_x2,
 int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const int32_t* d_n, const double* K,
                         const uint8_t* d_mask8, const uint64_t* d_mask_bits, const double* d_Rt0, int max_iter,
                         double* d_out14, unsigned tag);
-// KLT with a device-resident keypoint count (klt.hip)
+// KLT with a device-resident keypoint count (klt.hip).  src (optional): the frame loop's view of its points --
+// keypoints 0 .. *n-1 come from d_prev_xy; when *n < frac * *num_features (the re-detect rule, klt.py:207-230)
+// the detector's n_det keypoints follow as points *n .. *n + n_det - 1.
+struct vo_klt_source {
+  const int32_t* n = nullptr;
+  const int32_t* num_features = nullptr;
+  double frac = 0.0;
+  const double* det_kp = nullptr;
+  int n_det = 0;
+};
 int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
                       const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N,
                       const int32_t* d_n, int win, int max_iter, double eps, double min_eig, float* d_next_xy,
-                      uint8_t* d_status, float* d_err);
+                      uint8_t* d_status, float* d_err, const vo_klt_source* src = nullptr);

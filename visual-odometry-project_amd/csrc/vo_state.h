@@ -47,7 +47,7 @@ struct vo_seq_ctl {
   // ---- this step ----
   int32_t best_idx, best_count, consumed, hyp_valid;
   int64_t n_done;
-  int32_t n_cand, n_dropped, n_land, pad1;
+  int32_t n_cand, n_dropped, n_land, done;   // counters the bookkeeping kernels add to (zeroed by the replay kernel)
   double best_pose[12];    // R (9, row-major) then t (3) of the accepted hypothesis
   double refined[16];      // refine_pose_kernel's output: R, t, accepted steps, cost (+ tag)
   // 3x4 row-major, world->camera and camera->world: State.curr_pose / State.prev_pose (state.py:9-15), and a
@@ -59,14 +59,21 @@ struct vo_cam {
   double K[9], Kinv[9];
 };
 
+// The re-detect branch (klt.py:207-230) without a copy: when fewer than frac * _num_features features are left,
+// the tracker and the regroup kernel treat the detector's keypoints of the old frame as features n .. n+n_det-1.
+struct vo_append {
+  const double* det_kp;     // n_det x 2 (device)
+  int n_det;
+  double frac;
+  int pose_mode;            // vo_pipeline_config.redetect_start_pose
+  int debug_fault_every;
+};
+
 // ---- launches (state.hip); all asynchronous on ctx->stream ----
-// klt.py:207-230: when fewer than frac * _num_features survive, the detector's keypoints of the old
-// frame are appended as new, unmatched features (update_features, klt.py:117-189)
-int vo_state_append(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat F, const double* d_det_kp, int n_det, double frac, int cap,
-                    int debug_fault_every, int pose_mode);
-// klt.py:244-278 + matches.py:26-212: keep status & err < thr, then the 4-group regroup of the new frame
+// klt.py:207-230 + 244-278 + matches.py:26-212: (virtual) re-detect append, keep status & err < thr, then the
+// 4-group regroup of the new frame
 int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const float* d_next_xy,
-                         const uint8_t* d_status, const float* d_err, float err_thr, int cap);
+                         const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap);
 // matches.py:26-212 for an explicit match list (harris / sift trackers, tests)
 int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const int32_t* d_pairs, int M,
                            const double* d_new_kp, int n2_in, int cap);
@@ -74,11 +81,13 @@ int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, c
 int vo_state_ransac_replay(vo_ctx* ctx, vo_seq_ctl* ctl, const uint8_t* d_valid, const int32_t* d_counts,
                            const double* d_R, const double* d_t, const uint64_t* d_masks, int words, int hyp,
                            const double* d_thr_table, int table_len, int64_t max_iterations, uint64_t* d_best_mask);
-// main.py:261-286 + state.py:38-50, 90-107, 135-219 + triangulation.py:38-86.  phases: bit 0 = pose, outliers,
-// candidates; bit 1 = candidate triangulation, landmark insertion, cheirality check, step bookkeeping.
-int vo_state_update(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
-                    double bearing_thr, int use_refined, int phases, int cap, vo_step_result* m_result,
-                    unsigned* m_seq, unsigned seq);
+// main.py:261-268 + state.py:17-50, 135-219: pose, outliers, bearing-angle candidates
+int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
+                        double bearing_thr, int use_refined, int cap);
+// main.py:279-286 + triangulation.py:38-86 + state.py:69-107: candidate triangulation, landmark insertion,
+// cheirality check, step bookkeeping and the result record
+int vo_state_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, vo_cam cam, int use_refined, int cap,
+                       vo_step_result* m_result, unsigned* m_seq, unsigned seq);
 // n_iterations for an outlier ratio through the threshold table (host copy of the device lookup; tests)
 int64_t vo_ransac_table_lookup(const double* table, int table_len, int64_t max_iterations, double outlier_ratio);
 void vo_ransac_build_table(double confidence, int s, int table_len, double* table);

@@ -23,21 +23,21 @@ from vo.pose_estimation import P3PPoseEstimator
 from vo.primitives import Features, Sequence, State
 
 
-def make_estimators(camera):
-    """The triangulator and pose estimator as src/main.py:185-201 configures them."""
+def make_estimators(camera, ransac_threshold=0.25):
+    """The triangulator and pose estimator as src/main.py:185-201 configures them (ransac_threshold: 0.25 px there)."""
     triangulator = LandmarksTriangulator(camera1=camera, camera2=camera, use_ransac=True, use_opencv=True,
-                                         outlier_ratio=0.9, ransac_threshold=0.25, ransac_confidence=0.999)
+                                         outlier_ratio=0.9, ransac_threshold=ransac_threshold, ransac_confidence=0.999)
     pose_estimator = P3PPoseEstimator(use_opencv=True, intrinsic_matrix=camera.intrinsic_matrix,
                                       inlier_threshold=1.25, outlier_ratio=0.9, confidence=0.9999,
                                       nonlinear_refinement=True)
     return triangulator, pose_estimator
 
 
-def bootstrap(sequence: Sequence, tracker_mode: str = "klt", tracker_setup=None):
+def bootstrap(sequence: Sequence, tracker_mode: str = "klt", tracker_setup=None, ransac_threshold=0.25):
     """main.py:204-230: frames 0 and 2 -> (state, tracker, triangulator, pose_estimator).  Runs on the host
     (8-point RANSAC, essential-matrix decomposition, cheirality) with the DLT passes on the GPU."""
     camera = sequence.get_camera()
-    triangulator, pose_estimator = make_estimators(camera)
+    triangulator, pose_estimator = make_estimators(camera, ransac_threshold)
     init_frame = next(sequence)
     state = State(init_frame)
     next(sequence)                                                       # frame 1 is skipped
