@@ -256,24 +256,28 @@ def main():
     want_exchange = world > 1 or args.exchange
 
     from vo import _native, sharding, synthetic
+    # torch's own (null-stream) work first, then the pipeline's streams: a stream is attached to one of the four
+    # hardware queues when it first runs, and the frame loop's four streams should not share one among themselves
+    cap = N_KP
+    rec_len = sharding.record_length(cap)
+    recs = [torch.zeros(EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
+    gathered = [torch.zeros(world * EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
     comp = torch.cuda.Stream()
     comm = torch.cuda.Stream()
     os.environ["VO_DEVICE"] = str(local)
     ctx = _native.Context(local, stream=comp.cuda_stream)
+    _native.set_default_context(ctx)      # the host classes of the bootstrap run on the same context / stream
     stream = synthetic.Stream(N_FRAMES, H, W, seed=2023 + rank)
-    state = bootstrap_state(stream)
     pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
                             hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
                             refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE)
+    state = bootstrap_state(stream)
     for i in range(N_FRAMES):
         pipe.set_frame(i, stream.image(i))
     pipe.set_state(2, state.curr_frame.features, state.curr_pose, state.prev_pose, num_features=N_KP)
     n_boot = int((state.curr_frame.features.state == 2).sum())
 
-    cap = N_KP
-    rec_len = sharding.record_length(cap)
-    recs = [torch.zeros(EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
-    gathered = [torch.zeros(world * EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
     batch_fill, batch_buf = 0, 0
 
     order = walk(2, N_FRAMES, args.warmup + args.steps + 96)

@@ -15,7 +15,10 @@
 // host sampler (recover_step) before re-enqueueing what was behind it.
 #include <time.h>
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <thread>
 
 #include "vo_state.h"
 
@@ -24,7 +27,9 @@
 struct vo_pipeline {
   vo_ctx* ctx = nullptr;
   vo_ctx* det[2] = {nullptr, nullptr};
-  vo_ctx* pyr = nullptr;
+  vo_ctx* pyr = nullptr;             // (= trk)
+  vo_ctx* trk = nullptr;             // the tracker's stream: KLT of step k+1 runs beside the pose estimation of step k
+  hipEvent_t evKlt[2] = {nullptr, nullptr}, evRegroup[2] = {nullptr, nullptr};
   vo_pipeline_config cfg;
   vo_cam cam;
   int n_levels = 1, cap = 0, words = 0;
@@ -59,6 +64,7 @@ struct vo_pipeline {
   uint32_t* h_stage = nullptr;
   size_t stage_cap = 0;
   uint64_t gen_upto = 0, pos_known = 0;
+  uint64_t pos_known_floor = 0;      // lower bound a fresh record's generator position must respect (wait_record)
   vo_pcg64 raw_gen, rng;
   hipEvent_t evRaw = nullptr;
   bool raw_pending = false, seeded = false, have_state = false;
@@ -67,7 +73,7 @@ struct vo_pipeline {
   volatile unsigned* h_seq = nullptr;
   unsigned* m_seq = nullptr;
   unsigned seq = 0;
-  struct flight_t { int prev_idx, next_idx, a, b, fcur, rslot; unsigned seq; };
+  struct flight_t { int prev_idx, next_idx, a, b, fcur, rslot; unsigned seq; long k; };
   flight_t flight[2];
   int n_flight = 0;
   long steps_submitted = 0;
@@ -78,6 +84,18 @@ struct vo_pipeline {
   double* d_newkp = nullptr;
   int32_t* d_pairs = nullptr;
   long n_recovered = 0;
+  // Detection worker: a second host thread enqueues the detection of every step (6 launches) while the caller's
+  // thread enqueues pyramid, tracker and the main-stream chain (7 launches): ~14 launches and half a dozen event
+  // calls per step cost one thread 70-150 us on a loaded host, more than the GPU needs for the step.
+  std::thread worker;
+  std::atomic<unsigned> job_posted{0}, job_done{0};
+  std::atomic<bool> quit{false};
+  struct job_t { flight_t f; bool pyramid, detection; };
+  job_t jobs[4];
+  int worker_rc = 0;
+  double dbg_part[4] = {0, 0, 0, 0};   // VO_DEBUG_TIMING: submit split into worker wait / tracker / raws / chain
+  double dbg_submit = 0, dbg_wait = 0;   // VO_DEBUG_TIMING: host seconds inside submit / waiting for records
+  long dbg_steps = 0;
 };
 
 namespace {
@@ -104,9 +122,21 @@ int dev_alloc(vo_ctx* ctx, T** p, size_t count) {
 
 template <typename T>
 int pin_alloc(vo_ctx* ctx, T** p, size_t count) {
-  hipError_t e = hipHostMalloc((void**)p, count * sizeof(T), hipHostMallocMapped);
+  hipError_t e = hipHostMalloc((void**)p, count * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
   if (e != hipSuccess) return vo_set_error(ctx, VO_ENOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
   return VO_OK;
+}
+
+// Blocking copies on the pipeline's own main stream: hipMemcpy would go through the null stream, one more stream
+// competing for the four hardware queues the pipeline's streams are spread over.
+hipError_t mcpy(hipStream_t st, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
+hipError_t mset(hipStream_t st, void* dst, int v, size_t bytes) {
+  hipError_t e = hipMemsetAsync(dst, v, bytes, st);
+  return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
 
 double now_s() {
@@ -145,6 +175,7 @@ vo_feat carve(char*& q, int cap) {
   f.land = (double*)take((size_t)cap * 24);
   f.track = (double*)take((size_t)cap * 16);
   f.pose = (double*)take((size_t)cap * 96);
+  f.pitch = cap;
   return f;
 }
 
@@ -155,7 +186,7 @@ size_t feat_bytes(int cap) {
 }
 
 void sync_prof(vo_pipeline* p) {
-  for (vo_ctx* q : {p->det[0], p->det[1], p->pyr}) {
+  for (vo_ctx* q : {p->det[0], p->trk}) {
     q->prof_on = p->ctx->prof_on;
     q->prof_kernel = p->ctx->prof_kernel;
     q->prof_every = p->ctx->prof_every;
@@ -163,6 +194,8 @@ void sync_prof(vo_pipeline* p) {
 }
 
 }  // namespace
+
+static void worker_main(vo_pipeline* p);
 
 extern "C" {
 
@@ -172,9 +205,13 @@ size_t vo_pyramid_bytes(int H, int W, int n_levels);
 void vo_pipeline_destroy(vo_pipeline* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
-  // every stream first: nothing may still read what is freed below
+  if (p->worker.joinable()) {          // the worker first: it enqueues on the side streams
+    p->quit.store(true, std::memory_order_release);
+    p->worker.join();
+  }
+  // every stream next: nothing may still read what is freed below
   (void)hipStreamSynchronize(p->ctx->stream);
-  for (vo_ctx* q : {p->det[0], p->det[1], p->pyr})
+  for (vo_ctx* q : {p->det[0], p->trk})
     if (q) (void)hipStreamSynchronize(q->stream);
   for (auto q : p->d_img)
     if (q) (void)hipFree(q);
@@ -187,12 +224,17 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   void* pin[] = {p->h_stage, p->h_res, (void*)p->h_seq};
   for (void* q : pin)
     if (q) (void)hipHostFree(q);
-  for (hipEvent_t e : {p->evPyr[0], p->evPyr[1], p->evPyr[2], p->evDet[0], p->evDet[1], p->evDet[2], p->evRaw, p->evA, p->evB})
+  for (hipEvent_t e : {p->evPyr[0], p->evPyr[1], p->evPyr[2], p->evDet[0], p->evDet[1], p->evDet[2], p->evRaw, p->evA, p->evB,
+                       p->evKlt[0], p->evKlt[1], p->evRegroup[0], p->evRegroup[1]})
     if (e) (void)hipEventDestroy(e);
-  for (vo_ctx* q : {p->det[0], p->det[1], p->pyr})
+  for (vo_ctx* q : {p->det[0], p->trk})
     if (q) vo_destroy(q);
-  if (p->n_recovered > 0 && getenv("VO_DEBUG_TIMING"))
-    fprintf(stderr, "[vo_pipeline] %ld step(s) finished through the host path\n", p->n_recovered);
+  if (getenv("VO_DEBUG_TIMING") && p->dbg_steps > 0)
+    fprintf(stderr, "[vo_pipeline] %ld steps: host %.1f us enqueueing (worker wait %.1f, tracker %.1f, raws %.1f, chain %.1f), "
+            "%.1f us waiting per step; %ld finished through the host path\n",
+            p->dbg_steps, 1e6 * p->dbg_submit / p->dbg_steps, 1e6 * p->dbg_part[0] / p->dbg_steps,
+            1e6 * p->dbg_part[1] / p->dbg_steps, 1e6 * p->dbg_part[2] / p->dbg_steps, 1e6 * p->dbg_part[3] / p->dbg_steps,
+            1e6 * p->dbg_wait / p->dbg_steps, p->n_recovered);
   delete p;
 }
 
@@ -228,9 +270,16 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     }
   }
   int rc = VO_OK;
-  if (vo_create(ctx->device, nullptr, &p->det[0]) != VO_OK || vo_create(ctx->device, nullptr, &p->det[1]) != VO_OK ||
-      vo_create(ctx->device, nullptr, &p->pyr) != VO_OK)
+  if (vo_create(ctx->device, nullptr, &p->det[0]) != VO_OK || vo_create(ctx->device, nullptr, &p->trk) != VO_OK)
     rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
+  // The next frame's pyramid is built on the tracker's stream, in front of the tracker that needs it: four streams
+  // in all (main, tracker, two detection streams), one hardware queue each -- with a fifth stream two of them share a
+  // queue and run in order, and which two depends on creation order (measured: 8.2k vs 5.1k frames/s run to run).
+  // ... and ONE detection stream: the runtime spreads streams over four hardware queues, the null stream (the
+  // caller's synchronous copies, torch) holds one of them, and kernels of one queue run in order -- with two
+  // detection streams the second shared a queue with the tracker and delayed it every other frame (rocprofv3 trace).
+  p->pyr = p->trk;
+  p->det[1] = p->det[0];
   const int N = cfg->n_keypoints, Hyp = cfg->hyp;
   const size_t px = (size_t)cfg->H * cfg->W;
   p->n_levels = vo_klt_num_levels(cfg->H, cfg->W, cfg->klt_win, cfg->klt_max_level);
@@ -293,19 +342,30 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
 #undef PA
   if (rc == VO_OK) {
     hipEvent_t* evs[] = {&p->evPyr[0], &p->evPyr[1], &p->evPyr[2], &p->evDet[0], &p->evDet[1], &p->evDet[2],
-                         &p->evRaw, &p->evA, &p->evB};
+                         &p->evRaw, &p->evA, &p->evB, &p->evKlt[0], &p->evKlt[1], &p->evRegroup[0], &p->evRegroup[1]};
     for (hipEvent_t* e : evs)
       if (rc == VO_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
         rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   }
-  if (rc == VO_OK && (hipMemcpy(p->d_table, p->table.data(), p->table.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-                      hipMemset(p->d_ctl, 0, sizeof(vo_seq_ctl)) != hipSuccess))
+  if (rc == VO_OK && (mcpy(p->ctx->stream, p->d_table, p->table.data(), p->table.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                      mset(p->ctx->stream, p->d_ctl, 0, sizeof(vo_seq_ctl)) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "pipeline: initial uploads failed");
   if (rc != VO_OK) {
     vo_pipeline_destroy(p);
     return rc;
   }
   memset(&p->rng, 0, sizeof(p->rng));
+  // First use in a fixed order -- main, tracker, detection: the runtime attaches a stream to a hardware queue when it
+  // first runs, and the three streams of the frame loop should end up on three different queues (kernels of one
+  // hardware queue execute in order: tracker and pose estimation sharing one serialises them).
+  {
+    hipStream_t order[3] = {ctx->stream, p->trk->stream, p->det[0]->stream};
+    for (hipStream_t q : order) {
+      (void)hipMemsetAsync(p->d_status, 0, 4, q);
+      (void)hipStreamSynchronize(q);
+    }
+  }
+  p->worker = std::thread(worker_main, p);
   *out = p;
   return VO_OK;
 }
@@ -339,7 +399,7 @@ int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
   p->raw_gen = *rng;
   // the device continues at the end of what has been generated so far; that look-ahead is dropped
   p->pos_known = p->gen_upto;
-  VO_HIP_TRY(p->ctx, hipMemcpy(&p->d_ctl->raw_pos, &p->gen_upto, 8, hipMemcpyHostToDevice));
+  VO_HIP_TRY(p->ctx, mcpy(p->ctx->stream, &p->d_ctl->raw_pos, &p->gen_upto, 8, hipMemcpyHostToDevice));
   p->seeded = true;
   return VO_OK;
 }
@@ -395,22 +455,63 @@ static int ensure_raws(vo_pipeline* p) {
   return VO_OK;
 }
 
-// the main-stream chain of one step; host_ransac: stop behind the regroup (recover_step continues)
-static int enqueue_main(vo_pipeline* p, const vo_pipeline::flight_t& f, bool first_half_only, int debug_fault_every) {
+static vo_pose_job make_pose_job(vo_pipeline* p, const vo_feat& B, int do_replay) {
+  const vo_pipeline_config& c = p->cfg;
+  vo_pose_job j;
+  j.ctl = p->d_ctl;
+  j.rp.valid = p->d_valid;
+  j.rp.counts = p->d_counts;
+  j.rp.R = p->d_R;
+  j.rp.t = p->d_t;
+  j.rp.masks = (const unsigned long long*)p->d_masks;
+  j.rp.words = p->words;
+  j.rp.hyp = c.hyp;
+  j.rp.table = p->d_table;
+  j.rp.table_len = p->table_len;
+  j.rp.max_it = c.ransac_max_iterations;
+  j.rp.best_mask = (unsigned long long*)p->d_best_mask;
+  j.do_replay = do_replay;
+  j.B = B;
+  j.cam = p->cam;
+  j.bearing_thr = c.bearing_threshold;
+  j.max_iter = c.refine_iters;
+  return j;
+}
+
+// tracker of one step, on its own stream: it needs the previous step's regroup (the features' positions) and this
+// frame's pyramid, nothing of the previous step's pose estimation, which runs beside it on the main stream
+static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool with_pyramid) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
-  const vo_feat A = p->F[f.fcur], B = p->F[1 - f.fcur];
-  if (hipEventQuery(p->evDet[f.a]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evDet[f.a], 0));
-  if (hipEventQuery(p->evPyr[f.b]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evPyr[f.b], 0));
+  const vo_feat A = p->F[f.fcur];
+  hipStream_t ts = p->trk->stream;
+  if (with_pyramid) VO_TRY(enqueue_pyramid(p, f.next_idx, f.b));
+  if (f.k > 0 && hipEventQuery(p->evRegroup[(f.k - 1) & 1]) != hipSuccess)
+    VO_HIP_TRY(ctx, hipStreamWaitEvent(ts, p->evRegroup[(f.k - 1) & 1], 0));
+  if (hipEventQuery(p->evDet[f.a]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ts, p->evDet[f.a], 0));
   vo_klt_source src;
-  src.n = &p->d_ctl->n;
+  src.n = &p->d_ctl->n2;             // (= n once the previous step has closed; known as soon as its regroup has run)
   src.num_features = &p->d_ctl->num_features;
   src.frac = c.redetect_fraction;
   src.det_kp = p->d_kp[f.a];
   src.n_det = c.n_keypoints;
-  VO_TRY(vo_klt_track_ndev(ctx, p->d_img[f.prev_idx], p->d_pyr[f.a], p->d_img[f.next_idx], p->d_pyr[f.b], c.H, c.W,
-                           p->n_levels, A.kp, p->cap, nullptr, c.klt_win, c.klt_max_iter, c.klt_eps, c.klt_min_eig,
-                           p->d_next, p->d_status, p->d_err, &src));
+  {
+    const int rc = vo_klt_track_ndev(p->trk, p->d_img[f.prev_idx], p->d_pyr[f.a], p->d_img[f.next_idx], p->d_pyr[f.b], c.H,
+                                     c.W, p->n_levels, A.kp, p->cap, nullptr, c.klt_win, c.klt_max_iter, c.klt_eps,
+                                     c.klt_min_eig, p->d_next, p->d_status, p->d_err, &src);
+    if (rc != VO_OK) return vo_set_error(ctx, rc, "tracker: %s", vo_last_error(p->trk));
+  }
+  VO_HIP_TRY(ctx, hipEventRecord(p->evKlt[f.k & 1], ts));
+  return VO_OK;
+}
+
+// the main-stream chain of one step (the tracker's event must have been recorded);
+// first_half_only: stop behind the regroup (recover_step continues on the host)
+static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool first_half_only, int debug_fault_every) {
+  vo_ctx* ctx = p->ctx;
+  const vo_pipeline_config& c = p->cfg;
+  const vo_feat A = p->F[f.fcur], B = p->F[1 - f.fcur];
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evKlt[f.k & 1], 0));
   vo_append ap;
   ap.det_kp = p->d_kp[f.a];
   ap.n_det = c.n_keypoints;
@@ -418,21 +519,53 @@ static int enqueue_main(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fir
   ap.pose_mode = c.redetect_start_pose;
   ap.debug_fault_every = debug_fault_every;
   VO_TRY(vo_state_regroup_klt(ctx, p->d_ctl, A, B, p->d_next, p->d_status, p->d_err, (float)c.klt_err_threshold, ap, p->cap));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], ctx->stream));
   if (first_half_only) return VO_OK;
   VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, B.land, B.kp64, &p->d_ctl->n_p3p, p->cap, c.K, p->d_raws, nullptr, 0u, c.hyp,
                                    c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks,
                                    (uint32_t*)&p->d_ctl->solve_flag, nullptr, nullptr, nullptr, &p->d_ctl->raw_pos,
                                    p->ring_len - 1));
-  VO_TRY(vo_state_ransac_replay(ctx, p->d_ctl, p->d_valid, p->d_counts, p->d_R, p->d_t, p->d_masks, p->words, c.hyp,
-                                p->d_table, p->table_len, c.ransac_max_iterations, p->d_best_mask));
-  if (c.refine_iters > 0)
-    VO_TRY(vo_refine_pose_ndev(ctx, B.land, B.kp64, p->cap, &p->d_ctl->n_p3p, c.K, nullptr, p->d_best_mask,
-                               p->d_ctl->best_pose, c.refine_iters, p->d_ctl->refined, 0u));
-  VO_TRY(vo_state_candidates(ctx, p->d_ctl, B, p->d_best_mask, p->cam, c.bearing_threshold, c.refine_iters > 0 ? 1 : 0,
-                             p->cap));
+  VO_TRY(vo_frame_pose(ctx, make_pose_job(p, B, 1)));
   VO_TRY(vo_state_landmarks(ctx, p->d_ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + f.rslot,
                             p->m_seq + f.rslot, f.seq));
   return VO_OK;
+}
+
+// ---- side-stream worker ----
+static void worker_main(vo_pipeline* p) {
+  (void)hipSetDevice(p->ctx->device);
+  unsigned seen = 0;
+  long idle = 0;
+  for (;;) {
+    if (p->job_posted.load(std::memory_order_acquire) == seen) {
+      if (p->quit.load(std::memory_order_acquire)) return;
+      if (++idle < 200000) __builtin_ia32_pause();            // a step is ~100 us: stay hot between steps
+      else std::this_thread::sleep_for(std::chrono::microseconds(200));
+      continue;
+    }
+    idle = 0;
+    const vo_pipeline::job_t j = p->jobs[seen & 3];
+    const int rc = enqueue_detection(p, j.f.next_idx, j.f.b);
+    if (rc != VO_OK) p->worker_rc = rc;
+    ++seen;
+    p->job_done.store(seen, std::memory_order_release);
+  }
+}
+
+static int worker_check(vo_pipeline* p) {
+  if (p->worker_rc != VO_OK) {
+    const int rc = p->worker_rc;
+    p->worker_rc = VO_OK;
+    return rc;                       // (the text is in the pipeline context's error buffer)
+  }
+  return VO_OK;
+}
+
+// waits (host) until the worker has enqueued everything it was given
+static int worker_idle(vo_pipeline* p) {
+  const unsigned posted = p->job_posted.load(std::memory_order_relaxed);
+  while (p->job_done.load(std::memory_order_acquire) != posted) __builtin_ia32_pause();
+  return worker_check(p);
 }
 
 int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, const uint8_t* state,
@@ -445,6 +578,7 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
   VO_REQUIRE(ctx, (n == 0 || (kp && state && landmarks && tracks && poses)) && T_wc && T_cw && T_wc_prev && T_cw_prev,
              "pipeline_set_state: null pointer");
   VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_set_state: %d submitted step(s) not collected", p->n_flight);
+  VO_TRY(worker_idle(p));
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -453,24 +587,27 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
   std::vector<float> kp32((size_t)n * 2);
   std::vector<uint8_t> zeros((size_t)n, 0);
   for (int i = 0; i < 2 * n; ++i) kp32[i] = (float)kp[i];
-  for (int i = 0; i < n; ++i) memcpy(&pose12[(size_t)12 * i], poses + (size_t)16 * i, 96);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 12; ++k) pose12[(size_t)k * n + i] = poses[(size_t)16 * i + k];   // component-major on the device
   if (n > 0) {
-    VO_HIP_TRY(ctx, hipMemcpy(F.kp, kp32.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, hipMemcpy(F.kp64, kp, (size_t)n * 16, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, hipMemcpy(F.state, state, (size_t)n, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, hipMemcpy(F.cand, zeros.data(), (size_t)n, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, hipMemcpy(F.land, landmarks, (size_t)n * 24, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, hipMemcpy(F.track, tracks, (size_t)n * 16, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, hipMemcpy(F.pose, pose12.data(), (size_t)n * 96, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.kp, kp32.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.kp64, kp, (size_t)n * 16, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.state, state, (size_t)n, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.cand, zeros.data(), (size_t)n, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.land, landmarks, (size_t)n * 24, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.track, tracks, (size_t)n * 16, hipMemcpyHostToDevice));
+    for (int k = 0; k < 12; ++k)
+      VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.pose + (size_t)k * F.pitch, &pose12[(size_t)k * n], (size_t)n * 8, hipMemcpyHostToDevice));
   }
   vo_seq_ctl h;
-  VO_HIP_TRY(ctx, hipMemcpy(&h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
   const uint64_t raw_pos = h.raw_pos;
   const int64_t n_it = h.n_iterations;
   const double orat = h.outlier_ratio;
   const bool keep_ransac = p->have_state;
   memset(&h, 0, sizeof(h));
   h.n = n;
+  h.n2 = n;
   h.num_features = num_features;
   h.raw_pos = raw_pos;
   if (keep_ransac) {
@@ -486,7 +623,7 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
   memcpy(h.T_cw, T_cw, 96);
   memcpy(h.T_wc_prev, T_wc_prev, 96);
   memcpy(h.T_cw_prev, T_cw_prev, 96);
-  VO_HIP_TRY(ctx, hipMemcpy(p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
   // pyramid and detector output of the frame the state belongs to
   p->slot = 0;
   sync_prof(p);
@@ -508,21 +645,26 @@ int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, double* kp, uint8_t* s
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   vo_seq_ctl h;
-  VO_HIP_TRY(ctx, hipMemcpy(&h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
   const int n = h.n;
   const vo_feat& F = p->F[p->cur];
   if (n_out) *n_out = n;
   if (num_features) *num_features = h.num_features;
   if (n > 0) {
-    if (kp) VO_HIP_TRY(ctx, hipMemcpy(kp, F.kp64, (size_t)n * 16, hipMemcpyDeviceToHost));
-    if (state) VO_HIP_TRY(ctx, hipMemcpy(state, F.state, (size_t)n, hipMemcpyDeviceToHost));
-    if (candidate_mask) VO_HIP_TRY(ctx, hipMemcpy(candidate_mask, F.cand, (size_t)n, hipMemcpyDeviceToHost));
-    if (landmarks) VO_HIP_TRY(ctx, hipMemcpy(landmarks, F.land, (size_t)n * 24, hipMemcpyDeviceToHost));
-    if (tracks) VO_HIP_TRY(ctx, hipMemcpy(tracks, F.track, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (kp) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, kp, F.kp64, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (state) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, state, F.state, (size_t)n, hipMemcpyDeviceToHost));
+    if (candidate_mask) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, candidate_mask, F.cand, (size_t)n, hipMemcpyDeviceToHost));
+    if (landmarks) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, landmarks, F.land, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (tracks) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, tracks, F.track, (size_t)n * 16, hipMemcpyDeviceToHost));
     if (poses) {
       std::vector<double> p12((size_t)n * 12);
-      VO_HIP_TRY(ctx, hipMemcpy(p12.data(), F.pose, (size_t)n * 96, hipMemcpyDeviceToHost));
-      for (int i = 0; i < n; ++i) expand_pose(&p12[(size_t)12 * i], poses + (size_t)16 * i);
+      for (int k = 0; k < 12; ++k)
+        VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &p12[(size_t)k * n], F.pose + (size_t)k * F.pitch, (size_t)n * 8, hipMemcpyDeviceToHost));
+      for (int i = 0; i < n; ++i) {
+        double row[12];
+        for (int k = 0; k < 12; ++k) row[k] = p12[(size_t)k * n + i];
+        expand_pose(row, poses + (size_t)16 * i);
+      }
     }
   }
   if (T_wc) expand_pose(h.T_wc, T_wc);
@@ -542,9 +684,10 @@ int vo_pipeline_get_detection(vo_pipeline* p, double* kp_xy) {
   if (!p || !kp_xy) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
   VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_get_detection: %d submitted step(s) not collected", p->n_flight);
+  VO_TRY(worker_idle(p));
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   VO_HIP_TRY(ctx, hipEventSynchronize(p->evDet[p->slot]));
-  VO_HIP_TRY(ctx, hipMemcpy(kp_xy, p->d_kp[p->slot], (size_t)p->cfg.n_keypoints * 16, hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, kp_xy, p->d_kp[p->slot], (size_t)p->cfg.n_keypoints * 16, hipMemcpyDeviceToHost));
   return VO_OK;
 }
 
@@ -558,6 +701,7 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
              prev_idx, p->prev_frame);
   VO_REQUIRE(ctx, p->n_flight < 2, "pipeline_submit: two steps are already in flight, collect one first");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const double t_in = now_s();
   vo_pipeline::flight_t f;
   f.prev_idx = prev_idx;
   f.next_idx = next_idx;
@@ -566,33 +710,62 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   f.fcur = p->cur;
   f.seq = ++p->seq;
   f.rslot = (int)(p->steps_submitted & 3);
+  f.k = p->steps_submitted;
   sync_prof(p);
-  // side streams first: the tracker needs the pyramid soonest
-  VO_TRY(enqueue_pyramid(p, next_idx, f.b));
-  VO_TRY(enqueue_detection(p, next_idx, f.b));
+  // The detection of `next` (half of the step's launches, needed only by the NEXT step) goes to the worker thread;
+  // this thread enqueues the pyramid, the tracker and the main-stream chain.  The tracker waits for the event behind
+  // the detection of `prev`: the worker must have recorded it (it was posted a whole step ago).
+  const unsigned my = p->job_posted.load(std::memory_order_relaxed);
+  double tq = now_s();
+  while ((int)(p->job_done.load(std::memory_order_acquire) - my) < 0) __builtin_ia32_pause();
+  VO_TRY(worker_check(p));
+  p->jobs[my & 3] = {f, false, true};
+  p->job_posted.store(my + 1, std::memory_order_release);
+  double tn = now_s();
+  p->dbg_part[0] += tn - tq;
+  tq = tn;
+  VO_TRY(enqueue_tracker(p, f, true));
+  tn = now_s();
+  p->dbg_part[1] += tn - tq;
+  tq = tn;
   VO_TRY(ensure_raws(p));
-  VO_TRY(enqueue_main(p, f, false, c.debug_fault_every));
+  tn = now_s();
+  p->dbg_part[2] += tn - tq;
+  tq = tn;
+  VO_TRY(enqueue_chain(p, f, false, c.debug_fault_every));
+  p->dbg_part[3] += now_s() - tq;
   p->flight[p->n_flight++] = f;
   ++p->steps_submitted;
   p->slot = f.b;
   p->cur = 1 - f.fcur;
   p->prev_frame = next_idx;
+  p->dbg_submit += now_s() - t_in;
+  ++p->dbg_steps;
   return VO_OK;
 }
 
-static int wait_record(vo_pipeline* p, int rslot, unsigned seq) {
+// Waits for the record of step `seq` in slot rslot and copies it out.  The kernel writes the record, fences at
+// system scope, then the sequence word; the record also carries the number at both ends and the generator position
+// can only grow, so a copy taken while some of the record's lines were still on their way (seen twice in ~40k
+// steps: the sequence word visible, a field behind it not yet) is recognised and taken again.
+static int wait_record(vo_pipeline* p, int rslot, unsigned seq, vo_step_result* out) {
   volatile unsigned* w = p->h_seq + rslot;
   const double t0 = now_s();
   long it = 0;
-  while (*w != seq) {
+  for (;;) {
+    if (*w == seq) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      memcpy(out, (const void*)(p->h_res + rslot), sizeof(*out));
+      if (out->seq_head == seq && out->seq_tail == seq && out->raw_pos >= p->pos_known_floor) return VO_OK;
+    }
     __builtin_ia32_pause();
     if ((++it & 0xffff) == 0 && now_s() - t0 > 5.0) {
       VO_HIP_TRY(p->ctx, hipStreamSynchronize(p->ctx->stream));
-      if (*w == seq) break;
+      memcpy(out, (const void*)(p->h_res + rslot), sizeof(*out));
+      if (*w == seq && out->seq_head == seq && out->seq_tail == seq) return VO_OK;
       return vo_set_error(p->ctx, VO_EHIP, "pipeline: the GPU never published the record of step %u", seq);
     }
   }
-  return VO_OK;
 }
 
 // The step of flight f raised a fault: nothing persistent was touched, so it is run again from its first
@@ -602,20 +775,23 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
   hipStream_t st = ctx->stream;
+  VO_TRY(worker_idle(p));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(p->trk->stream));
   vo_seq_ctl h;
-  VO_HIP_TRY(ctx, hipMemcpy(&h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
   if (h.fault & VO_FAULT_CAPACITY)
     return vo_set_error(ctx, VO_ECAPACITY, "pipeline: %d features + %d new keypoints exceed the capacity %d", h.n,
                         c.n_keypoints, p->cap);
   const int zero = 0;
-  VO_HIP_TRY(ctx, hipMemcpy(&p->d_ctl->fault, &zero, 4, hipMemcpyHostToDevice));
-  VO_TRY(enqueue_main(p, f, true, 0));
+  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &p->d_ctl->fault, &zero, 4, hipMemcpyHostToDevice));
+  VO_TRY(enqueue_tracker(p, f, false));
+  VO_TRY(enqueue_chain(p, f, true, 0));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
-  VO_HIP_TRY(ctx, hipMemcpy(&h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
   const int n = h.n_tri;
   if (n < 4) return vo_set_error(ctx, VO_ETRACKING, "pipeline: only %d triangulated tracks survive, no pose", n);
-  if (h.fault) VO_HIP_TRY(ctx, hipMemcpy(&p->d_ctl->fault, &zero, 4, hipMemcpyHostToDevice));   // (few landmarks)
+  if (h.fault) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &p->d_ctl->fault, &zero, 4, hipMemcpyHostToDevice));   // (few landmarks)
   const vo_feat B = p->F[1 - f.fcur];
   vo_ransac_state rs;
   rs.outlier_ratio = h.outlier_ratio;
@@ -649,9 +825,9 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
       // the winner so far lives in this batch: take its pose and mask row before the buffers are reused
       // (vo_p3p_hypotheses_dev packs mask rows with ceil(n / 64) words)
       const int local = best_idx - batches * c.hyp;
-      VO_HIP_TRY(ctx, hipMemcpy(best_pose, p->d_R + (size_t)local * 9, 72, hipMemcpyDeviceToHost));
-      VO_HIP_TRY(ctx, hipMemcpy(best_pose + 9, p->d_t + (size_t)local * 3, 24, hipMemcpyDeviceToHost));
-      VO_HIP_TRY(ctx, hipMemcpy(p->d_best_mask, p->d_masks + (size_t)local * vo_cdiv(n, 64), (size_t)vo_cdiv(n, 64) * 8,
+      VO_HIP_TRY(ctx, mcpy(p->ctx->stream, best_pose, p->d_R + (size_t)local * 9, 72, hipMemcpyDeviceToHost));
+      VO_HIP_TRY(ctx, mcpy(p->ctx->stream, best_pose + 9, p->d_t + (size_t)local * 3, 24, hipMemcpyDeviceToHost));
+      VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_best_mask, p->d_masks + (size_t)local * vo_cdiv(n, 64), (size_t)vo_cdiv(n, 64) * 8,
                                 hipMemcpyDeviceToDevice));
     }
     if (++batches > 64 && !finished)
@@ -677,17 +853,13 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
   h.n_done = n_done;
   h.n_cand = h.n_dropped = h.n_land = h.done = 0;
   memcpy(h.best_pose, best_pose, 96);
-  VO_HIP_TRY(ctx, hipMemcpy(p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
   const unsigned seq = ++p->seq;
-  if (c.refine_iters > 0)
-    VO_TRY(vo_refine_pose_ndev(ctx, B.land, B.kp64, p->cap, &p->d_ctl->n_p3p, c.K, nullptr, p->d_best_mask,
-                               p->d_ctl->best_pose, c.refine_iters, p->d_ctl->refined, 0u));
-  VO_TRY(vo_state_candidates(ctx, p->d_ctl, B, p->d_best_mask, p->cam, c.bearing_threshold, c.refine_iters > 0 ? 1 : 0,
-                             p->cap));
+  VO_TRY(vo_frame_pose(ctx, make_pose_job(p, B, 0)));
   VO_TRY(vo_state_landmarks(ctx, p->d_ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + f.rslot,
                             p->m_seq + f.rslot, seq));
-  VO_TRY(wait_record(p, f.rslot, seq));
-  *out = p->h_res[f.rslot];
+  p->pos_known_floor = 0;
+  VO_TRY(wait_record(p, f.rslot, seq, out));
   out->recovered = 1;
   ++p->n_recovered;
   return VO_OK;
@@ -699,8 +871,12 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
   VO_REQUIRE(ctx, p->n_flight > 0, "pipeline_collect: nothing submitted");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const vo_pipeline::flight_t f = p->flight[0];
-  VO_TRY(wait_record(p, f.rslot, f.seq));
-  *out = p->h_res[f.rslot];
+  {
+    const double t_in = now_s();
+    p->pos_known_floor = p->pos_known;
+    VO_TRY(wait_record(p, f.rslot, f.seq, out));
+    p->dbg_wait += now_s() - t_in;
+  }
   if (out->fault) {
     const int rc = recover_step(p, f, out);
     if (rc != VO_OK) {
@@ -715,7 +891,8 @@ int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
     for (int k = 0; k < p->n_flight; ++k) {
       p->flight[k].seq = ++p->seq;
       VO_TRY(ensure_raws(p));
-      VO_TRY(enqueue_main(p, p->flight[k], false, 0));
+      VO_TRY(enqueue_tracker(p, p->flight[k], false));
+      VO_TRY(enqueue_chain(p, p->flight[k], false, 0));
     }
   } else {
     // the estimator's generator follows the device: 7 outputs per consumed sample
@@ -756,16 +933,16 @@ int vo_pipeline_bookkeeping(vo_pipeline* p, int phases, const double* new_kp, in
     VO_HIP_TRY(ctx, hipStreamSynchronize(st));
     p->cur = 1 - p->cur;
     vo_seq_ctl h;
-    VO_HIP_TRY(ctx, hipMemcpy(&h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
     memcpy(h.T_in_wc, T_wc, 96);
     memcpy(h.T_in_cw, T_cw, 96);
     h.n_cand = h.n_dropped = h.n_land = h.done = 0;
-    VO_HIP_TRY(ctx, hipMemcpy(p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     std::vector<uint64_t> bits((size_t)p->words, ~0ull);
     if (p3p_inliers)
       for (int i = 0; i < h.n_tri; ++i)
         if (!p3p_inliers[i]) bits[i >> 6] &= ~(1ull << (i & 63));
-    VO_HIP_TRY(ctx, hipMemcpy(p->d_best_mask, bits.data(), bits.size() * 8, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_best_mask, bits.data(), bits.size() * 8, hipMemcpyHostToDevice));
   }
   if (phases & 1)
     VO_TRY(vo_state_candidates(ctx, p->d_ctl, p->F[p->cur], p->d_best_mask, p->cam, p->cfg.bearing_threshold, -1, p->cap));
@@ -816,9 +993,10 @@ int vo_pipeline_export_state_join(vo_pipeline* p, void* consumer) {
 // per-kernel event times accumulated over all of the pipeline's streams
 int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64_t* launches) {
   if (!p) return VO_EINVAL;
+  VO_TRY(worker_idle(p));
   double sum = 0;
   int64_t n = 0;
-  for (vo_ctx* q : {p->ctx, p->det[0], p->det[1], p->pyr}) {
+  for (vo_ctx* q : {p->ctx, p->det[0], p->trk}) {
     double ms = 0;
     int64_t k = 0;
     const int rc = vo_prof_read(q, kernel_id, &ms, &k);
@@ -833,7 +1011,8 @@ int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64
 
 int vo_pipeline_prof_reset(vo_pipeline* p) {
   if (!p) return VO_EINVAL;
-  for (vo_ctx* q : {p->ctx, p->det[0], p->det[1], p->pyr}) VO_TRY(vo_prof_reset(q));
+  VO_TRY(worker_idle(p));
+  for (vo_ctx* q : {p->ctx, p->det[0], p->trk}) VO_TRY(vo_prof_reset(q));
   return VO_OK;
 }
 

@@ -12,7 +12,7 @@
 // accumulates their 21 + 6 + 1 terms once per iteration; a wave adds its lanes' terms with a
 // halving butterfly (32 shuffles for all 28 sums), wave 0 adds the eight wave totals, solves the
 // 6x6 system with one lane per row and applies the update; all fp64, two barriers per iteration.
-#include "vo_internal.h"
+#include "state_device.h"
 
 #pragma clang fp contract(off)
 
@@ -185,38 +185,23 @@ __device__ __forceinline__ void rodrigues_coefficients(double th2, double* a, do
   }
 }
 
-// Rt0: R (9, row-major) then t (3).  out: R (9), t (3), iterations, cost (14 doubles).
-// Two barriers per iteration: every wave adds up its points for the trial pose and leaves 28 wave totals
-// in LDS; wave 0 alone then adds those, accepts or rejects the trial, solves for the next step and
-// writes the next trial pose while the other waves wait.
-__global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restrict__ X, const double* __restrict__ x, int N,
-                                                           const int* __restrict__ d_n,
-                                                           const uint8_t* __restrict__ mask8,
-                                                           const unsigned long long* __restrict__ mask_bits,
-                                                           const double* __restrict__ Rt0, double fx, double fy, double cx,
-                                                           double cy, int max_iter, double tol, double* __restrict__ out,
-                                                           unsigned tag) {
-  __shared__ double s_w[RF_T / 64][RF_S];
-  __shared__ double s_pose[12], s_try[12];
-  __shared__ int s_state;   // 0 run the next trial, 1 finished (s_pose holds the result)
+// Gauss-Newton on the pose in s_pose (s_try = the trial pose, both 12 doubles of LDS, initialised by the caller,
+// s_state = 0), all RF_T threads.  Two barriers per iteration: every wave adds up its points for the trial pose
+// and leaves 28 wave totals in LDS; wave 0 alone then adds those, accepts or rejects the trial, solves for the
+// next step and writes the next trial pose while the other waves wait.  On return s_pose holds the result;
+// *it_out / *cost_out are valid in wave 0.
+__device__ __forceinline__ void gauss_newton(const rf_point* cache, const double* __restrict__ X,
+                                             const double* __restrict__ x, int N, const uint8_t* __restrict__ mask8,
+                                             const unsigned long long* __restrict__ mask_bits, double fx, double fy,
+                                             double cx, double cy, int max_iter, double tol, double (*s_w)[RF_S],
+                                             double* s_pose, double* s_try, int* s_state, int* it_out,
+                                             double* cost_out) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (d_n) N = min(N, *d_n);
-  if (threadIdx.x < 12) {
-    const double v = Rt0[threadIdx.x];
-    s_pose[threadIdx.x] = v;
-    s_try[threadIdx.x] = v;
-  }
-  if (threadIdx.x == 0) s_state = 0;
-  // the thread's points stay in registers for every iteration (all loads go out together, once)
-  rf_point cache[RF_PT];
-#pragma unroll
-  for (int k = 0; k < RF_PT; ++k) cache[k] = load_point(X, x, N, mask8, mask_bits, k * RF_T + threadIdx.x);
-  // wave 0's bookkeeping (uniform across its lanes)
   int it = -1;              // -1: the first pass evaluates the starting pose
   double cost = 0.0;
   for (;;) {
     __syncthreads();
-    if (s_state != 0) break;
+    if (*s_state != 0) break;
     double s[RF_S];
     accumulate(cache, X, x, N, mask8, mask_bits, s_try, s_try + 9, fx, fy, cx, cy, s);
     const double wsum = wave_sums(s, lane);
@@ -284,8 +269,38 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
         if (dn <= tol * (1.0 + tn)) stop = true;   // converged: a step this small is not taken (nor evaluated)
       }
     }
-    if (stop && lane == 0) s_state = 1;
+    if (stop && lane == 0) *s_state = 1;
   }
+  *it_out = it;
+  *cost_out = cost;
+}
+
+// Rt0: R (9, row-major) then t (3).  out: R (9), t (3), iterations, cost (14 doubles).
+__global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restrict__ X, const double* __restrict__ x, int N,
+                                                           const int* __restrict__ d_n,
+                                                           const uint8_t* __restrict__ mask8,
+                                                           const unsigned long long* __restrict__ mask_bits,
+                                                           const double* __restrict__ Rt0, double fx, double fy, double cx,
+                                                           double cy, int max_iter, double tol, double* __restrict__ out,
+                                                           unsigned tag) {
+  __shared__ double s_w[RF_T / 64][RF_S];
+  __shared__ double s_pose[12], s_try[12];
+  __shared__ int s_state;   // 0 run the next trial, 1 finished (s_pose holds the result)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (d_n) N = min(N, *d_n);
+  if (threadIdx.x < 12) {
+    const double v = Rt0[threadIdx.x];
+    s_pose[threadIdx.x] = v;
+    s_try[threadIdx.x] = v;
+  }
+  if (threadIdx.x == 0) s_state = 0;
+  // the thread's points stay in registers for every iteration (all loads go out together, once)
+  rf_point cache[RF_PT];
+#pragma unroll
+  for (int k = 0; k < RF_PT; ++k) cache[k] = load_point(X, x, N, mask8, mask_bits, k * RF_T + threadIdx.x);
+  int it;
+  double cost;
+  gauss_newton(cache, X, x, N, mask8, mask_bits, fx, fy, cx, cy, max_iter, tol, s_w, s_pose, s_try, &s_state, &it, &cost);
   if (wv == 0) {
     if (lane < 12) out[lane] = s_pose[lane];
     if (lane == 0) {
@@ -298,6 +313,92 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
         __hip_atomic_store(&out[14], (double)tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
+  }
+}
+
+// The frame loop's pose kernel (vo_pose_job): one workgroup.
+//   1. wave 0 replays the sequential RANSAC rule over the scored hypotheses (ransac.py:90-121, state_device.h)
+//      while the other waves already fetch the population's coordinates;
+//   2. all waves refine the accepted pose over its inliers (p3p.py:188-213), as refine_pose_kernel does;
+//   3. all threads walk the new frame's features: pose, outliers, bearing-angle candidates (main.py:261-268).
+__global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
+  using namespace vo_state_dev;
+  __shared__ double s_table[RP_TABLE_LDS];
+  __shared__ double s_w[RF_T / 64][RF_S];
+  __shared__ double s_pose[12], s_try[12];
+  __shared__ int s_state, s_cand[RF_T / 64];
+  vo_seq_ctl* ctl = job.ctl;
+  if (ctl->fault) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double* X = job.B.land;
+  const double* x = job.B.kp64;
+  const int cap = job.B.pitch;
+  const bool lds_table = job.do_replay && job.rp.table_len + 1 <= RP_TABLE_LDS;
+  if (lds_table)
+    for (int k = tid; k < job.rp.table_len + 1; k += RF_T) s_table[k] = job.rp.table[k];
+  // coordinates first (the population's size and the inlier mask are known only after the replay)
+  rf_point cache[RF_PT];
+#pragma unroll
+  for (int k = 0; k < RF_PT; ++k) cache[k] = load_point(X, x, cap, nullptr, nullptr, k * RF_T + tid);
+  if (tid == 0) s_state = 0;
+  __syncthreads();
+  if (job.do_replay && wv == 0) replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table);
+  __syncthreads();
+  if (ctl->fault) return;                       // (raised by the replay: the host finishes this step)
+  const int N = min(ctl->n_p3p, cap);
+  const unsigned long long* mask_bits = job.rp.best_mask;
+#pragma unroll
+  for (int k = 0; k < RF_PT; ++k) {
+    const int i = k * RF_T + tid;
+    cache[k].on = i < N && ((mask_bits[min(i, cap - 1) >> 6] >> (i & 63)) & 1ull) != 0;
+  }
+  if (tid < 12) {
+    const double v = ctl->best_pose[tid];
+    s_pose[tid] = v;
+    s_try[tid] = v;
+  }
+  int it;
+  double cost;
+  gauss_newton(cache, X, x, N, nullptr, mask_bits, job.cam.K[0], job.cam.K[4], job.cam.K[2], job.cam.K[5], job.max_iter,
+               1e-9, s_w, s_pose, s_try, &s_state, &it, &cost);
+  if (wv == 0) {
+    if (lane < 12) ctl->refined[lane] = s_pose[lane];
+    if (lane == 0) {
+      ctl->refined[12] = (double)(it < 0 ? 0 : it);
+      ctl->refined[13] = cost;
+    }
+  }
+  // ---- the new pose, both ways (update_with_world_pose, state.py:38-50), then every feature ----
+  double Tcw[12], Twc[12];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Tcw[4 * r] = s_pose[3 * r];
+    Tcw[4 * r + 1] = s_pose[3 * r + 1];
+    Tcw[4 * r + 2] = s_pose[3 * r + 2];
+    Tcw[4 * r + 3] = s_pose[9 + r];
+  }
+  rigid_inverse_3x4(Tcw, Twc);
+  const int n2 = ctl->n2, n_tri = ctl->n_tri;
+  int count = 0;
+  for (int i = tid; i < n2; i += RF_T) count += candidate_feature(job.B, i, n_tri, mask_bits, job.cam, Twc, job.bearing_thr);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off);
+  if (lane == 0) s_cand[wv] = count;
+  __syncthreads();
+  if (tid == 0) {
+    int total = 0;
+    for (int w = 0; w < RF_T / 64; ++w) total += s_cand[w];
+    ctl->n_cand = total;
+    ctl->n = n2;                                 // the new frame is the current one from here on
+  }
+  if (tid < 12) {
+    double ncw = 0.0, nwc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      ncw = tid == k ? Tcw[k] : ncw;
+      nwc = tid == k ? Twc[k] : nwc;
+    }
+    commit_pose(ctl, tid, ncw, nwc);
   }
 }
 
@@ -320,6 +421,17 @@ int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N
                        (const unsigned long long*)d_mask_bits, d_Rt0, K[0], K[4], K[2], K[5], max_iter, 1e-9, d_out14, tag);
   }
   return vo_check_launch(ctx, "refine_pose_kernel");
+}
+
+int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, job.ctl && job.B.land && job.B.kp64 && job.rp.best_mask, "frame_pose: null pointer");
+  VO_REQUIRE(ctx, job.max_iter >= 0 && job.max_iter <= 100, "frame_pose: bad iteration limit");
+  {
+    vo_prof_scope ps(ctx, VO_K_REFINE);
+    hipLaunchKernelGGL(frame_pose_kernel, dim3(1), dim3(RF_T), 0, ctx->stream, job);
+  }
+  return vo_check_launch(ctx, "frame_pose_kernel");
 }
 
 extern "C" {

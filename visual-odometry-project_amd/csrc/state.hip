@@ -15,7 +15,7 @@
 #include <cmath>
 
 #include "dlt_device.h"
-#include "vo_state.h"
+#include "state_device.h"
 
 #pragma clang fp contract(off)
 
@@ -24,7 +24,7 @@ namespace {
 constexpr int RG_T = 1024;   // regroup: threads
 
 
-__device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000ll); }
+using namespace vo_state_dev;
 
 // ---------------------------------------------------------------------------------------------
 // Block-wide exclusive scan of three counters packed into one 64-bit word (21 bits each).
@@ -72,7 +72,7 @@ __device__ __forceinline__ void write_group(const vo_feat& A, const vo_feat& B, 
     B.land[3 * dst + 2] = A.land[3 * src + 2];
     B.track[2 * dst] = B.track[2 * dst + 1] = nan;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) B.pose[12 * dst + k] = nan;
+    for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + dst] = nan;
   } else {
     B.state[dst] = 1;
     B.land[3 * dst] = B.land[3 * dst + 1] = B.land[3 * dst + 2] = nan;
@@ -84,7 +84,7 @@ __device__ __forceinline__ void write_group(const vo_feat& A, const vo_feat& B, 
       B.track[2 * dst + 1] = A.kp64[2 * src + 1];
     }
 #pragma unroll
-    for (int k = 0; k < 12; ++k) B.pose[12 * dst + k] = A.pose[12 * src + k];
+    for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + dst] = A.pose[(size_t)k * A.pitch + src];
   }
 }
 
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
       B.track[2 * p] = x;
       B.track[2 * p + 1] = y;
 #pragma unroll
-      for (int q = 0; q < 12; ++q) B.pose[12 * p + q] = nan;
+      for (int q = 0; q < 12; ++q) B.pose[(size_t)q * B.pitch + p] = nan;
       ++p;
     }
     n2 += (int)tot2;
@@ -188,39 +188,6 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
     ctl->n_p3p = fault ? 0 : T0;
     if (fault) ctl->fault = fault;
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// n_iterations for an outlier ratio: k_min + #{thresholds <= ratio}; table[0] = k_min, table[1..len] thresholds
-// (pipeline.hip builds it from the host's libm by bisection, so the device needs neither log nor pow and
-// returns exactly what ransac.py:58-67 returns on the host).
-__host__ __device__ inline long long table_lookup(const double* table, int len, long long max_it, double orat) {
-  int lo = 0, hi = len;                 // number of thresholds <= orat
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (table[1 + mid] <= orat) lo = mid + 1;
-    else hi = mid;
-  }
-  long long k = lo == len ? 0x7fffffffffffffffll : (long long)table[0] + lo;
-  return (max_it >= 0 && max_it < k) ? max_it : k;
-}
-
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rigid_inverse_3x4(const double* T, double* Ti) {
-  // [R t] -> [R^T  -R^T t]
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Ti[4 * r + c] = T[4 * c + r];
-    Ti[4 * r + 3] = -(T[r] * T[3] + T[4 + r] * T[7] + T[8 + r] * T[11]);
-  }
-}
-
-__device__ __forceinline__ void k_times(const double* K, const double* T, double* C) {
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) C[4 * r + c] = K[3 * r] * T[c] + K[3 * r + 1] * T[4 + c] + K[3 * r + 2] * T[8 + c];
 }
 
 
@@ -260,13 +227,19 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
   const int start = blockIdx.x * 256;
   if (start >= n_in && blockIdx.x != 0) return;
   auto key_of = [&](int j) -> int {      // 0 triangulated, 1 matched, 2 newly matched, 3 dropped
-    if (j >= n_in) return 3;
-    const bool keep = status[j] != 0 && err[j] < err_thr;
-    const int st = j < n ? (int)A.state[j] : 0;
+    // (unconditional loads at clamped indices, no short-circuit: the three requests of an item, and those of the
+    //  following items, go out together instead of one dependent round trip after the other)
+    const int jc = min(j, n_in - 1), js = min(j, max(n - 1, 0));
+    const int s8 = status[jc];
+    const float e = err[jc];
+    const int st_raw = A.state[js];
+    const int keep = (int)(j < n_in) & (int)(s8 != 0) & (int)(e < err_thr);
+    const int st = j < n ? st_raw : 0;
     return keep ? (st == 2 ? 0 : (st == 1 ? 1 : 2)) : 3;
   };
   unsigned long long c_all = 0ull, c_before = 0ull;
   int my_key = 3;
+#pragma unroll 4
   for (int base = 0; base < n_in; base += 256) {
     const int j = base + tid;
     const int key = key_of(j);
@@ -320,7 +293,7 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
       B.track[2 * dst + 1] = (double)(float)ap.det_kp[2 * d + 1];
 #pragma unroll
       for (int k = 0; k < 12; ++k)   // np.eye(4) (klt.py:148-153), or the pose of the frame the keypoints were found on
-        B.pose[12 * dst + k] = ap.pose_mode ? ctl->T_wc[k] : ((k == 0 || k == 5 || k == 10) ? 1.0 : 0.0);
+        B.pose[(size_t)k * B.pitch + dst] = ap.pose_mode ? ctl->T_wc[k] : ((k == 0 || k == 5 || k == 10) ? 1.0 : 0.0);
     }
   }
   if (blockIdx.x == 0 && tid == 0) {
@@ -337,138 +310,8 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// One wave walks the batch of hypotheses through the reference's loop (ransac.py:90-121):
-//     while n < n_iterations: draw; model None -> continue; count; strictly better -> keep, adapt; n += 1
-// 64 hypotheses per round: a prefix maximum finds the hypotheses that improve on everything before them,
-// and between two such events n_iterations is constant, so the place where the loop ends is a ballot.
-// The flags and counts of 16 rounds are requested together, the threshold table sits in LDS.
-constexpr int RP_TABLE_LDS = 4097;
-__global__ __launch_bounds__(64) void ransac_replay_kernel(vo_seq_ctl* __restrict__ ctl,
-                                                           const uint8_t* __restrict__ valid,
-                                                           const int* __restrict__ counts,
-                                                           const double* __restrict__ Rall,
-                                                           const double* __restrict__ tall,
-                                                           const unsigned long long* __restrict__ masks, int words,
-                                                           int hyp, const double* __restrict__ table, int table_len,
-                                                           long long max_it,
-                                                           unsigned long long* __restrict__ best_mask) {
-  __shared__ double s_table[RP_TABLE_LDS];
-  if (ctl->fault) return;
-  const int lane = threadIdx.x;
-  if (lane == 0) {            // counters the bookkeeping kernels of this step add to
-    ctl->n_cand = 0;
-    ctl->n_dropped = 0;
-    ctl->n_land = 0;
-    ctl->done = 0;
-  }
-  const bool lds_table = table_len + 1 <= RP_TABLE_LDS;
-  if (lds_table)
-    for (int k = lane; k < table_len + 1; k += 64) s_table[k] = table[k];
-  const double* tb = lds_table ? s_table : table;
-  const int N = ctl->n_p3p;
-  long long n_it = ctl->n_iterations;
-  double orat = ctl->outlier_ratio;
-  long long n = 0;
-  int best = -1, best_idx = -1, consumed = -1, hyp_valid = 0;
-  bool risky_seen = false;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  __syncthreads();
-  for (int sbase = 0; sbase < hyp; sbase += 1024) {
-    int vbs[16], cs[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int h = min(sbase + 64 * q + lane, hyp - 1);
-      vbs[q] = valid[h];
-      cs[q] = counts[h];
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int base = sbase + 64 * q;
-      if (base >= hyp) break;
-      const int h = base + lane;
-      const int vb = h < hyp ? vbs[q] : 0;
-      const bool v = (vb & 1) != 0;
-      const unsigned long long vmask = __ballot(v);
-      hyp_valid += __popcll(vmask);
-      if (consumed >= 0) continue;                // (the loop has ended; only the statistics go on)
-      const int c = v ? cs[q] : -1;
-      const unsigned long long rmask = __ballot((vb & 2) != 0);
-      int pm = c;                                   // inclusive prefix maximum
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(pm, off);
-        if (lane >= off) pm = max(pm, o);
-      }
-      int epm = __shfl_up(pm, 1);
-      if (lane == 0) epm = -1;
-      epm = max(epm, best);
-      const unsigned long long imask = __ballot(v && c > epm);
-      const long long n_here = n + __popcll(vmask & lt);       // iterations counted before this lane's draw
-      int cur = 0;
-      for (;;) {
-        const unsigned long long ge = cur >= 64 ? 0ull : ~((1ull << cur) - 1ull);
-        const unsigned long long smask = __ballot(n_here >= n_it) & ge;   // the `while` test fails before this draw
-        const unsigned long long emask = imask & ge;
-        const int sp = smask ? __ffsll((long long)smask) - 1 : 64;
-        const int ep = emask ? __ffsll((long long)emask) - 1 : 64;
-        if (sp <= ep && sp < 64) {
-          consumed = base + sp;
-          n = __shfl(n_here, sp);
-          risky_seen |= (rmask & ((1ull << sp) - 1ull)) != 0ull;
-          break;
-        }
-        if (ep == 64) {
-          n += __popcll(vmask);
-          risky_seen |= rmask != 0ull;
-          break;
-        }
-        best = __shfl(c, ep);
-        best_idx = base + ep;
-        {   // ransac.py:113-120
-          double o = 1.0 - (double)best / (double)N;
-          o = fmin(fmax(o, 0.01), 0.99);
-          orat = o;
-          n_it = table_lookup(tb, table_len, max_it, o);
-        }
-        cur = ep + 1;
-      }
-    }
-  }
-  int fault = 0;
-  if (consumed < 0) {
-    if (n >= n_it) consumed = hyp;                // the loop ends exactly behind the last sample of the batch
-    else fault |= VO_FAULT_UNFINISHED;            // (also: no hypothesis had a solution)
-  }
-  if (risky_seen) fault |= VO_FAULT_RISKY_DRAW;
-  if (!fault && best_idx < 0) fault |= VO_FAULT_UNFINISHED;
-  if (fault) {
-    if (lane == 0) {
-      ctl->fault = fault;
-      ctl->n_p3p = 0;
-    }
-    return;
-  }
-  if (lane < 9) ctl->best_pose[lane] = Rall[9 * best_idx + lane];
-  if (lane < 3) ctl->best_pose[9 + lane] = tall[3 * best_idx + lane];
-  const int wn = (N + 63) >> 6;
-  for (int w = lane; w < wn; w += 64) best_mask[w] = masks[(size_t)best_idx * words + w];
-  if (lane == 0) {
-    ctl->n_iterations = n_it;
-    ctl->outlier_ratio = orat;
-    ctl->raw_pos += 7ull * (unsigned long long)consumed;
-    ctl->best_idx = best_idx;
-    ctl->best_count = best;
-    ctl->consumed = consumed;
-    ctl->hyp_valid = hyp_valid;
-    ctl->n_done = n;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// main.py:261-268 on the new frame's features, one feature per work item:
-//   outliers[triangulate_inliers] = ~inliers; update_from_matches + update_with_world_pose (state.py:17-50);
-//   reset_outliers (state.py:162-172); compute_candidates (state.py:135-160, 174-219: bearing angle between the
-//   rays through the track's first and last keypoint >= threshold, among state == 1).
+// main.py:261-268 as a kernel of its own (vo_pipeline_bookkeeping and the host recovery path; inside the frame loop
+// the same per-feature function runs at the end of the pose kernel, refine.hip).
 // use_refined: 1 the refinement's pose, 0 the accepted hypothesis, -1 the pose the host put into ctl->T_in_*.
 __global__ __launch_bounds__(256) void state_candidates_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat B,
                                                                const unsigned long long* __restrict__ best_mask,
@@ -495,58 +338,18 @@ __global__ __launch_bounds__(256) void state_candidates_kernel(vo_seq_ctl* __res
     rigid_inverse_3x4(Tcw, Twc);
   }
   const int i = blockIdx.x * 256 + tid;
-  int cand = 0;
-  if (i < n2) {
-    int st = B.state[i];
-    const int st0 = st;
-    const double u = B.kp64[2 * i], v = B.kp64[2 * i + 1];
-    bool reset = st == 0;                                     // set_pose_for_new_tracks (features.py:224-237)
-    if (i < n_tri && !((best_mask[i >> 6] >> (i & 63)) & 1ull)) {   // P3P outlier (main.py:261-262)
-      st = 0;
-      reset = true;
-    }
-    if (reset) {
-      if (st0 != 0) {                                         // reset_outliers (state.py:162-172)
-        B.track[2 * i] = u;
-        B.track[2 * i + 1] = v;
-        B.state[i] = 0;
-      }
-#pragma unroll
-      for (int k = 0; k < 12; ++k) B.pose[12 * i + k] = Twc[k];
-    } else if (st == 1) {
-      const double* P = B.pose + 12 * i;
-      const double a = B.track[2 * i], b = B.track[2 * i + 1];
-      const double* Ki = cam.Kinv;
-      const double n1x = Ki[0] * a + Ki[1] * b + Ki[2], n1y = Ki[3] * a + Ki[4] * b + Ki[5],
-                   n1z = Ki[6] * a + Ki[7] * b + Ki[8];
-      const double n2x = Ki[0] * u + Ki[1] * v + Ki[2], n2y = Ki[3] * u + Ki[4] * v + Ki[5],
-                   n2z = Ki[6] * u + Ki[7] * v + Ki[8];
-      const double r1x = P[0] * n1x + P[1] * n1y + P[2] * n1z, r1y = P[4] * n1x + P[5] * n1y + P[6] * n1z,
-                   r1z = P[8] * n1x + P[9] * n1y + P[10] * n1z;
-      const double r2x = Twc[0] * n2x + Twc[1] * n2y + Twc[2] * n2z, r2y = Twc[4] * n2x + Twc[5] * n2y + Twc[6] * n2z,
-                   r2z = Twc[8] * n2x + Twc[9] * n2y + Twc[10] * n2z;
-      const double dot = r1x * r2x + r1y * r2y + r1z * r2z;
-      const double l1 = sqrt(r1x * r1x + r1y * r1y + r1z * r1z), l2 = sqrt(r2x * r2x + r2y * r2y + r2z * r2z);
-      const double ang = acos(dot / (l1 * l2));
-      cand = ang >= bearing_thr ? 1 : 0;                      // (NaN compares false, as in NumPy)
-    }
-    B.cand[i] = (uint8_t)cand;
-  }
+  const int cand = i < n2 ? candidate_feature(B, i, n_tri, best_mask, cam, Twc, bearing_thr) : 0;
   const unsigned long long cm = __ballot(cand != 0);
   if ((tid & 63) == 0 && cm) atomicAdd(&ctl->n_cand, __popcll(cm));
   if (blockIdx.x == 0) {
-    if (tid < 12) {          // update_from_matches (state.py:17-22): what was current becomes previous
-      const double ocw = ctl->T_cw[tid], owc = ctl->T_wc[tid];
+    if (tid < 12) {
       double ncw = 0.0, nwc = 0.0;
 #pragma unroll
       for (int k = 0; k < 12; ++k) {
         ncw = tid == k ? Tcw[k] : ncw;
         nwc = tid == k ? Twc[k] : nwc;
       }
-      ctl->T_cw_prev[tid] = ocw;
-      ctl->T_wc_prev[tid] = owc;
-      ctl->T_cw[tid] = ncw;
-      ctl->T_wc[tid] = nwc;
+      commit_pose(ctl, tid, ncw, nwc);
     }
     if (tid == 0) ctl->n = n2;       // the new frame is the current one from here on
   }
@@ -564,11 +367,13 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
   const int fault = ctl->fault;
   if (fault) {
     if (res && blockIdx.x == 0 && tid == 0) {
+      res->seq_head = seq;
       res->fault = fault;
       res->n_features_in = ctl->n_in;
       res->n_tracked = ctl->n2;
       res->n_triangulated = ctl->n_tri;
       res->raw_pos = ctl->raw_pos;
+      res->seq_tail = seq;
       __threadfence_system();
       *seq_word = seq;
     }
@@ -593,7 +398,7 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
       // proj1 = K inv(pose_start)[:3], proj2 = K inv(current_pose)[:3] (triangulation.py:53-57)
       double Ts[12], Ti[12], C1[12], C2[12];
 #pragma unroll
-      for (int q = 0; q < 12; ++q) Ts[q] = B.pose[12 * i + q];
+      for (int q = 0; q < 12; ++q) Ts[q] = B.pose[(size_t)q * B.pitch + i];
       rigid_inverse_3x4(Ts, Ti);
       k_times(cam.K, Ti, C1);
       k_times(cam.K, Tcw, C2);
@@ -615,7 +420,7 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
         B.track[2 * i] = B.kp64[2 * i];
         B.track[2 * i + 1] = B.kp64[2 * i + 1];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) B.pose[12 * i + k] = Twc[k];
+        for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + i] = Twc[k];
         dropped = 1;
       }
     }
@@ -651,6 +456,7 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
   }
   if (tid < 12) res->T_wc[tid] = ctl->T_wc[tid];
   if (tid == 0) {
+    res->seq_head = seq;
     res->n_tracked = n2;
     res->n_inliers = ctl->best_count;
     res->best_index = ctl->best_idx;
@@ -672,6 +478,7 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
   __threadfence_system();
   __syncthreads();
   if (tid == 0) {
+    res->seq_tail = seq;
     __threadfence_system();
     *seq_word = seq;
   }
@@ -700,18 +507,6 @@ int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, c
   return vo_check_launch(ctx, "state_regroup_kernel");
 }
 
-int vo_state_ransac_replay(vo_ctx* ctx, vo_seq_ctl* ctl, const uint8_t* d_valid, const int32_t* d_counts,
-                           const double* d_R, const double* d_t, const uint64_t* d_masks, int words, int hyp,
-                           const double* d_thr_table, int table_len, int64_t max_iterations, uint64_t* d_best_mask) {
-  {
-    vo_prof_scope ps(ctx, VO_K_RANSAC_REPLAY);
-    hipLaunchKernelGGL(ransac_replay_kernel, dim3(1), dim3(64), 0, ctx->stream, ctl, d_valid, d_counts, d_R, d_t,
-                       (const unsigned long long*)d_masks, words, hyp, d_thr_table, table_len, (long long)max_iterations,
-                       (unsigned long long*)d_best_mask);
-  }
-  return vo_check_launch(ctx, "ransac_replay_kernel");
-}
-
 int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
                         double bearing_thr, int use_refined, int cap) {
   {
@@ -733,7 +528,7 @@ int vo_state_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, vo_cam cam, int 
 }
 
 int64_t vo_ransac_table_lookup(const double* table, int table_len, int64_t max_iterations, double outlier_ratio) {
-  return (int64_t)table_lookup(table, table_len, (long long)max_iterations, outlier_ratio);
+  return (int64_t)vo_state_dev::table_lookup(table, table_len, (long long)max_iterations, outlier_ratio);
 }
 
 // table[0] = f(0.01) (the clip's lower end), table[1 + j] = smallest outlier ratio in [0.01, 0.99] with

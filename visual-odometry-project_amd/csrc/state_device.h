@@ -1,0 +1,219 @@
+// Device functions of the frame state shared by state.hip (stand-alone kernels) and refine.hip (the frame
+// loop's pose kernel, which runs the RANSAC replay in front of the refinement and the candidate selection
+// behind it so that three launches of the dependent chain become one).
+#pragma once
+#include "vo_state.h"
+
+#pragma clang fp contract(off)
+
+namespace vo_state_dev {
+
+__device__ __forceinline__ double dnan() { return __longlong_as_double(0x7ff8000000000000ll); }
+
+__device__ __forceinline__ void rigid_inverse_3x4(const double* T, double* Ti) {
+  // [R t] -> [R^T  -R^T t]
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Ti[4 * r + c] = T[4 * c + r];
+    Ti[4 * r + 3] = -(T[r] * T[3] + T[4 + r] * T[7] + T[8 + r] * T[11]);
+  }
+}
+
+__device__ __forceinline__ void k_times(const double* K, const double* T, double* C) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) C[4 * r + c] = K[3 * r] * T[c] + K[3 * r + 1] * T[4 + c] + K[3 * r + 2] * T[8 + c];
+}
+
+// n_iterations for an outlier ratio: k_min + #{thresholds <= ratio}; table[0] = k_min, table[1..len] thresholds
+// (pipeline.hip builds it from the host's libm by bisection, so the device needs neither log nor pow and
+// returns exactly what ransac.py:58-67 returns on the host).
+__host__ __device__ inline long long table_lookup(const double* table, int len, long long max_it, double orat) {
+  int lo = 0, hi = len;                 // number of thresholds <= orat
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (table[1 + mid] <= orat) lo = mid + 1;
+    else hi = mid;
+  }
+  long long k = lo == len ? 0x7fffffffffffffffll : (long long)table[0] + lo;
+  return (max_it >= 0 && max_it < k) ? max_it : k;
+}
+
+using replay_args = ::vo_replay_args;
+
+constexpr int RP_TABLE_LDS = 4097;
+
+// ONE WAVE walks the batch of hypotheses through the reference's loop (ransac.py:90-121):
+//     while n < n_iterations: draw; model None -> continue; count; strictly better -> keep, adapt; n += 1
+// 64 hypotheses per round: a prefix maximum finds the hypotheses that improve on everything before them,
+// and between two such events n_iterations is constant, so the place where the loop ends is a ballot.
+// The flags and counts of 16 rounds are requested together; tb: the threshold table (table_len + 1 doubles, in
+// LDS when the caller staged it there).  Leaves the accepted pose in ctl->best_pose, its mask row in a.best_mask, the loop's bookkeeping in ctl; on a
+// step the device cannot finish alone, ctl->fault.  Must be called by all 64 lanes of the wave.
+__device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const replay_args& a, int lane,
+                                            const double* tb) {
+  if (lane == 0) {            // counters the bookkeeping kernels of this step add to
+    ctl->n_cand = 0;
+    ctl->n_dropped = 0;
+    ctl->n_land = 0;
+    ctl->done = 0;
+  }
+  const int hyp = a.hyp;
+  const int N = ctl->n_p3p;
+  long long n_it = ctl->n_iterations;
+  double orat = ctl->outlier_ratio;
+  long long n = 0;
+  int best = -1, best_idx = -1, consumed = -1, hyp_valid = 0;
+  bool risky_seen = false;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int sbase = 0; sbase < hyp; sbase += 1024) {
+    int vbs[16], cs[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int h = min(sbase + 64 * q + lane, hyp - 1);
+      vbs[q] = a.valid[h];
+      cs[q] = a.counts[h];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int base = sbase + 64 * q;
+      if (base >= hyp) break;
+      const int h = base + lane;
+      const int vb = h < hyp ? vbs[q] : 0;
+      const bool v = (vb & 1) != 0;
+      const unsigned long long vmask = __ballot(v);
+      hyp_valid += __popcll(vmask);
+      if (consumed >= 0) continue;                // (the loop has ended; only the statistics go on)
+      const int c = v ? cs[q] : -1;
+      const unsigned long long rmask = __ballot((vb & 2) != 0);
+      int pm = c;                                   // inclusive prefix maximum
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(pm, off);
+        if (lane >= off) pm = max(pm, o);
+      }
+      int epm = __shfl_up(pm, 1);
+      if (lane == 0) epm = -1;
+      epm = max(epm, best);
+      const unsigned long long imask = __ballot(v && c > epm);
+      const long long n_here = n + __popcll(vmask & lt);       // iterations counted before this lane's draw
+      int cur = 0;
+      for (;;) {
+        const unsigned long long ge = cur >= 64 ? 0ull : ~((1ull << cur) - 1ull);
+        const unsigned long long smask = __ballot(n_here >= n_it) & ge;   // the `while` test fails before this draw
+        const unsigned long long emask = imask & ge;
+        const int sp = smask ? __ffsll((long long)smask) - 1 : 64;
+        const int ep = emask ? __ffsll((long long)emask) - 1 : 64;
+        if (sp <= ep && sp < 64) {
+          consumed = base + sp;
+          n = __shfl(n_here, sp);
+          risky_seen |= (rmask & ((1ull << sp) - 1ull)) != 0ull;
+          break;
+        }
+        if (ep == 64) {
+          n += __popcll(vmask);
+          risky_seen |= rmask != 0ull;
+          break;
+        }
+        best = __shfl(c, ep);
+        best_idx = base + ep;
+        {   // ransac.py:113-120
+          double o = 1.0 - (double)best / (double)N;
+          o = fmin(fmax(o, 0.01), 0.99);
+          orat = o;
+          n_it = table_lookup(tb, a.table_len, a.max_it, o);
+        }
+        cur = ep + 1;
+      }
+    }
+  }
+  int fault = 0;
+  if (consumed < 0) {
+    if (n >= n_it) consumed = hyp;                // the loop ends exactly behind the last sample of the batch
+    else fault |= VO_FAULT_UNFINISHED;            // (also: no hypothesis had a solution)
+  }
+  if (risky_seen) fault |= VO_FAULT_RISKY_DRAW;
+  if (!fault && best_idx < 0) fault |= VO_FAULT_UNFINISHED;
+  if (fault) {
+    if (lane == 0) {
+      ctl->fault = fault;
+      ctl->n_p3p = 0;
+    }
+    return;
+  }
+  if (lane < 9) ctl->best_pose[lane] = a.R[9 * best_idx + lane];
+  if (lane < 3) ctl->best_pose[9 + lane] = a.t[3 * best_idx + lane];
+  const int wn = (N + 63) >> 6;
+  for (int w = lane; w < wn; w += 64) a.best_mask[w] = a.masks[(size_t)best_idx * a.words + w];
+  if (lane == 0) {
+    ctl->n_iterations = n_it;
+    ctl->outlier_ratio = orat;
+    ctl->raw_pos += 7ull * (unsigned long long)consumed;
+    ctl->best_idx = best_idx;
+    ctl->best_count = best;
+    ctl->consumed = consumed;
+    ctl->hyp_valid = hyp_valid;
+    ctl->n_done = n;
+  }
+}
+
+// main.py:261-268 for feature i of the new frame, given the new pose both ways (Tcw world -> camera, Twc its
+// inverse):  outliers[triangulate_inliers] = ~inliers; set_pose_for_new_tracks (features.py:224-237);
+// reset_outliers (state.py:162-172); compute_candidates (state.py:135-160, 174-219: bearing angle between the rays
+// through the track's first and last keypoint >= threshold, among state == 1).  Returns the candidate flag.
+__device__ __forceinline__ int candidate_feature(const vo_feat& B, int i, int n_tri,
+                                                 const unsigned long long* __restrict__ best_mask, const vo_cam& cam,
+                                                 const double* Twc, double bearing_thr) {
+  int st = B.state[i];
+  const int st0 = st;
+  const double u = B.kp64[2 * i], v = B.kp64[2 * i + 1];
+  bool reset = st == 0;
+  if (i < n_tri && !((best_mask[i >> 6] >> (i & 63)) & 1ull)) {   // P3P outlier (main.py:261-262)
+    st = 0;
+    reset = true;
+  }
+  int cand = 0;
+  if (reset) {
+    if (st0 != 0) {
+      B.track[2 * i] = u;
+      B.track[2 * i + 1] = v;
+      B.state[i] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + i] = Twc[k];
+  } else if (st == 1) {
+    double P[11];           // rotation part of the track's start pose (rows of the 3x4)
+#pragma unroll
+    for (int k = 0; k < 11; ++k) P[k] = B.pose[(size_t)k * B.pitch + i];
+    const double a = B.track[2 * i], b = B.track[2 * i + 1];
+    const double* Ki = cam.Kinv;
+    const double n1x = Ki[0] * a + Ki[1] * b + Ki[2], n1y = Ki[3] * a + Ki[4] * b + Ki[5],
+                 n1z = Ki[6] * a + Ki[7] * b + Ki[8];
+    const double n2x = Ki[0] * u + Ki[1] * v + Ki[2], n2y = Ki[3] * u + Ki[4] * v + Ki[5],
+                 n2z = Ki[6] * u + Ki[7] * v + Ki[8];
+    const double r1x = P[0] * n1x + P[1] * n1y + P[2] * n1z, r1y = P[4] * n1x + P[5] * n1y + P[6] * n1z,
+                 r1z = P[8] * n1x + P[9] * n1y + P[10] * n1z;
+    const double r2x = Twc[0] * n2x + Twc[1] * n2y + Twc[2] * n2z, r2y = Twc[4] * n2x + Twc[5] * n2y + Twc[6] * n2z,
+                 r2z = Twc[8] * n2x + Twc[9] * n2y + Twc[10] * n2z;
+    const double dot = r1x * r2x + r1y * r2y + r1z * r2z;
+    const double l1 = sqrt(r1x * r1x + r1y * r1y + r1z * r1z), l2 = sqrt(r2x * r2x + r2y * r2y + r2z * r2z);
+    const double ang = acos(dot / (l1 * l2));
+    cand = ang >= bearing_thr ? 1 : 0;                      // (NaN compares false, as in NumPy)
+  }
+  B.cand[i] = (uint8_t)cand;
+  return cand;
+}
+
+// update_from_matches + update_with_world_pose (state.py:17-50) on the control block: what was current becomes
+// previous, the new pose current.  Call with tid = 0..11 (one matrix entry each) from ONE workgroup.
+__device__ __forceinline__ void commit_pose(vo_seq_ctl* __restrict__ ctl, int tid, double ncw, double nwc) {
+  const double ocw = ctl->T_cw[tid], owc = ctl->T_wc[tid];
+  ctl->T_cw_prev[tid] = ocw;
+  ctl->T_wc_prev[tid] = owc;
+  ctl->T_cw[tid] = ncw;
+  ctl->T_wc[tid] = nwc;
+}
+
+}  // namespace vo_state_dev

@@ -18,7 +18,9 @@ struct vo_feat {
   uint8_t* cand;     // cap: candidate_mask (features.py:54)
   double* land;      // cap x 3, NaN = unknown
   double* track;     // cap x 2, keypoint at which the track started
-  double* pose;      // cap x 12, rows 0..2 of the 4x4 camera-to-world pose at the track's start (NaN = none)
+  double* pose;      // 12 x pitch (component-major: entry k of feature i at pose[k * pitch + i]): rows 0..2 of the
+                     // 4x4 camera-to-world pose at the track's start (NaN = none)
+  int pitch;         // = capacity
 };
 
 enum {
@@ -69,6 +71,32 @@ struct vo_append {
   int debug_fault_every;
 };
 
+struct vo_replay_args {
+  const uint8_t* valid;                 // bit 0: the hypothesis has a pose; bit 1: one of its draws could have been rejected
+  const int32_t* counts;
+  const double *R, *t;                  // hyp x 9, hyp x 3
+  const unsigned long long* masks;      // hyp rows of `words` 64-bit words
+  int words, hyp;
+  const double* table;                  // table_len + 1 doubles (vo_ransac_build_table)
+  int table_len;
+  long long max_it;
+  unsigned long long* best_mask;        // receives the accepted hypothesis' mask row
+};
+
+// One launch for the middle of the dependent chain (refine.hip, frame_pose_kernel): the sequential RANSAC rule
+// over the scored hypotheses, the refinement of the accepted pose over its inliers, then pose / outliers /
+// bearing-angle candidates of every feature.
+struct vo_pose_job {
+  vo_seq_ctl* ctl;
+  vo_replay_args rp;
+  int do_replay;        // 0: ctl->best_pose / best_mask are given (host recovery path)
+  vo_feat B;            // the new frame's features: land / kp64 are the P3P population
+  vo_cam cam;
+  double bearing_thr;
+  int max_iter;         // Gauss-Newton steps allowed; 0 = refinement off
+};
+int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job);
+
 // ---- launches (state.hip); all asynchronous on ctx->stream ----
 // klt.py:207-230 + 244-278 + matches.py:26-212: (virtual) re-detect append, keep status & err < thr, then the
 // 4-group regroup of the new frame
@@ -77,10 +105,6 @@ int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, con
 // matches.py:26-212 for an explicit match list (harris / sift trackers, tests)
 int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const int32_t* d_pairs, int M,
                            const double* d_new_kp, int n2_in, int cap);
-// ransac.py:90-121 replayed over (valid, count) of the hypothesis batch; thr_table: see pipeline.hip
-int vo_state_ransac_replay(vo_ctx* ctx, vo_seq_ctl* ctl, const uint8_t* d_valid, const int32_t* d_counts,
-                           const double* d_R, const double* d_t, const uint64_t* d_masks, int words, int hyp,
-                           const double* d_thr_table, int table_len, int64_t max_iterations, uint64_t* d_best_mask);
 // main.py:261-268 + state.py:17-50, 135-219: pose, outliers, bearing-angle candidates
 int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
                         double bearing_thr, int use_refined, int cap);

@@ -78,7 +78,8 @@ class StepResult(C.Structure):
                 ("R_refined", C.c_double * 9), ("t_refined", C.c_double * 3), ("refine_cost", C.c_double),
                 ("n_features_in", C.c_int32), ("redetected", C.c_int32), ("n_triangulated", C.c_int32),
                 ("n_candidates", C.c_int32), ("n_dropped", C.c_int32), ("n_landmarks", C.c_int32),
-                ("fault", C.c_int32), ("recovered", C.c_int32), ("raw_pos", C.c_uint64), ("T_wc", C.c_double * 12)]
+                ("fault", C.c_int32), ("recovered", C.c_int32), ("raw_pos", C.c_uint64), ("T_wc", C.c_double * 12),
+                ("seq_head", C.c_uint32), ("seq_tail", C.c_uint32)]
 
     def pose_world_cam(self):
         """State.curr_pose after the step: camera-to-world, 4x4."""
@@ -492,6 +493,12 @@ from vo._pipeline import Pipeline  # noqa: E402,F401  (device-resident frame loo
 
 
 _default_ctx = None
+
+
+def set_default_context(ctx):
+    """Make `ctx` the context the drop-in classes use when none is passed to them."""
+    global _default_ctx
+    _default_ctx = ctx
 
 
 def default_context():
