@@ -320,6 +320,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
   const int i = blockIdx.x * KLT_WAVES + (threadIdx.x >> 6);
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
   int n_own = N;                                       // points 0 .. n_own-1 are prev_xy's, the rest the detector's
+  if (src.ts && blockIdx.x == 0 && threadIdx.x == 0) *src.ts = wall_clock64();
   if (src.n) {
     n_own = *src.n;
     const bool redetect = (double)n_own < (double)*src.num_features * src.frac;
@@ -647,6 +648,7 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   const int i = blockIdx.x * KPW + lane / LPK;
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
   int n_own = N;                                       // points 0 .. n_own-1 are prev_xy's, the rest the detector's
+  if (src.ts && blockIdx.x == 0 && threadIdx.x == 0) *src.ts = wall_clock64();
   if (src.n) {
     n_own = *src.n;
     const bool redetect = (double)n_own < (double)*src.num_features * src.frac;

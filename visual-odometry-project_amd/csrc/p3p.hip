@@ -213,25 +213,6 @@ __device__ __forceinline__ unsigned bounded_from_raw(unsigned raw, unsigned rng,
   return (unsigned)(m >> 32);
 }
 
-// Tracks straight from the tracker's outputs (pipeline): with status != nullptr the solve kernel selects
-// the tracked keypoints itself -- status != 0 and err < err_thr, in their original order (the boolean
-// mask of klt.py:244-269) -- instead of reading arrays a separate kernel compacted: every workgroup
-// builds the bit masks and their prefix counts (one round trip, overlapping the generator words it
-// waits for anyway), maps its sample positions through them, and writes its share of the compacted
-// arrays (prev_c, next_c, land_c, *n_out) for the kernels that follow.
-struct p3p_tracks {
-  const uint8_t* status = nullptr;
-  const float* err = nullptr;
-  float err_thr = 0.f;
-  int N = 0;                        // keypoints (<= P3P_TRACK_CHUNKS * 64)
-  const double* kp_prev = nullptr;  // N x 2
-  const float* next_xy = nullptr;   // N x 2
-  const double* land_all = nullptr; // N x 3
-  double *prev_c = nullptr, *next_c = nullptr, *land_c = nullptr;
-  int* n_out = nullptr;
-};
-constexpr int P3P_TRACK_CHUNKS = 256;   // 64 keypoints each: 16384
-
 // RAW == false: sample indices are given.
 // RAW == true : hypothesis h derives its sample from generator outputs raws[7h .. 7h+6] and the
 //   population size *d_n, both of which may still be in flight when the kernel is enqueued:
@@ -240,108 +221,15 @@ constexpr int P3P_TRACK_CHUNKS = 256;   // 64 keypoints each: 16384
 //   rejection (or n < 8, where the draw count changes) sets *flag and the host redoes the batch
 //   with the sequential sampler.
 template <bool RAW>
-__global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
-                                                       const int* __restrict__ samples,
-                                                       const unsigned* __restrict__ raws,
-                                                       const unsigned* __restrict__ rawctl, unsigned raw_tag,
-                                                       const unsigned long long* __restrict__ d_rawpos, unsigned raw_mask,
-                                                       const int* __restrict__ d_n, unsigned* __restrict__ flag,
-                                                       int Hyp, double fx,
-                                                       double fy, double cx, double cy, double* __restrict__ Rout,
-                                                       double* __restrict__ tout, uint8_t* __restrict__ valid,
-                                                       double* __restrict__ Rhost, double* __restrict__ thost,
-                                                       p3p_tracks T) {
-  // Rhost / thost (optional, mapped host memory): the poses are also written there, so the host
-  // finds the winner's without a copy kernel moving all of them.
+__device__ __forceinline__ void p3p_solve_quad(int gt, const double* __restrict__ Xw, const double* __restrict__ xi,
+                                               const int* __restrict__ samples, const unsigned* __restrict__ raws,
+                                               const unsigned long long* __restrict__ d_rawpos, unsigned raw_mask,
+                                               const int* __restrict__ d_n, unsigned* __restrict__ flag, int Hyp,
+                                               double fx, double fy, double cx, double cy, double* __restrict__ Rout,
+                                               double* __restrict__ tout, uint8_t* __restrict__ valid) {
   // four lanes (a DPP quad) per hypothesis: the set-up and the quartic are computed by all four,
   // then lane `sub` takes root `sub` through the triad alignment and the fourth-point test
-  const int gt = blockIdx.x * blockDim.x + threadIdx.x;
   const int h = gt >> 2, sub = gt & 3;
-  __shared__ unsigned long long s_tmask[RAW ? P3P_TRACK_CHUNKS : 1];
-  __shared__ int s_tpref[RAW ? P3P_TRACK_CHUNKS + 1 : 1];
-  int n_tracks = 0;
-  const bool own_tracks = RAW && T.status != nullptr;
-  if (RAW && own_tracks) {
-    const int lane = threadIdx.x;
-    const int chunks = (T.N + 63) >> 6;
-    // masks: 32 chunks' flags are requested together (one round trip per group)
-    for (int c0 = 0; c0 < chunks; c0 += 32) {
-      uint8_t st[32];
-      float er[32];
-      // (unconditional loads at clamped indices and non-short-circuit flags: with `&&` the compiler
-      //  nests the second load under the first and the 64 requests become 32 dependent round trips)
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const int i = min((c0 + k) * 64 + lane, T.N - 1);
-        st[k] = T.status[i];
-        er[k] = T.err[i];
-      }
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        const int i = (c0 + k) * 64 + lane;
-        const int keep = (int)(i < T.N) & (int)(st[k] != 0) & (int)(er[k] < T.err_thr);
-        const unsigned long long m = __ballot(keep != 0);
-        if (lane == 0 && c0 + k < chunks) s_tmask[c0 + k] = m;
-      }
-    }
-    __syncthreads();
-    // exclusive prefix counts over the chunks (64 chunks per pass, wave scan)
-    int base = 0;
-    for (int c0 = 0; c0 < chunks; c0 += 64) {
-      const int c = c0 + lane;
-      const int cnt = c < chunks ? __popcll(s_tmask[c]) : 0;
-      int inc = cnt;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-      }
-      if (c < chunks) s_tpref[c] = base + inc - cnt;
-      base += __shfl(inc, 63);
-    }
-    n_tracks = base;
-    if (lane == 0) s_tpref[chunks] = base;
-    __syncthreads();
-    // this workgroup's share of the compacted arrays
-    for (int c = blockIdx.x; c < chunks; c += gridDim.x) {
-      const unsigned long long m = s_tmask[c];
-      const int i = c * 64 + lane;
-      if ((m >> lane) & 1ull) {
-        const int o = s_tpref[c] + __popcll(m & ((1ull << lane) - 1ull));
-        T.prev_c[2 * o] = T.kp_prev[2 * i];
-        T.prev_c[2 * o + 1] = T.kp_prev[2 * i + 1];
-        T.next_c[2 * o] = (double)T.next_xy[2 * i];
-        T.next_c[2 * o + 1] = (double)T.next_xy[2 * i + 1];
-        T.land_c[3 * o] = T.land_all[3 * i];
-        T.land_c[3 * o + 1] = T.land_all[3 * i + 1];
-        T.land_c[3 * o + 2] = T.land_all[3 * i + 2];
-      }
-    }
-    if (gt == 0) T.n_out[0] = n_tracks;
-  }
-  if (RAW && rawctl) {
-    // Where this step's outputs start in the host's look-ahead buffer is known once the previous
-    // step's consumption is: the host publishes {tag, position} in mapped memory, normally long
-    // before this kernel runs.  Bounded wait; on time-out the host redoes the batch.
-    __shared__ unsigned s_pos;
-    if (threadIdx.x == 0) {
-      int spins = 0;
-      bool ok = true;
-      const unsigned long long* ctl = reinterpret_cast<const unsigned long long*>(rawctl);   // tag | offset << 32
-      unsigned long long w;
-      while ((unsigned)(w = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != raw_tag) {
-        if (++spins > 4000) {
-          ok = false;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(64);
-      }
-      s_pos = ok ? (unsigned)(w >> 32) : 0u;
-      if (!ok) atomicOr(flag, 1u);
-    }
-    __syncthreads();
-    raws += s_pos;
-  }
   // (device-resident frame state: the position in the generator's output stream is a word the previous
   //  step's replay kernel left in HBM, the outputs live in a power-of-two ring)
   const unsigned ring_pos = (RAW && d_rawpos) ? (unsigned)(*d_rawpos) : 0u;
@@ -349,7 +237,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
   int sidx[4];
   bool risky = false;                   // a draw of this sample could have been rejected: valid[h] bit 1
   if (RAW) {
-    const int n = own_tracks ? n_tracks : *d_n;
+    const int n = *d_n;
     if (n < 8) {
       if (gt == 0) atomicOr(flag, 1u);
       if (sub == 0) {
@@ -389,39 +277,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
     for (int k = 0; k < 4; ++k) sidx[k] = samples[4 * h + k];
   }
   double P[4][3], px[4][2];
-  if (RAW && own_tracks) {
-    // position among the tracked keypoints -> keypoint: the chunk by bisection over the prefix counts,
-    // the bit inside its mask by bisection over popcounts
-    const int chunks = (T.N + 63) >> 6;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int pos = sidx[k];
-      int lo = 0, hi = chunks;              // s_tpref[lo] <= pos < s_tpref[hi]
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_tpref[mid] <= pos) lo = mid;
-        else hi = mid;
-      }
-      unsigned long long m = s_tmask[lo];
-      int want = pos - s_tpref[lo];         // the want-th set bit of m
-      int bit = 0;
-#pragma unroll
-      for (int w = 32; w >= 1; w >>= 1) {
-        const int c = __popcll(m & ((1ull << w) - 1ull));
-        if (want >= c) {
-          want -= c;
-          m >>= w;
-          bit += w;
-        }
-      }
-      const int idx = lo * 64 + bit;
-      P[k][0] = T.land_all[3 * idx];
-      P[k][1] = T.land_all[3 * idx + 1];
-      P[k][2] = T.land_all[3 * idx + 2];
-      px[k][0] = (double)T.next_xy[2 * idx];
-      px[k][1] = (double)T.next_xy[2 * idx + 1];
-    }
-  } else {
+  {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int idx = sidx[k];
@@ -538,12 +394,103 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
       for (int k = 0; k < 9; ++k) Rout[9 * h + k] = bestR[k];
       for (int k = 0; k < 3; ++k) tout[3 * h + k] = bestt[k];
       valid[h] = risky ? 3 : 1;
-      if (Rhost) {
-        for (int k = 0; k < 9; ++k) Rhost[9 * h + k] = bestR[k];
-        for (int k = 0; k < 3; ++k) thost[3 * h + k] = bestt[k];
+    }
+  }
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
+                                                       const int* __restrict__ samples,
+                                                       const unsigned* __restrict__ raws,
+                                                       const unsigned long long* __restrict__ d_rawpos, unsigned raw_mask,
+                                                       const int* __restrict__ d_n, unsigned* __restrict__ flag, int Hyp,
+                                                       double fx, double fy, double cx, double cy,
+                                                       double* __restrict__ Rout, double* __restrict__ tout,
+                                                       uint8_t* __restrict__ valid) {
+  p3p_solve_quad<RAW>(blockIdx.x * blockDim.x + threadIdx.x, Xw, xi, samples, raws, d_rawpos, raw_mask, d_n, flag, Hyp, fx,
+                      fy, cx, cy, Rout, tout, valid);
+}
+
+// Frame loop: hypotheses AND their inlier counts in one launch.  A workgroup of 256 owns HG hypotheses:
+//   wave 0 solves them (4 lanes each, p3p_solve_quad) while waves 1-3 already fetch the population;
+//   then every thread keeps up to HP correspondences in registers and scores all HG poses against them --
+//   the population is read from memory once per workgroup (Hyp / HG times in all, not Hyp times: the one-workgroup-
+//   per-hypothesis kernel streams ~70 MB through L2 at cfg-2 and slows down 3x when the tracker and the detector
+//   run beside it), inlier bits leave as one ballot word per wave, counts as popcounts.
+constexpr int HG = 8;      // hypotheses per workgroup
+constexpr int HP = 7;      // correspondences per thread and tile (256 * 7 = 1792 = 28 mask words)
+__global__ __launch_bounds__(256) void p3p_hyp_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
+                                                      const unsigned* __restrict__ raws,
+                                                      const unsigned long long* __restrict__ d_rawpos, unsigned raw_mask,
+                                                      const int* __restrict__ d_n, unsigned* __restrict__ flag, int Hyp,
+                                                      double fx, double fy, double cx, double cy, double thr,
+                                                      double* __restrict__ Rout, double* __restrict__ tout,
+                                                      uint8_t* __restrict__ valid, int* __restrict__ counts,
+                                                      unsigned long long* __restrict__ masks, int words,
+                                                      unsigned long long* __restrict__ ts_out) {
+  __shared__ int s_cnt[4][HG];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (ts_out && blockIdx.x == 0 && tid == 0) *ts_out = wall_clock64();
+  const int N = *d_n;
+  const int h0 = blockIdx.x * HG;
+  double pX[HP], pY[HP], pZ[HP], pu[HP], pv[HP];
+  auto load_tile = [&](int tile) {
+#pragma unroll
+    for (int k = 0; k < HP; ++k) {
+      const int i = min(tile * (256 * HP) + k * 256 + tid, max(N - 1, 0));
+      pX[k] = Xw[3 * i];
+      pY[k] = Xw[3 * i + 1];
+      pZ[k] = Xw[3 * i + 2];
+      pu[k] = xi[2 * i];
+      pv[k] = xi[2 * i + 1];
+    }
+  };
+  if (wv == 0) {
+    if (lane < 4 * HG)
+      p3p_solve_quad<true>(h0 * 4 + lane, Xw, xi, nullptr, raws, d_rawpos, raw_mask, d_n, flag, Hyp, fx, fy, cx, cy, Rout,
+                           tout, valid);
+    if (N > 0) load_tile(0);
+  } else if (N > 0) {
+    load_tile(0);
+  }
+  __syncthreads();            // (the poses wave 0 wrote are visible to the workgroup)
+  int cnt[HG];
+#pragma unroll
+  for (int g = 0; g < HG; ++g) cnt[g] = 0;
+  const int words_n = (N + 63) >> 6;
+  const int tiles = (N + 256 * HP - 1) / (256 * HP);
+  for (int tile = 0; tile < tiles; ++tile) {
+    if (tile > 0) load_tile(tile);
+#pragma unroll
+    for (int g = 0; g < HG; ++g) {
+      const int h = h0 + g;
+      if (h >= Hyp) break;
+      const bool ok = (valid[h] & 1) != 0;
+      double R[9], t[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = Rout[9 * h + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[k] = tout[3 * h + k];
+#pragma unroll
+      for (int k = 0; k < HP; ++k) {
+        const int i = tile * (256 * HP) + k * 256 + tid;
+        bool in = false;
+        if (ok && i < N) in = reproj_sq(R, t, fx, fy, cx, cy, pX[k], pY[k], pZ[k], pu[k], pv[k]) < thr;
+        const unsigned long long m = __ballot(in);
+        const int w = i >> 6;                  // (uniform in the wave)
+        if (lane == 0 && w < words_n) {
+          if (masks) masks[(size_t)h * words + w] = m;
+          cnt[g] += __popcll(m);
+        }
       }
     }
   }
+  if (lane == 0) {
+#pragma unroll
+    for (int g = 0; g < HG; ++g) s_cnt[wv][g] = cnt[g];
+  }
+  __syncthreads();
+  if (tid < HG && h0 + tid < Hyp) counts[h0 + tid] = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
 }
 
 constexpr int SC_T = 256;
@@ -609,50 +556,26 @@ __global__ __launch_bounds__(256) void reproj_kernel(const double* __restrict__ 
 
 }  // namespace
 
-// Pipeline-internal form of vo_p3p_hypotheses_dev: population size and generator outputs are
-// device-readable and need not be final when this is enqueued (see p3p_solve_kernel<true>).
-int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
-                              const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
-                              int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
-                              uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t,
-                              const vo_track_source* tracks, const uint64_t* d_rawpos, uint32_t raw_mask) {
+// Frame-loop form of vo_p3p_hypotheses_dev: the population size, the position in the generator's output stream and
+// the outputs themselves (a power-of-two ring, raw_mask = length - 1) are read on the device, so the launch can be
+// enqueued before any of them exists; a draw that NumPy might have rejected marks its hypothesis (valid[h] bit 1),
+// a population below 8 raises *d_flag.  One launch: hypotheses and inlier counts (p3p_hyp_kernel).
+int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
+                               const double* K, const uint32_t* d_raws, const uint64_t* d_rawpos, uint32_t raw_mask,
+                               int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
+                               uint64_t* d_masks, uint32_t* d_flag, uint64_t* d_ts) {
   if (!ctx) return VO_EINVAL;
-  VO_REQUIRE(ctx, d_X && d_x && d_n && K && d_raws && d_R && d_t && d_valid && d_counts && d_flag,
-             "p3p_hypotheses_raw: null pointer");
-  VO_REQUIRE(ctx, n_cap >= 4 && Hyp >= 1, "p3p_hypotheses_raw: need n_cap >= 4 and Hyp >= 1");
-  VO_REQUIRE(ctx, K[0] != 0.0 && K[4] != 0.0, "p3p_hypotheses_raw: singular intrinsics");
-  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-  p3p_tracks T;
-  if (tracks) {
-    VO_REQUIRE(ctx, tracks->status && tracks->err && tracks->kp_prev && tracks->next_xy && tracks->land_all,
-               "p3p_hypotheses_raw: incomplete track source");
-    VO_REQUIRE(ctx, tracks->N >= 1 && tracks->N <= P3P_TRACK_CHUNKS * 64 && tracks->N <= n_cap,
-               "p3p_hypotheses_raw: track source holds %d keypoints (1..%d)", tracks->N, P3P_TRACK_CHUNKS * 64);
-    T.status = tracks->status;
-    T.err = tracks->err;
-    T.err_thr = tracks->err_thr;
-    T.N = tracks->N;
-    T.kp_prev = tracks->kp_prev;
-    T.next_xy = tracks->next_xy;
-    T.land_all = tracks->land_all;
-    T.prev_c = tracks->prev_c;
-    T.next_c = const_cast<double*>(d_x);
-    T.land_c = const_cast<double*>(d_X);
-    T.n_out = const_cast<int*>(d_n);
-  }
+  VO_REQUIRE(ctx, d_X && d_x && d_n && K && d_raws && d_rawpos && d_R && d_t && d_valid && d_counts && d_flag,
+             "p3p_hypotheses_ring: null pointer");
+  VO_REQUIRE(ctx, n_cap >= 4 && Hyp >= 1, "p3p_hypotheses_ring: need n_cap >= 4 and Hyp >= 1");
+  VO_REQUIRE(ctx, K[0] != 0.0 && K[4] != 0.0, "p3p_hypotheses_ring: singular intrinsics");
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
-    hipLaunchKernelGGL(p3p_solve_kernel<true>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
-                       (const int*)nullptr, d_raws, d_rawctl, raw_tag, (const unsigned long long*)d_rawpos,
-                       d_rawpos ? raw_mask : 0xffffffffu, d_n, d_flag, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid, m_R, m_t, T);
+    hipLaunchKernelGGL(p3p_hyp_kernel, dim3(vo_cdiv(Hyp, HG)), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
+                       (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], thr_sq, d_R,
+                       d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts);
   }
-  VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
-  {
-    vo_prof_scope ps(ctx, VO_K_P3P_SCORE);
-    hipLaunchKernelGGL(p3p_score_kernel, dim3(Hyp), dim3(SC_T), 0, ctx->stream, d_X, d_x, 0, d_n, d_R, d_t, d_valid,
-                       fx, fy, cx, cy, thr_sq, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64));
-  }
-  return vo_check_launch(ctx, "p3p_score_kernel");
+  return vo_check_launch(ctx, "p3p_hyp_kernel");
 }
 
 extern "C" {
@@ -669,9 +592,8 @@ int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     hipLaunchKernelGGL(p3p_solve_kernel<false>, dim3(vo_cdiv(Hyp, 16)), dim3(64), 0, ctx->stream, d_X, d_x,
-                       d_samples, (const unsigned*)nullptr, (const unsigned*)nullptr, 0u,
-                       (const unsigned long long*)nullptr, 0xffffffffu, (const int*)nullptr, (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid, (double*)nullptr, (double*)nullptr,
-                       p3p_tracks());
+                       d_samples, (const unsigned*)nullptr, (const unsigned long long*)nullptr, 0xffffffffu,
+                       (const int*)nullptr, (unsigned*)nullptr, Hyp, fx, fy, cx, cy, d_R, d_t, d_valid);
   }
   VO_TRY(vo_check_launch(ctx, "p3p_solve_kernel"));
   const int words = vo_cdiv(N, 64);

@@ -495,6 +495,7 @@ static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool 
   src.frac = c.redetect_fraction;
   src.det_kp = p->d_kp[f.a];
   src.n_det = c.n_keypoints;
+  src.ts = &p->d_ctl->ts[0];
   {
     const int rc = vo_klt_track_ndev(p->trk, p->d_img[f.prev_idx], p->d_pyr[f.a], p->d_img[f.next_idx], p->d_pyr[f.b], c.H,
                                      c.W, p->n_levels, A.kp, p->cap, nullptr, c.klt_win, c.klt_max_iter, c.klt_eps,
@@ -521,10 +522,9 @@ static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fi
   VO_TRY(vo_state_regroup_klt(ctx, p->d_ctl, A, B, p->d_next, p->d_status, p->d_err, (float)c.klt_err_threshold, ap, p->cap));
   VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], ctx->stream));
   if (first_half_only) return VO_OK;
-  VO_TRY(vo_p3p_hypotheses_raw_dev(ctx, B.land, B.kp64, &p->d_ctl->n_p3p, p->cap, c.K, p->d_raws, nullptr, 0u, c.hyp,
-                                   c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_masks,
-                                   (uint32_t*)&p->d_ctl->solve_flag, nullptr, nullptr, nullptr, &p->d_ctl->raw_pos,
-                                   p->ring_len - 1));
+  VO_TRY(vo_p3p_hypotheses_ring_dev(ctx, B.land, B.kp64, &p->d_ctl->n_p3p, p->cap, c.K, p->d_raws, &p->d_ctl->raw_pos,
+                                    p->ring_len - 1, c.hyp, c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts,
+                                    p->d_masks, (uint32_t*)&p->d_ctl->solve_flag, (uint64_t*)&p->d_ctl->ts[2]));
   VO_TRY(vo_frame_pose(ctx, make_pose_job(p, B, 1)));
   VO_TRY(vo_state_landmarks(ctx, p->d_ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + f.rslot,
                             p->m_seq + f.rslot, f.seq));

@@ -328,6 +328,7 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   __shared__ double s_pose[12], s_try[12];
   __shared__ int s_state, s_cand[RF_T / 64];
   vo_seq_ctl* ctl = job.ctl;
+  if (threadIdx.x == 0) ctl->ts[3] = wall_clock64();
   if (ctl->fault) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const double* X = job.B.land;

@@ -208,6 +208,10 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
   __shared__ unsigned long long s_red[2][4];
   __shared__ int s_wcnt[3][4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (blockIdx.x == 0 && tid == 0) {
+    ctl->ts[1] = wall_clock64();
+    ctl->ts[6] = ctl->ts[0];          // this step's tracker start (the next step's tracker overwrites ts[0] meanwhile)
+  }
   int fault = ctl->fault;
   const int n = ctl->n;
   if (ap.debug_fault_every > 0 && (ctl->step % ap.debug_fault_every) == ap.debug_fault_every - 1) fault |= VO_FAULT_FORCED;
@@ -364,6 +368,7 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
   __shared__ int s_cnt[2];
   __shared__ int s_last;
   const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) ctl->ts[4] = wall_clock64();
   const int fault = ctl->fault;
   if (fault) {
     if (res && blockIdx.x == 0 && tid == 0) {
@@ -474,6 +479,10 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
     res->fault = 0;
     res->recovered = 0;
     res->raw_pos = ctl->raw_pos;
+    res->ts[0] = ctl->ts[6];
+    for (int k = 1; k < 4; ++k) res->ts[k] = ctl->ts[k];
+    res->ts[4] = atomicAdd(&ctl->ts[4], 0ull);
+    res->ts[5] = wall_clock64();
   }
   __threadfence_system();
   __syncthreads();

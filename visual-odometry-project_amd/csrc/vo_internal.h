@@ -100,31 +100,12 @@ static inline int vo_check_launch(vo_ctx* ctx, const char* what) {
 static inline int vo_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- internal entry points shared between translation units (not part of the C ABI) ----
-// P3P hypotheses whose sample indices are derived on the device from raw generator outputs
-// and a device-resident population size (p3p.hip).
-// d_rawctl (optional, mapped host memory): {tag, offset}; the kernel waits (bounded) until the tag
-// equals raw_tag and reads its outputs from d_raws + offset.
-struct vo_track_source {   // tracker outputs the solve kernel selects the tracked keypoints from (p3p.hip)
-  const uint8_t* status;
-  const float* err;
-  float err_thr;
-  int N;
-  const double* kp_prev;     // N x 2
-  const float* next_xy;      // N x 2
-  const double* land_all;    // N x 3
-  double* prev_c;            // compacted previous keypoints (the next ones and the landmarks go to d_x / d_X, the count to d_n)
-};
-int vo_p3p_hypotheses_raw_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
-                              const double* K, const uint32_t* d_raws, const uint32_t* d_rawctl, uint32_t raw_tag,
-                              int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
-                              uint64_t* d_masks, uint32_t* d_flag, double* m_R, double* m_t,
-                              const vo_track_source* tracks, const uint64_t* d_rawpos = nullptr,
-                              uint32_t raw_mask = 0xffffffffu);
-// d_rawpos (optional, device memory): absolute position of the step's first generator output; the outputs are
-// then read from the ring d_raws[(pos + k) & raw_mask], and a possibly rejected draw marks its own hypothesis
-// (valid[h] bit 1) instead of raising the batch-wide flag.
-// m_R / m_t (optional, mapped host memory): every pose is also written there.
-// tracks (optional): d_X / d_x / *d_n are then OUTPUTS too -- the kernel compacts the tracked keypoints itself.
+// P3P hypotheses + inlier counts of the frame loop (p3p.hip): sample indices derived on the device from raw
+// generator outputs in a ring, population size and stream position read on the device.
+int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
+                               const double* K, const uint32_t* d_raws, const uint64_t* d_rawpos, uint32_t raw_mask,
+                               int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
+                               uint64_t* d_masks, uint32_t* d_flag, uint64_t* d_ts = nullptr);
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
 void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
 // DLT with a device-resident point count (dlt.hip)
@@ -143,6 +124,7 @@ struct vo_klt_source {
   double frac = 0.0;
   const double* det_kp = nullptr;
   int n_det = 0;
+  unsigned long long* ts = nullptr;   // (optional) receives wall_clock64() when the kernel's first work item starts
 };
 int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
                       const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N,

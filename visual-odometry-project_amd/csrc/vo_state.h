@@ -55,6 +55,9 @@ struct vo_seq_ctl {
   // 3x4 row-major, world->camera and camera->world: State.curr_pose / State.prev_pose (state.py:9-15), and a
   // pose handed in by the host (vo_pipeline_bookkeeping)
   double T_cw[12], T_wc[12], T_cw_prev[12], T_wc_prev[12], T_in_cw[12], T_in_wc[12];
+  // wall_clock64() (100 MHz) when the first work item of each kernel of the chain started: tracker, regroup,
+  // hypotheses, pose, landmarks, and when the landmarks kernel's last workgroup wrote the record
+  unsigned long long ts[8];
 };
 
 struct vo_cam {

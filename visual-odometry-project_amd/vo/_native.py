@@ -79,7 +79,7 @@ class StepResult(C.Structure):
                 ("n_features_in", C.c_int32), ("redetected", C.c_int32), ("n_triangulated", C.c_int32),
                 ("n_candidates", C.c_int32), ("n_dropped", C.c_int32), ("n_landmarks", C.c_int32),
                 ("fault", C.c_int32), ("recovered", C.c_int32), ("raw_pos", C.c_uint64), ("T_wc", C.c_double * 12),
-                ("seq_head", C.c_uint32), ("seq_tail", C.c_uint32)]
+                ("ts", C.c_uint64 * 8), ("seq_head", C.c_uint32), ("seq_tail", C.c_uint32)]
 
     def pose_world_cam(self):
         """State.curr_pose after the step: camera-to-world, 4x4."""
