@@ -225,6 +225,29 @@ def test_headless_driver_runs_the_reference_call_sequence(ctx):
     assert err["rms"] < 0.05 * err["path_length"], err
 
 
+def test_harris_feature_matcher_on_the_reference_kitti_frames(ctx, tmp_path):
+    """tests/test_harris.py:126-171 restated: Sequence("kitti") -> frames 0 and 1 -> HarrisCornerDetector(
+    num_keypoints=200).featureMatcher; the reference asserts types / shapes / at least one match; here the
+    keypoints are also the reference's own (tests/golden/kitti_harris.npz)."""
+    from test_loader import make_kitti_dir
+    from vo.features import HarrisCornerDetector
+    from vo.primitives import Matches, Sequence
+    g = make_kitti_dir(str(tmp_path))
+    seq = Sequence("kitti", path=str(tmp_path))
+    f1, f2 = seq.get_frame(0), seq.get_frame(1)
+    harris = HarrisCornerDetector(f1, num_keypoints=200)
+    m = harris.featureMatcher(f1, f2)
+    assert isinstance(m, Matches)
+    assert m.frame1.features.keypoints.shape[0] <= 200 and m.frame1.features.descriptors.shape[0] <= 200
+    assert m.frame1.features.descriptors.shape == m.frame2.features.descriptors.shape
+    assert len(m.frame1.features.keypoints) > 0
+    # every keypoint of both frames is one of the reference's (Matches re-orders them)
+    for feats, k in ((m.frame1.features, 0), (m.frame2.features, 1)):
+        ref = {tuple(p) for p in g["keypoints%d" % k][:, :, 0]}
+        assert {tuple(p) for p in feats.keypoints[:, :, 0]} == ref
+    assert int((m.frame2.features.state >= 1).sum()) > 50
+
+
 def test_headless_driver_on_the_device_pipeline(ctx):
     """Same bootstrap, steady state as the device-resident pipeline (vo.driver.run_on_device): images in,
     pose records out, Features / State never leave HBM."""
