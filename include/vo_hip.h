@@ -119,6 +119,11 @@ int vo_harris_keypoints(vo_ctx* ctx, const uint8_t* img, int H, int W, int patch
                         double* scores /* nullable */);
 int vo_nms_keypoints(vo_ctx* ctx, const double* scores, int H, int W, int N, int r,
                      double* kp_xy);
+/* The detector on S frames of one size in one set of launches (the sequence is the grid's extra dimension: several
+ * sequences per GPU advance together).  imgs: S*H*W bytes; kp_xy: S*N*2; scores: S*H*W or NULL.
+ * Results are those of S calls of vo_harris_keypoints.                                                     */
+int vo_harris_keypoints_batch(vo_ctx* ctx, const uint8_t* imgs, int S, int H, int W, int patch, double kappa, int N,
+                              int r, double* kp_xy, double* scores /* nullable */);
 int vo_harris_response_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int patch,
                            double kappa, double* d_scores);
 int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int N,

@@ -151,6 +151,23 @@ def test_reference_kitti_fixture(ctx):
         assert np.array_equal(_sha(desc.reshape(200, -1, 1)), g["descriptors%d_sha256" % k])
 
 
+@pytest.mark.parametrize("shape,S,n", [((240, 320), 3, 300), ((97, 131), 5, 64), ((480, 640), 2, 500)])
+def test_batched_detector_equals_single_calls(ctx, shape, S, n):
+    """Several sequences per launch (grid's extra dimension = sequence): S different frames through one set of
+    launches give what S single calls give, score maps and keypoints bit for bit -- including after a call with
+    a different S on the same context (workspace regrown, histograms / state maps re-zeroed)."""
+    imgs = np.stack([synthetic_image(shape[0], shape[1], 40 + q, block=6 + q) for q in range(S)])
+    imgs[-1, 10:40, 10:60] = 128                              # one frame with a flat patch: plateaus / ties
+    kp, sc = ctx.harris_keypoints_batch(imgs, 9, 0.09, n, 5, want_scores=True)
+    for q in range(S):
+        kq, sq = ctx.harris_keypoints(imgs[q], 9, 0.09, n, 5, want_scores=True)
+        assert np.array_equal(sc[q], sq) and np.array_equal(kp[q], kq), q
+    kp2 = ctx.harris_keypoints_batch(imgs[:1], 9, 0.09, n, 5)
+    assert np.array_equal(kp2[0], kp[0])
+    kp3 = ctx.harris_keypoints_batch(imgs, 9, 0.09, n, 5)
+    assert np.array_equal(kp3, kp)
+
+
 def test_errors_are_reported_not_raised_across_abi(ctx):
     from vo._native import VoError
     img = np.zeros((32, 32), np.uint8)

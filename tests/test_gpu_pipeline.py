@@ -160,7 +160,10 @@ def test_pipeline_lookahead_and_host_recovery_match_blocking_steps(ctx):
     assert all(r.recovered == 0 for r in ref)
     for la, kw in ((True, {}), (False, dict(debug_fault_every=3)), (True, dict(debug_fault_every=3))):
         got, st, g = run(la, **kw)
-        assert [fields(r) for r in got] == [fields(r) for r in ref], (la, kw)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            fa, fb = fields(a), fields(b)
+            assert fa == fb, (la, kw, "step", k, "recovered", a.recovered,
+                              [(i, fa[i], fb[i]) for i in range(len(fa)) if fa[i] != fb[i]][:3])
         if kw:
             assert sum(r.recovered for r in got) == len(pairs) // 3
         assert g == g_ref

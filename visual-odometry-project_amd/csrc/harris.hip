@@ -69,8 +69,10 @@ __host__ __device__ inline resp_geom response_geometry(int p) {
 template <int P_T>
 __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __restrict__ img, int H, int W,
                                                              int p_arg, double kappa,
-                                                             double* __restrict__ out) {
+                                                             double* __restrict__ out, size_t img_stride) {
   extern __shared__ __align__(16) unsigned char smem[];
+  img += (size_t)blockIdx.z * img_stride;            // several sequences per launch: grid.z = sequence
+  out += (size_t)blockIdx.z * ((size_t)H * W);
   const int p = P_T > 0 ? P_T : p_arg;
   const resp_geom g = response_geometry(p);
   const int pr = g.pr, GWp = g.GWp, GH = g.GH, IWp = g.IWp, IH = g.IH;
@@ -328,6 +330,19 @@ struct nms_ctl {
   unsigned pad[2];
 };
 
+// Several sequences per launch: every buffer of the chain holds S consecutive per-sequence blocks, the
+// sequence is the grid's extra dimension (z for the tiled kernels, y for the 1-D ones) and each kernel moves
+// its pointers to its block first.  Strides in elements of the respective array; all zero for one sequence.
+struct nms_batch {
+  size_t sc = 0;        // score map (doubles)
+  size_t seg = 0;       // per-tile list segments (keys_l1/a1, idx_l1/a1, cand)
+  size_t segcnt = 0;    // per-tile counters
+  size_t comp = 0;      // compacted lists (keys_c, idx_c)
+  size_t alive = 0;     // state map
+  size_t hist = 0;      // one histogram
+  size_t rank = 0, sel = 0, kp = 0;
+};
+
 constexpr int HIST_SHIFT = 47;           // 65536 bins over non-negative doubles
 constexpr int HIST_BINS = 1 << 16;
 constexpr int HIST_TOTAL = HIST_BINS + 256;   // fine bins, then 256 coarse bins (fine >> 8)
@@ -378,8 +393,19 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
                                                             unsigned long long* __restrict__ seg_keys_a1,
                                                             unsigned* __restrict__ seg_idx_a1,
                                                             uint4* __restrict__ seg_cnt,
-                                                            unsigned* __restrict__ hist, nms_ctl* ctl) {
+                                                            unsigned* __restrict__ hist, nms_ctl* ctl, nms_batch B) {
   extern __shared__ __align__(16) unsigned char smem[];
+  {
+    const size_t q = blockIdx.z;
+    sc += q * B.sc;
+    seg_keys_l1 += q * B.seg;
+    seg_idx_l1 += q * B.seg;
+    seg_keys_a1 += q * B.seg;
+    seg_idx_a1 += q * B.seg;
+    seg_cnt += q * B.segcnt;
+    hist += q * B.hist;
+    ctl += q;
+  }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // counters of this call (first kernel of the chain)
     ctl->n_c = 0;
     ctl->n_rem = 0;
@@ -627,7 +653,22 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
                                                          unsigned* __restrict__ idx_c, unsigned* __restrict__ alive,
                                                          nms_ctl* ctl, unsigned cap_c,
                                                          const unsigned* __restrict__ hist,
-                                                         unsigned* __restrict__ hist_other, int N) {
+                                                         unsigned* __restrict__ hist_other, int N, nms_batch B) {
+  {
+    const size_t q = blockIdx.y;
+    seg_keys_l1 += q * B.seg;
+    seg_idx_l1 += q * B.seg;
+    seg_keys_a1 += q * B.seg;
+    seg_idx_a1 += q * B.seg;
+    seg_cnt += q * B.segcnt;
+    seg_cand += q * B.seg;
+    keys_c += q * B.comp;
+    idx_c += q * B.comp;
+    alive += q * B.alive;
+    ctl += q;
+    hist += q * B.hist;
+    hist_other += q * B.hist;
+  }
   __shared__ unsigned s_n, s_l1n, s_base;
   static_assert(NT == 256, "nms_threshold_bits is written for 256 threads");
   const unsigned blk = blockIdx.x;
@@ -729,8 +770,18 @@ __global__ __launch_bounds__(RT) void nms_round_kernel(const double* __restrict_
                                                        const unsigned* __restrict__ seg_cand,
                                                        unsigned long long* __restrict__ keys_c,
                                                        unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c,
-                                                       int H, int W, int r_arg, int tiles_x) {
+                                                       int H, int W, int r_arg, int tiles_x, nms_batch B) {
   extern __shared__ __align__(16) unsigned s_dyn[];
+  {
+    const size_t q = blockIdx.y;
+    sc += q * B.sc;
+    alive += q * B.alive;
+    seg_cnt += q * B.segcnt;
+    seg_cand += q * B.seg;
+    keys_c += q * B.comp;
+    idx_c += q * B.comp;
+    ctl += q;
+  }
   const int r = R_T > 0 ? R_T : r_arg;
   const int WN = 2 * r + 1;
   const int LW = CX + 2 * r, LH = CY + 2 * r;
@@ -992,7 +1043,18 @@ __global__ __launch_bounds__(NT) void nms_rank_kernel(const unsigned long long* 
                                                       const unsigned* __restrict__ idx_c, const nms_ctl* ctl,
                                                       unsigned* __restrict__ rank, unsigned* __restrict__ alive,
                                                       const uint4* __restrict__ seg_cnt,
-                                                      const unsigned* __restrict__ seg_cand, unsigned nblk) {
+                                                      const unsigned* __restrict__ seg_cand, unsigned nblk,
+                                                      nms_batch B) {
+  {
+    const size_t q = blockIdx.y;
+    keys_c += q * B.comp;
+    idx_c += q * B.comp;
+    ctl += q;
+    rank += q * B.rank;
+    alive += q * B.alive;
+    seg_cnt += q * B.segcnt;
+    seg_cand += q * B.seg;
+  }
   __shared__ unsigned long long s_k[RK_J];
   __shared__ unsigned s_i[RK_J];
   const int tid = threadIdx.x;
@@ -1082,7 +1144,17 @@ __global__ __launch_bounds__(SEL_T) void nms_finalize_kernel(unsigned long long*
                                                              unsigned cap_pow2, int W, int N, int r,
                                                              unsigned* __restrict__ sel,
                                                              double* __restrict__ kp_xy,
-                                                             float* __restrict__ kp_f32) {
+                                                             float* __restrict__ kp_f32, nms_batch B) {
+  {
+    const size_t q = blockIdx.y;
+    keys_c += q * B.comp;
+    idx_c += q * B.comp;
+    ctl += q;
+    rank += q * B.rank;
+    sel += q * B.sel;
+    kp_xy += q * B.kp;
+    if (kp_f32) kp_f32 += q * B.kp;
+  }
   __shared__ __align__(16) unsigned long long s_keys[CHUNK];   // 64 KiB
   __shared__ __align__(16) unsigned s_idx[CHUNK];              // 32 KiB
   __shared__ unsigned s_wsum[SEL_T / 64];
@@ -1338,12 +1410,21 @@ extern "C" {
 
 int vo_harris_response_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int patch, double kappa,
                            double* d_scores) {
+  return vo_harris_response_batch_dev(ctx, d_img, 0, 1, H, W, patch, kappa, d_scores);
+}
+
+}  // extern "C"
+
+// S images (d_img + s * img_stride) -> S score maps (d_scores + s * H * W), one launch (grid.z = sequence)
+int vo_harris_response_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_stride, int S, int H, int W, int patch,
+                                 double kappa, double* d_scores) {
   if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, S >= 1 && S <= 65535, "harris_response: bad sequence count");
   VO_REQUIRE(ctx, d_img && d_scores, "harris_response: null pointer");
   VO_REQUIRE(ctx, H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "harris_response: bad image size %dx%d", W, H);
   VO_REQUIRE(ctx, patch >= 3 && patch <= 31 && (patch & 1), "harris_response: patch must be odd in 3..31");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  dim3 grid(vo_cdiv(W, RX), vo_cdiv(H, RY));
+  dim3 grid(vo_cdiv(W, RX), vo_cdiv(H, RY), S);
   size_t lds = response_lds_bytes(patch);
   {
     static bool lds_opt_in = false;   // dynamic LDS above 64 KiB must be requested per kernel
@@ -1355,16 +1436,28 @@ int vo_harris_response_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int 
     vo_prof_scope ps(ctx, VO_K_HARRIS_RESPONSE);
     if (patch == 9)
       hipLaunchKernelGGL(harris_response_kernel<9>, grid, dim3(NT), lds, ctx->stream, d_img, H, W, patch, kappa,
-                         d_scores);
+                         d_scores, img_stride);
     else
       hipLaunchKernelGGL(harris_response_kernel<0>, grid, dim3(NT), lds, ctx->stream, d_img, H, W, patch, kappa,
-                         d_scores);
+                         d_scores, img_stride);
   }
   return vo_check_launch(ctx, "harris_response_kernel");
 }
 
+extern "C" {
+
 int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int N, int r, double* d_kp_xy) {
+  return vo_nms_keypoints_batch_dev(ctx, d_scores, 1, H, W, N, r, d_kp_xy, 0);
+}
+
+}  // extern "C"
+
+// S score maps (d_scores + s * H * W) -> S keypoint lists (d_kp_xy + s * kp_stride doubles; the float copies, when
+// ctx->nms_kp_f32 is set, at the same element stride), every kernel of the chain launched once for all sequences
+int vo_nms_keypoints_batch_dev(vo_ctx* ctx, const double* d_scores, int S, int H, int W, int N, int r, double* d_kp_xy,
+                               size_t kp_stride) {
   if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, S >= 1 && S <= 65535, "nms: bad sequence count");
   VO_REQUIRE(ctx, d_scores && d_kp_xy, "nms: null pointer");
   VO_REQUIRE(ctx, H > 0 && W > 0 && (int64_t)H * W < (1ll << 30), "nms: bad map size %dx%d", W, H);
   VO_REQUIRE(ctx, W < 65536 && H < 65536, "nms: map side must be < 65536");
@@ -1373,32 +1466,46 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const unsigned cap = (unsigned)H * (unsigned)W;
   const unsigned cap_c = next_pow2(2u * cap);
-  const dim3 grid(vo_cdiv(W, CX), vo_cdiv(H, CY));
+  const dim3 grid(vo_cdiv(W, CX), vo_cdiv(H, CY), S);
   const unsigned nblk = grid.x * grid.y;
   const size_t seg_total = (size_t)nblk * SEG;
-  VO_TRY(vo_ensure(ctx, ctx->nms_keys_l1, seg_total * 8));
-  VO_TRY(vo_ensure(ctx, ctx->nms_idx_l1, seg_total * 4));
-  VO_TRY(vo_ensure(ctx, ctx->nms_keys_a1, seg_total * 8));
-  VO_TRY(vo_ensure(ctx, ctx->nms_idx_a1, seg_total * 4));
-  VO_TRY(vo_ensure(ctx, ctx->nms_cand, seg_total * 4));
-  VO_TRY(vo_ensure(ctx, ctx->nms_segcnt, (size_t)nblk * sizeof(uint4)));
-  VO_TRY(vo_ensure(ctx, ctx->nms_keys_c, (size_t)cap_c * 8));
-  VO_TRY(vo_ensure(ctx, ctx->nms_idx_c, (size_t)cap_c * 4));
-  VO_TRY(vo_ensure(ctx, ctx->nms_sel, (size_t)MAX_N * 4));
-  if (!ctx->nms_hist.p) {
-    VO_TRY(vo_ensure(ctx, ctx->nms_hist, (size_t)2 * HIST_TOTAL * 4));   // one histogram per call parity
-    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_hist.p, 0, (size_t)2 * HIST_TOTAL * 4, ctx->stream));
+  const size_t Sz = (size_t)S;
+  VO_TRY(vo_ensure(ctx, ctx->nms_keys_l1, Sz * seg_total * 8));
+  VO_TRY(vo_ensure(ctx, ctx->nms_idx_l1, Sz * seg_total * 4));
+  VO_TRY(vo_ensure(ctx, ctx->nms_keys_a1, Sz * seg_total * 8));
+  VO_TRY(vo_ensure(ctx, ctx->nms_idx_a1, Sz * seg_total * 4));
+  VO_TRY(vo_ensure(ctx, ctx->nms_cand, Sz * seg_total * 4));
+  VO_TRY(vo_ensure(ctx, ctx->nms_segcnt, Sz * nblk * sizeof(uint4)));
+  VO_TRY(vo_ensure(ctx, ctx->nms_keys_c, Sz * cap_c * 8));
+  VO_TRY(vo_ensure(ctx, ctx->nms_idx_c, Sz * cap_c * 4));
+  VO_TRY(vo_ensure(ctx, ctx->nms_sel, Sz * MAX_N * 4));
+  if (ctx->nms_hist.cap < Sz * 2 * HIST_TOTAL * 4 || ctx->nms_S != S) {     // one histogram per call parity and sequence;
+    VO_TRY(vo_ensure(ctx, ctx->nms_hist, Sz * 2 * HIST_TOTAL * 4));         // where each lies depends on S
+    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_hist.p, 0, ctx->nms_hist.cap, ctx->stream));
+    ctx->nms_S = S;
   }
-  if (!ctx->nms_rank.p) {
-    VO_TRY(vo_ensure(ctx, ctx->nms_rank, (size_t)RANK_MAX * 4));
-    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_rank.p, 0, (size_t)RANK_MAX * 4, ctx->stream));
+  if (ctx->nms_rank.cap < Sz * RANK_MAX * 4) {
+    VO_TRY(vo_ensure(ctx, ctx->nms_rank, Sz * RANK_MAX * 4));
+    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_rank.p, 0, ctx->nms_rank.cap, ctx->stream));
   }
-  if (ctx->nms_alive.cap < (size_t)cap * 4 || ctx->nms_alive_dirty) {
-    VO_TRY(vo_ensure(ctx, ctx->nms_alive, (size_t)cap * 4));
+  if (ctx->nms_alive.cap < Sz * cap * 4 || ctx->nms_alive_dirty) {
+    VO_TRY(vo_ensure(ctx, ctx->nms_alive, Sz * cap * 4));
     VO_HIP_TRY(ctx, hipMemsetAsync(ctx->nms_alive.p, 0, ctx->nms_alive.cap, ctx->stream));
     ctx->nms_alive_dirty = false;
   }
-  VO_TRY(vo_ensure(ctx, ctx->nms_ctl, sizeof(nms_ctl)));
+  VO_TRY(vo_ensure(ctx, ctx->nms_ctl, Sz * sizeof(nms_ctl)));
+  nms_batch B;
+  if (S > 1) {
+    B.sc = cap;
+    B.seg = seg_total;
+    B.segcnt = nblk;
+    B.comp = cap_c;
+    B.alive = cap;
+    B.hist = HIST_TOTAL;
+    B.rank = RANK_MAX;
+    B.sel = MAX_N;
+    B.kp = kp_stride;
+  }
   nms_ctl* ctl = (nms_ctl*)ctx->nms_ctl.p;   // its counters are reset by the threshold kernel
 
   unsigned long long* keys_l1 = (unsigned long long*)ctx->nms_keys_l1.p;
@@ -1411,8 +1518,8 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
   uint4* segcnt = (uint4*)ctx->nms_segcnt.p;
   unsigned* alive = (unsigned*)ctx->nms_alive.p;
   ctx->nms_parity ^= 1;
-  unsigned* hist = (unsigned*)ctx->nms_hist.p + (size_t)ctx->nms_parity * HIST_TOTAL;
-  unsigned* hist_other = (unsigned*)ctx->nms_hist.p + (size_t)(1 - ctx->nms_parity) * HIST_TOTAL;
+  unsigned* hist = (unsigned*)ctx->nms_hist.p + (size_t)ctx->nms_parity * Sz * HIST_TOTAL;
+  unsigned* hist_other = (unsigned*)ctx->nms_hist.p + (size_t)(1 - ctx->nms_parity) * Sz * HIST_TOTAL;
   unsigned* rank = (unsigned*)ctx->nms_rank.p;
   hipStream_t st = ctx->stream;
   {
@@ -1429,46 +1536,48 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
     const size_t lds = candidates_lds_bytes(r);
     if (r == 5)
       hipLaunchKernelGGL(nms_candidates_kernel<5>, grid, dim3(NT), lds, st, d_scores, H, W, r, keys_l1, idx_l1,
-                         keys_a1, idx_a1, segcnt, hist, ctl);
+                         keys_a1, idx_a1, segcnt, hist, ctl, B);
     else
       hipLaunchKernelGGL(nms_candidates_kernel<0>, grid, dim3(NT), lds, st, d_scores, H, W, r, keys_l1, idx_l1,
-                         keys_a1, idx_a1, segcnt, hist, ctl);
+                         keys_a1, idx_a1, segcnt, hist, ctl, B);
   }
   VO_TRY(vo_check_launch(ctx, "nms_candidates_kernel"));
   ctx->nms_alive_dirty = true;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_COMPACT);
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(nblk), dim3(NT), 0, st, keys_l1, idx_l1, keys_a1, idx_a1, segcnt,
-                       cand, keys_c, idx_c, alive, ctl, cap_c, hist, hist_other, N);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(nblk, S), dim3(NT), 0, st, keys_l1, idx_l1, keys_a1, idx_a1, segcnt,
+                       cand, keys_c, idx_c, alive, ctl, cap_c, hist, hist_other, N, B);
   }
   VO_TRY(vo_check_launch(ctx, "nms_compact_kernel"));
   const size_t round_lds = (size_t)((CX + 2 * r) | 1) * ((CY + 2 * r) + CY) * 4;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_ROUND);
-    const dim3 g(nblk), b(RT);
+    const dim3 g(nblk, S), b(RT);
     if (r == 5)
       hipLaunchKernelGGL((nms_round_kernel<5, true>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
-                         idx_c, ctl, cap_c, H, W, r, (int)grid.x);
+                         idx_c, ctl, cap_c, H, W, r, (int)grid.x, B);
     else
       hipLaunchKernelGGL((nms_round_kernel<0, true>), g, b, round_lds, st, d_scores, alive, segcnt, cand, keys_c,
-                         idx_c, ctl, cap_c, H, W, r, (int)grid.x);
+                         idx_c, ctl, cap_c, H, W, r, (int)grid.x, B);
   }
   VO_TRY(vo_check_launch(ctx, "nms_round_kernel"));
   {
     // ranks for the usual case (nothing undecided, short list); returns the state map to all-zero
     vo_prof_scope ps(ctx, VO_K_NMS_RANK);
-    hipLaunchKernelGGL(nms_rank_kernel, dim3(RK_BLOCKS), dim3(NT), 0, st, keys_c, idx_c, ctl, rank, alive, segcnt,
-                       cand, nblk);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3(RK_BLOCKS, S), dim3(NT), 0, st, keys_c, idx_c, ctl, rank, alive, segcnt,
+                       cand, nblk, B);
   }
   VO_TRY(vo_check_launch(ctx, "nms_rank_kernel"));
   ctx->nms_alive_dirty = false;
   {
     vo_prof_scope ps(ctx, VO_K_NMS_SELECT);
-    hipLaunchKernelGGL(nms_finalize_kernel, dim3(1), dim3(SEL_T), 0, st, keys_c, idx_c, ctl, rank, cap_c, W, N, r,
-                       (unsigned*)ctx->nms_sel.p, d_kp_xy, ctx->nms_kp_f32);
+    hipLaunchKernelGGL(nms_finalize_kernel, dim3(1, S), dim3(SEL_T), 0, st, keys_c, idx_c, ctl, rank, cap_c, W, N, r,
+                       (unsigned*)ctx->nms_sel.p, d_kp_xy, ctx->nms_kp_f32, B);
   }
   return vo_check_launch(ctx, "nms_finalize_kernel");
 }
+
+extern "C" {
 
 int vo_patch_descriptors_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, const double* d_kp_xy, int N,
                              int r, double* d_desc) {
@@ -1528,6 +1637,28 @@ int vo_harris_keypoints(vo_ctx* ctx, const uint8_t* img, int H, int W, int patch
   VO_HIP_TRY(ctx, hipMemcpyAsync(kp_xy, ctx->kp.p, (size_t)N * 16, hipMemcpyDeviceToHost, ctx->stream));
   if (scores) VO_HIP_TRY(ctx, hipMemcpyAsync(scores, ctx->scores.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
   return check_overflow(ctx);
+}
+
+int vo_harris_keypoints_batch(vo_ctx* ctx, const uint8_t* imgs, int S, int H, int W, int patch, double kappa, int N,
+                              int r, double* kp_xy, double* scores) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, imgs && kp_xy, "harris_keypoints_batch: null pointer");
+  VO_REQUIRE(ctx, S >= 1 && H > 0 && W > 0 && N >= 1, "harris_keypoints_batch: bad arguments");
+  const size_t n = (size_t)H * W;
+  VO_TRY(vo_ensure(ctx, ctx->img, (size_t)S * n));
+  VO_TRY(vo_ensure(ctx, ctx->scores, (size_t)S * n * 8));
+  VO_TRY(vo_ensure(ctx, ctx->kp, (size_t)S * N * 16));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, imgs, (size_t)S * n, hipMemcpyHostToDevice, ctx->stream));
+  VO_TRY(vo_harris_response_batch_dev(ctx, (const uint8_t*)ctx->img.p, n, S, H, W, patch, kappa, (double*)ctx->scores.p));
+  VO_TRY(vo_nms_keypoints_batch_dev(ctx, (const double*)ctx->scores.p, S, H, W, N, r, (double*)ctx->kp.p, (size_t)N * 2));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(kp_xy, ctx->kp.p, (size_t)S * N * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (scores) VO_HIP_TRY(ctx, hipMemcpyAsync(scores, ctx->scores.p, (size_t)S * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<nms_ctl> h((size_t)S);
+  VO_HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->nms_ctl.p, (size_t)S * sizeof(nms_ctl), hipMemcpyDeviceToHost, ctx->stream));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int q = 0; q < S; ++q)
+    if (h[q].overflow) return vo_set_error(ctx, VO_ECAPACITY, "nms: candidate list overflow (sequence %d)", q);
+  return VO_OK;
 }
 
 int vo_nms_keypoints(vo_ctx* ctx, const double* scores, int H, int W, int N, int r, double* kp_xy) {

@@ -49,7 +49,10 @@ __device__ __forceinline__ int reflect101(int c, int n) {
 // One thread per pixel of the padded destination level: the border pixels take the value of
 // the interior pixel they mirror.  src points at the interior origin of the level above.
 __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src, int spitch, int H, int W,
-                                                       uint8_t* __restrict__ dst, int dpitch, int Hd, int Wd) {
+                                                       uint8_t* __restrict__ dst, int dpitch, int Hd, int Wd,
+                                                       size_t seq_stride) {
+  src += (size_t)blockIdx.z * seq_stride;          // several sequences per launch: both levels live in the
+  dst += (size_t)blockIdx.z * seq_stride;          // sequence's pyramid buffer
   const int xp = blockIdx.x * 64 + (threadIdx.x & 63);
   const int yp = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (xp >= Wd + 2 * PYR_PAD || yp >= Hd + 2 * PYR_PAD) return;
@@ -70,7 +73,10 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict
 
 // level 0: the frame itself with its reflected border
 __global__ __launch_bounds__(256) void pad_reflect_kernel(const uint8_t* __restrict__ src, int H, int W,
-                                                          uint8_t* __restrict__ dst, int dpitch) {
+                                                          uint8_t* __restrict__ dst, int dpitch, size_t img_stride,
+                                                          size_t pyr_stride) {
+  src += (size_t)blockIdx.z * img_stride;
+  dst += (size_t)blockIdx.z * pyr_stride;
   const int xp = blockIdx.x * 64 + (threadIdx.x & 63);
   const int yp = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (xp >= W + 2 * PYR_PAD || yp >= H + 2 * PYR_PAD) return;
@@ -119,7 +125,12 @@ __device__ __forceinline__ int pyr_tap(const uint8_t* __restrict__ src, int pitc
 __global__ __launch_bounds__(256) void pyramid3_kernel(const uint8_t* __restrict__ src, int H0, int W0,
                                                        uint8_t* __restrict__ d0, int p0, uint8_t* __restrict__ d1,
                                                        int p1, int H1, int W1, uint8_t* __restrict__ d2, int p2,
-                                                       int H2, int W2, int nB, int tiles2_x, int blocks1_x) {
+                                                       int H2, int W2, int nB, int tiles2_x, int blocks1_x,
+                                                       size_t img_stride, size_t pyr_stride) {
+  src += (size_t)blockIdx.y * img_stride;            // several sequences per launch: grid.y = sequence
+  d0 += (size_t)blockIdx.y * pyr_stride;
+  d1 += (size_t)blockIdx.y * pyr_stride;
+  d2 += (size_t)blockIdx.y * pyr_stride;
   __shared__ uint8_t s_l0[73 * 76];   // frame patch under the level-1 patch
   __shared__ uint8_t s_l1[35 * 36];
   const int tid = threadIdx.x;
@@ -312,12 +323,29 @@ __device__ __forceinline__ void wave_sync() {
 
 // WIN_T > 0: window side known at compile time (index arithmetic folds, loops unroll)
 template <int WIN_T>
-__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, int win_arg,
+__global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, vo_klt_batch B, int win_arg,
                                                        int max_iter, double eps2, float min_eig_thr,
                                                        float* __restrict__ next_xy, uint8_t* __restrict__ status,
                                                        float* __restrict__ err, int lds_per_wave) {
   extern __shared__ __align__(16) unsigned char smem_all[];
   const int i = blockIdx.x * KLT_WAVES + (threadIdx.x >> 6);
+  if (blockIdx.y != 0) {                               // several sequences per launch: grid.y = sequence
+    const size_t q = blockIdx.y;
+    for (int l = 0; l < P.n_levels; ++l) {
+      P.prev[l] += q * B.pyr;
+      P.next[l] += q * B.pyr;
+    }
+    prev_xy += q * B.xy;
+    next_xy += q * B.xy;
+    status += q * B.out;
+    err += q * B.out;
+    if (src.n) {
+      src.n = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(src.n) + q * B.ctl);
+      src.num_features = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(src.num_features) + q * B.ctl);
+      src.det_kp += q * B.det;
+      if (src.ts) src.ts = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(src.ts) + q * B.ctl);
+    }
+  }
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
   int n_own = N;                                       // points 0 .. n_own-1 are prev_xy's, the rest the detector's
   if (src.ts && blockIdx.x == 0 && threadIdx.x == 0) *src.ts = wall_clock64();
@@ -636,7 +664,7 @@ __device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pit
 }
 
 template <int WIN, int LPK>
-__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, int max_iter,
+__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, vo_klt_batch B, int max_iter,
                                                          double eps2, float min_eig_thr, float* __restrict__ next_xy,
                                                          uint8_t* __restrict__ status, float* __restrict__ err) {
   typedef klt_rows<WIN> G;
@@ -646,6 +674,23 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   __shared__ __align__(16) uint8_t smem[KPW * G::SLICE + 16];
   const int lane = threadIdx.x;
   const int i = blockIdx.x * KPW + lane / LPK;
+  if (blockIdx.y != 0) {                               // several sequences per launch: grid.y = sequence
+    const size_t q = blockIdx.y;
+    for (int l = 0; l < P.n_levels; ++l) {
+      P.prev[l] += q * B.pyr;
+      P.next[l] += q * B.pyr;
+    }
+    prev_xy += q * B.xy;
+    next_xy += q * B.xy;
+    status += q * B.out;
+    err += q * B.out;
+    if (src.n) {
+      src.n = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(src.n) + q * B.ctl);
+      src.num_features = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(src.num_features) + q * B.ctl);
+      src.det_kp += q * B.det;
+      if (src.ts) src.ts = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(src.ts) + q * B.ctl);
+    }
+  }
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
   int n_own = N;                                       // points 0 .. n_own-1 are prev_xy's, the rest the detector's
   if (src.ts && blockIdx.x == 0 && threadIdx.x == 0) *src.ts = wall_clock64();
@@ -922,7 +967,16 @@ size_t vo_pyramid_bytes(int H, int W, int n_levels) {
 
 // d_pyr receives levels 0 .. n_levels-1 back to back, each with its reflected border (see pyr_t)
 int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_levels, uint8_t* d_pyr) {
+  return vo_pyramid_build_batch_dev(ctx, d_img, 0, 1, H, W, n_levels, d_pyr, 0);
+}
+
+}  // extern "C"
+
+// S frames (d_img + s * img_stride) -> S pyramids (d_pyr + s * pyr_stride), every launch once for all sequences
+int vo_pyramid_build_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_stride, int S, int H, int W, int n_levels,
+                               uint8_t* d_pyr, size_t pyr_stride) {
   if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, S >= 1 && S <= 65535, "pyramid_build: bad sequence count");
   VO_REQUIRE(ctx, d_img && d_pyr, "pyramid_build: null pointer");
   VO_REQUIRE(ctx, H > 0 && W > 0 && n_levels >= 1 && n_levels <= MAX_LEVELS, "pyramid_build: bad arguments");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -939,8 +993,8 @@ int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_
     const int blocks1_x = vo_cdiv(w1, 32), nA = blocks1_x * vo_cdiv(h1, 8);
     {
       vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
-      hipLaunchKernelGGL(pyramid3_kernel, dim3(nB + nA), dim3(256), 0, ctx->stream, d_img, H, W, d_pyr, pyr_pitch(W), d1,
-                         pyr_pitch(w1), h1, w1, d2, pyr_pitch(w2), h2, w2, nB, tiles2_x, blocks1_x);
+      hipLaunchKernelGGL(pyramid3_kernel, dim3(nB + nA, S), dim3(256), 0, ctx->stream, d_img, H, W, d_pyr, pyr_pitch(W), d1,
+                         pyr_pitch(w1), h1, w1, d2, pyr_pitch(w2), h2, w2, nB, tiles2_x, blocks1_x, img_stride, pyr_stride);
     }
     VO_TRY(vo_check_launch(ctx, "pyramid3_kernel"));
     first_plain = 3;
@@ -951,8 +1005,12 @@ int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_
     w = w2;
   } else {
     vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
-    hipLaunchKernelGGL(pad_reflect_kernel, dim3(vo_cdiv(W + 2 * PYR_PAD, 64), vo_cdiv(H + 2 * PYR_PAD, 4)), dim3(256), 0,
-                       ctx->stream, d_img, H, W, d_pyr, pyr_pitch(W));
+    hipLaunchKernelGGL(pad_reflect_kernel, dim3(vo_cdiv(W + 2 * PYR_PAD, 64), vo_cdiv(H + 2 * PYR_PAD, 4), S), dim3(256), 0,
+                       ctx->stream, d_img, H, W, d_pyr, pyr_pitch(W), img_stride, pyr_stride);
+    // (the next level reads the bordered copy of level 0, which lives in the sequence's pyramid buffer like every
+    //  other level: same pixels as the frame, one stride for source and destination)
+    src = d_pyr + (size_t)PYR_PAD * pyr_pitch(W) + PYR_PAD;
+    spitch = pyr_pitch(W);
   }
   VO_TRY(vo_check_launch(ctx, "pad_reflect_kernel"));
   for (int l = first_plain; l < n_levels; ++l) {
@@ -960,8 +1018,8 @@ int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_
     const int dpitch = pyr_pitch(wd);
     {
       vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
-      hipLaunchKernelGGL(pyr_down_kernel, dim3(vo_cdiv(wd + 2 * PYR_PAD, 64), vo_cdiv(hd + 2 * PYR_PAD, 4)), dim3(256), 0,
-                         ctx->stream, src, spitch, h, w, dst, dpitch, hd, wd);
+      hipLaunchKernelGGL(pyr_down_kernel, dim3(vo_cdiv(wd + 2 * PYR_PAD, 64), vo_cdiv(hd + 2 * PYR_PAD, 4), S), dim3(256), 0,
+                         ctx->stream, src, spitch, h, w, dst, dpitch, hd, wd, pyr_stride);
     }
     VO_TRY(vo_check_launch(ctx, "pyr_down_kernel"));
     src = dst + (size_t)PYR_PAD * dpitch + PYR_PAD;
@@ -972,6 +1030,8 @@ int vo_pyramid_build_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int n_
   }
   return VO_OK;
 }
+
+extern "C" {
 
 int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
                      const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N, int win,
@@ -986,9 +1046,11 @@ int vo_klt_track_dev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_p
 int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
                       const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N,
                       const int32_t* d_n, int win, int max_iter, double eps, double min_eig, float* d_next_xy,
-                      uint8_t* d_status, float* d_err, const vo_klt_source* src_in) {
+                      uint8_t* d_status, float* d_err, const vo_klt_source* src_in, const vo_klt_batch* batch) {
   if (!ctx) return VO_EINVAL;
   const vo_klt_source src = src_in ? *src_in : vo_klt_source();
+  const vo_klt_batch B = batch ? *batch : vo_klt_batch();
+  const int S = B.S > 0 ? B.S : 1;
   VO_REQUIRE(ctx, N >= 0, "klt_track: bad N");
   if (N == 0) return VO_OK;
   VO_REQUIRE(ctx, d_prev && d_next && d_prev_xy && d_next_xy && d_status && d_err, "klt_track: null pointer");
@@ -1026,22 +1088,22 @@ int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_
     const size_t lds = (size_t)lds_wave * KLT_WAVES;
     hipStream_t st = ctx->stream;
     const float me = (float)min_eig;
-    const dim3 kgrid(vo_cdiv(N, KLT_WAVES)), kblock(64 * KLT_WAVES);
+    const dim3 kgrid(vo_cdiv(N, KLT_WAVES), S), kblock(64 * KLT_WAVES);
     switch (win) {
       case 15:
-        hipLaunchKernelGGL((klt_track16_kernel<15, 16>), dim3(vo_cdiv(N, 4)), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<15, 16>), dim3(vo_cdiv(N, 4), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 17:   // the reference's default window (klt.py:29)
-        hipLaunchKernelGGL((klt_track16_kernel<17, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<17, 32>), dim3(vo_cdiv(N, 2), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 21:
-        hipLaunchKernelGGL((klt_track16_kernel<21, 32>), dim3(vo_cdiv(N, 2)), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, max_iter,
+        hipLaunchKernelGGL((klt_track16_kernel<21, 32>), dim3(vo_cdiv(N, 2), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B, max_iter,
                            eps * eps, me, d_next_xy, d_status, d_err);
         break;
       default:
-        hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, d_n, src, win, max_iter, eps * eps,
+        hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, d_n, src, B, win, max_iter, eps * eps,
                            me, d_next_xy, d_status, d_err, lds_wave);
     }
   }

@@ -427,9 +427,24 @@ __global__ __launch_bounds__(256) void p3p_hyp_kernel(const double* __restrict__
                                                       double* __restrict__ Rout, double* __restrict__ tout,
                                                       uint8_t* __restrict__ valid, int* __restrict__ counts,
                                                       unsigned long long* __restrict__ masks, int words,
-                                                      unsigned long long* __restrict__ ts_out) {
+                                                      unsigned long long* __restrict__ ts_out, vo_hyp_batch B) {
   __shared__ int s_cnt[4][HG];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (blockIdx.y != 0) {               // several sequences per launch: grid.y = sequence
+    const size_t q = blockIdx.y;
+    Xw += q * B.X;
+    xi += q * B.x;
+    raws += q * B.raws;
+    d_rawpos = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(d_rawpos) + q * B.ctl);
+    d_n = reinterpret_cast<const int*>(reinterpret_cast<const char*>(d_n) + q * B.ctl);
+    flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(flag) + q * B.ctl);
+    if (ts_out) ts_out = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ts_out) + q * B.ctl);
+    Rout += q * (size_t)Hyp * 9;
+    tout += q * (size_t)Hyp * 3;
+    valid += q * (size_t)Hyp;
+    counts += q * (size_t)Hyp;
+    if (masks) masks += q * (size_t)Hyp * words;
+  }
   if (ts_out && blockIdx.x == 0 && tid == 0) *ts_out = wall_clock64();
   const int N = *d_n;
   const int h0 = blockIdx.x * HG;
@@ -563,17 +578,19 @@ __global__ __launch_bounds__(256) void reproj_kernel(const double* __restrict__ 
 int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
                                const double* K, const uint32_t* d_raws, const uint64_t* d_rawpos, uint32_t raw_mask,
                                int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
-                               uint64_t* d_masks, uint32_t* d_flag, uint64_t* d_ts) {
+                               uint64_t* d_masks, uint32_t* d_flag, uint64_t* d_ts, const vo_hyp_batch* batch) {
   if (!ctx) return VO_EINVAL;
+  const vo_hyp_batch B = batch ? *batch : vo_hyp_batch();
+  const int S = B.S > 0 ? B.S : 1;
   VO_REQUIRE(ctx, d_X && d_x && d_n && K && d_raws && d_rawpos && d_R && d_t && d_valid && d_counts && d_flag,
              "p3p_hypotheses_ring: null pointer");
   VO_REQUIRE(ctx, n_cap >= 4 && Hyp >= 1, "p3p_hypotheses_ring: need n_cap >= 4 and Hyp >= 1");
   VO_REQUIRE(ctx, K[0] != 0.0 && K[4] != 0.0, "p3p_hypotheses_ring: singular intrinsics");
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
-    hipLaunchKernelGGL(p3p_hyp_kernel, dim3(vo_cdiv(Hyp, HG)), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
+    hipLaunchKernelGGL(p3p_hyp_kernel, dim3(vo_cdiv(Hyp, HG), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
                        (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], thr_sq, d_R,
-                       d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts);
+                       d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts, B);
   }
   return vo_check_launch(ctx, "p3p_hyp_kernel");
 }

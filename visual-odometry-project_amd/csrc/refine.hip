@@ -327,6 +327,17 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   __shared__ double s_w[RF_T / 64][RF_S];
   __shared__ double s_pose[12], s_try[12];
   __shared__ int s_state, s_cand[RF_T / 64];
+  if (blockIdx.x != 0) {               // several sequences per launch: one workgroup per sequence
+    const size_t q = blockIdx.x;
+    job.ctl += q;
+    job.rp.valid += q * (size_t)job.rp.hyp;
+    job.rp.counts += q * (size_t)job.rp.hyp;
+    job.rp.R += q * (size_t)job.rp.hyp * 9;
+    job.rp.t += q * (size_t)job.rp.hyp * 3;
+    job.rp.masks += q * (size_t)job.rp.hyp * job.rp.words;
+    job.rp.best_mask += q * (size_t)job.rp.words;
+    job.B = vo_feat_seq(job.B, q);
+  }
   vo_seq_ctl* ctl = job.ctl;
   if (threadIdx.x == 0) ctl->ts[3] = wall_clock64();
   if (ctl->fault) return;
@@ -424,13 +435,13 @@ int vo_refine_pose_ndev(vo_ctx* ctx, const double* d_X, const double* d_x, int N
   return vo_check_launch(ctx, "refine_pose_kernel");
 }
 
-int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job) {
+int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job, int S) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, job.ctl && job.B.land && job.B.kp64 && job.rp.best_mask, "frame_pose: null pointer");
   VO_REQUIRE(ctx, job.max_iter >= 0 && job.max_iter <= 100, "frame_pose: bad iteration limit");
   {
     vo_prof_scope ps(ctx, VO_K_REFINE);
-    hipLaunchKernelGGL(frame_pose_kernel, dim3(1), dim3(RF_T), 0, ctx->stream, job);
+    hipLaunchKernelGGL(frame_pose_kernel, dim3(S), dim3(RF_T), 0, ctx->stream, job);
   }
   return vo_check_launch(ctx, "frame_pose_kernel");
 }

@@ -208,6 +208,16 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
   __shared__ unsigned long long s_red[2][4];
   __shared__ int s_wcnt[3][4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (blockIdx.y != 0) {               // several sequences per launch: grid.y = sequence
+    const size_t q = blockIdx.y;
+    ctl += q;
+    A = vo_feat_seq(A, q);
+    B = vo_feat_seq(B, q);
+    next_xy += q * (size_t)cap * 2;
+    status += q * (size_t)cap;
+    err += q * (size_t)cap;
+    ap.det_kp += q * ap.det_stride;
+  }
   if (blockIdx.x == 0 && tid == 0) {
     ctl->ts[1] = wall_clock64();
     ctl->ts[6] = ctl->ts[0];          // this step's tracker start (the next step's tracker overwrites ts[0] meanwhile)
@@ -368,6 +378,15 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
   __shared__ int s_cnt[2];
   __shared__ int s_last;
   const int tid = threadIdx.x;
+  if (blockIdx.y != 0) {               // several sequences per launch: grid.y = sequence
+    const size_t q = blockIdx.y;
+    ctl += q;
+    B = vo_feat_seq(B, q);
+    if (res) {
+      res += q;
+      seq_word += q;
+    }
+  }
   if (blockIdx.x == 0 && tid == 0) ctl->ts[4] = wall_clock64();
   const int fault = ctl->fault;
   if (fault) {
@@ -496,10 +515,10 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
 }  // namespace
 
 int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const float* d_next_xy,
-                         const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap) {
+                         const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap, int S) {
   {
     vo_prof_scope ps(ctx, VO_K_STATE_REGROUP);
-    hipLaunchKernelGGL(state_regroup_klt_kernel, dim3(vo_cdiv(cap, 256)), dim3(256), 0, ctx->stream, ctl, A, B, d_next_xy,
+    hipLaunchKernelGGL(state_regroup_klt_kernel, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, A, B, d_next_xy,
                        d_status, d_err, err_thr, ap, cap);
   }
   return vo_check_launch(ctx, "state_regroup_klt_kernel");
@@ -527,10 +546,10 @@ int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t*
 }
 
 int vo_state_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, vo_cam cam, int use_refined, int cap,
-                       vo_step_result* m_result, unsigned* m_seq, unsigned seq) {
+                       vo_step_result* m_result, unsigned* m_seq, unsigned seq, int S) {
   {
     vo_prof_scope ps(ctx, VO_K_STATE_LANDMARKS);
-    hipLaunchKernelGGL(state_landmarks_kernel, dim3(vo_cdiv(cap, 256)), dim3(256), 0, ctx->stream, ctl, B, cam,
+    hipLaunchKernelGGL(state_landmarks_kernel, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, B, cam,
                        use_refined, m_result, m_seq, seq);
   }
   return vo_check_launch(ctx, "state_landmarks_kernel");

@@ -50,6 +50,7 @@ struct vo_ctx {
   vo_buf nms_hist, nms_ctl, nms_sel, nms_cand, nms_alive, nms_segcnt, nms_rank;
   bool nms_alive_dirty = false;
   int nms_parity = 0;            // NMS calls alternate between two histograms (the idle one is cleared meanwhile)
+  int nms_S = 0;                 // sequences per launch of the last NMS call (the histograms' layout depends on it)
   float* nms_kp_f32 = nullptr;   // optional: the NMS also writes its keypoints as float pairs here (device)
   vo_buf scratch[16];
   vo_buf sift_arena;
@@ -102,10 +103,17 @@ static inline int vo_cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---- internal entry points shared between translation units (not part of the C ABI) ----
 // P3P hypotheses + inlier counts of the frame loop (p3p.hip): sample indices derived on the device from raw
 // generator outputs in a ring, population size and stream position read on the device.
+struct vo_hyp_batch {     // several sequences per launch (grid.y = sequence); the output arrays are S blocks of Hyp entries
+  int S = 1;
+  size_t X = 0, x = 0;    // doubles between the sequences' landmark / keypoint arrays
+  size_t raws = 0;        // words between their generator rings
+  size_t ctl = 0;         // bytes between their control blocks (d_n, d_rawpos, d_flag, d_ts point into them)
+};
 int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x, const int32_t* d_n, int n_cap,
                                const double* K, const uint32_t* d_raws, const uint64_t* d_rawpos, uint32_t raw_mask,
                                int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
-                               uint64_t* d_masks, uint32_t* d_flag, uint64_t* d_ts = nullptr);
+                               uint64_t* d_masks, uint32_t* d_flag, uint64_t* d_ts = nullptr,
+                               const vo_hyp_batch* batch = nullptr);
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
 void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
 // DLT with a device-resident point count (dlt.hip)
@@ -126,7 +134,25 @@ struct vo_klt_source {
   int n_det = 0;
   unsigned long long* ts = nullptr;   // (optional) receives wall_clock64() when the kernel's first work item starts
 };
+// several sequences per launch (grid.y = sequence): element strides from one sequence's block to the next
+struct vo_klt_batch {
+  int S = 1;
+  size_t pyr = 0;      // bytes between the sequences' pyramid buffers (same for prev and next)
+  size_t xy = 0;       // floats between their keypoint arrays (prev_xy and next_xy)
+  size_t out = 0;      // elements between their status / err arrays
+  size_t ctl = 0;      // bytes between their control blocks (vo_klt_source.n / num_features / ts point into them)
+  size_t det = 0;      // doubles between their detector keypoint lists
+};
 int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_pyr, const uint8_t* d_next,
                       const uint8_t* d_next_pyr, int H, int W, int n_levels, const float* d_prev_xy, int N,
                       const int32_t* d_n, int win, int max_iter, double eps, double min_eig, float* d_next_xy,
-                      uint8_t* d_status, float* d_err, const vo_klt_source* src = nullptr);
+                      uint8_t* d_status, float* d_err, const vo_klt_source* src = nullptr,
+                      const vo_klt_batch* batch = nullptr);
+int vo_pyramid_build_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_stride, int S, int H, int W, int n_levels,
+                               uint8_t* d_pyr, size_t pyr_stride);
+// Several sequences per launch (harris.hip): S images at d_img + s * img_stride -> S score maps at d_scores + s * H * W;
+// S score maps -> S keypoint lists at d_kp_xy + s * kp_stride (doubles).  S = 1 is what the C ABI's _dev forms call.
+int vo_harris_response_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_stride, int S, int H, int W, int patch,
+                                 double kappa, double* d_scores);
+int vo_nms_keypoints_batch_dev(vo_ctx* ctx, const double* d_scores, int S, int H, int W, int N, int r, double* d_kp_xy,
+                               size_t kp_stride);

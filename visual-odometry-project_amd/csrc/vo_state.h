@@ -23,6 +23,20 @@ struct vo_feat {
   int pitch;         // = capacity
 };
 
+// Several sequences per launch: every array of a vo_feat holds S consecutive per-sequence blocks of `pitch`
+// features; block q of each array:
+__host__ __device__ inline vo_feat vo_feat_seq(vo_feat F, size_t q) {
+  const size_t n = q * (size_t)F.pitch;
+  F.kp += 2 * n;
+  F.kp64 += 2 * n;
+  F.state += n;
+  F.cand += n;
+  F.land += 3 * n;
+  F.track += 2 * n;
+  F.pose += 12 * n;
+  return F;
+}
+
 enum {
   VO_FAULT_FEW_LANDMARKS = 1,   // fewer than 8 triangulated tracks: the device-side sampler does not apply
   VO_FAULT_RISKY_DRAW = 2,      // a bounded draw inside the consumed prefix could have been rejected by NumPy
@@ -68,6 +82,7 @@ struct vo_cam {
 // the tracker and the regroup kernel treat the detector's keypoints of the old frame as features n .. n+n_det-1.
 struct vo_append {
   const double* det_kp;     // n_det x 2 (device)
+  size_t det_stride;        // doubles between the sequences' detector lists (several sequences per launch)
   int n_det;
   double frac;
   int pose_mode;            // vo_pipeline_config.redetect_start_pose
@@ -98,13 +113,13 @@ struct vo_pose_job {
   double bearing_thr;
   int max_iter;         // Gauss-Newton steps allowed; 0 = refinement off
 };
-int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job);
+int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job, int S = 1);   // S > 1: sequence q uses block q of every array
 
 // ---- launches (state.hip); all asynchronous on ctx->stream ----
 // klt.py:207-230 + 244-278 + matches.py:26-212: (virtual) re-detect append, keep status & err < thr, then the
 // 4-group regroup of the new frame
 int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const float* d_next_xy,
-                         const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap);
+                         const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap, int S = 1);
 // matches.py:26-212 for an explicit match list (harris / sift trackers, tests)
 int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const int32_t* d_pairs, int M,
                            const double* d_new_kp, int n2_in, int cap);
@@ -114,7 +129,7 @@ int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t*
 // main.py:279-286 + triangulation.py:38-86 + state.py:69-107: candidate triangulation, landmark insertion,
 // cheirality check, step bookkeeping and the result record
 int vo_state_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, vo_cam cam, int use_refined, int cap,
-                       vo_step_result* m_result, unsigned* m_seq, unsigned seq);
+                       vo_step_result* m_result, unsigned* m_seq, unsigned seq, int S = 1);
 // n_iterations for an outlier ratio through the threshold table (host copy of the device lookup; tests)
 int64_t vo_ransac_table_lookup(const double* table, int table_len, int64_t max_iterations, double outlier_ratio);
 void vo_ransac_build_table(double confidence, int s, int table_len, double* table);

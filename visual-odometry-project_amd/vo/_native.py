@@ -107,6 +107,7 @@ _SIGS = {
     "vo_harris_response": (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),
     "vo_harris_keypoints": (_i, [_vp, _vp, _i, _i, _i, _d, _i, _i, _vp, _vp]),
     "vo_nms_keypoints": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vo_harris_keypoints_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _d, _i, _i, _vp, _vp]),
     "vo_harris_response_dev": (_i, [_vp, _vp, _i, _i, _i, _d, _vp]),
     "vo_nms_keypoints_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vo_patch_descriptors": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp]),
@@ -284,6 +285,17 @@ class Context:
         sc = np.empty((H, W), np.float64) if want_scores else None
         self._chk(self._lib.vo_harris_keypoints(self._h, _ptr(img), H, W, int(patch), float(kappa),
                                                 int(num_keypoints), int(r), _ptr(kp), _ptr(sc)))
+        return (kp, sc) if want_scores else kp
+
+    def harris_keypoints_batch(self, imgs, patch=9, kappa=0.09, num_keypoints=1000, r=5, want_scores=False):
+        """(S, H, W) uint8 -> (S, N, 2) keypoints [, (S, H, W) score maps]: S frames in one set of launches."""
+        imgs = _c(imgs, np.uint8)
+        assert imgs.ndim == 3
+        S, H, W = imgs.shape
+        kp = np.empty((S, num_keypoints, 2), np.float64)
+        sc = np.empty((S, H, W), np.float64) if want_scores else None
+        self._chk(self._lib.vo_harris_keypoints_batch(self._h, _ptr(imgs), S, H, W, int(patch), float(kappa),
+                                                      int(num_keypoints), int(r), _ptr(kp), _ptr(sc)))
         return (kp, sc) if want_scores else kp
 
     def nms_keypoints(self, scores, num_keypoints, r):
