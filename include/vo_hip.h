@@ -317,6 +317,11 @@ typedef struct vo_pipeline_config {
                                     update_features writes it (klt.py:148-153) -- away from the origin such
                                     tracks triangulate against the wrong baseline; 1 = the current pose,
                                     what State.reset_outliers gives a restarted track (state.py:170-172) */
+  int32_t sequences;             /* S independent frame streams advancing in lock step through the same
+                                    launches (the sequence is the grid's extra dimension; SURVEY.md 8e: streams
+                                    are independent, so they batch).  0 = 1.  Every sequence has its own frame
+                                    store, Features, State, RANSAC object and generator; the plain entry points
+                                    address sequence 0, the _seq forms any of them.                      */
 } vo_pipeline_config;
 typedef struct vo_step_result {
   double R[9], t[3];            /* world -> camera pose of `next` (best hypothesis)   */
@@ -355,7 +360,8 @@ int vo_pipeline_get_rng(vo_pipeline* p, vo_pcg64* rng);      /* estimator genera
  * n*3, tracks n*2, poses n*16 (4x4 row-major, camera-to-world; NaN rows where the reference holds
  * NaN) -- plus curr / prev pose as 4x4 camera-to-world AND world-to-camera matrices (the
  * reference forms the latter with np.linalg.inv; passing both keeps every later product the
- * same), and KLTTracker._num_features.  Builds the pyramid and runs the detector on frame idx.  */
+ * same), and KLTTracker._num_features.  The pyramid and the detector's keypoints of frame idx are
+ * made by the first submit after it.                                                            */
 int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, const uint8_t* state,
                           const double* landmarks, const double* tracks, const double* poses,
                           const double* T_wc, const double* T_cw, const double* T_wc_prev,
@@ -395,10 +401,28 @@ int vo_pipeline_prof_reset(vo_pipeline* p);
  *          posted so far, and records posted after the call are written after everything
  *          `consumer` held at the time of the call (an exchange still reading the buffer).   */
 int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record);
+int vo_pipeline_export_state_post_seq(vo_pipeline* p, int seq, const vo_step_result* r, int cap, double* d_record);
 int vo_pipeline_export_state_join(vo_pipeline* p, void* consumer);
 /* the ransac.py:58-67 iteration bound through the pipeline's threshold table (what the device
  * evaluates); equals vo_ransac_num_iterations clipped to max_iterations                         */
 int64_t vo_pipeline_ransac_bound(vo_pipeline* p, double outlier_ratio);
+/* Several sequences per pipeline (vo_pipeline_config.sequences = S): the sequences step together --
+ * vo_pipeline_submit enqueues frame slot prev_idx -> next_idx of EVERY sequence in one set of launches,
+ * vo_pipeline_collect_all waits for all S records (outs: S entries; vo_pipeline_collect returns sequence
+ * 0's).  A sequence whose step leaves the device-only path is redone alone through the host path; the
+ * others are not held up on the device.  vo_pipeline_seed gives every sequence's estimator the same
+ * generator state (each then advances by its own draws).                                        */
+int vo_pipeline_sequences(vo_pipeline* p);
+int vo_pipeline_set_frame_seq(vo_pipeline* p, int seq, int idx, const uint8_t* img);
+int vo_pipeline_set_state_seq(vo_pipeline* p, int seq, int idx, int n, const double* kp, const uint8_t* state,
+                              const double* landmarks, const double* tracks, const double* poses,
+                              const double* T_wc, const double* T_cw, const double* T_wc_prev,
+                              const double* T_cw_prev, int num_features);
+int vo_pipeline_get_state_seq(vo_pipeline* p, int seq, int32_t* n_out, double* kp, uint8_t* state,
+                              uint8_t* candidate_mask, double* landmarks, double* tracks, double* poses,
+                              double* T_wc, double* T_wc_prev, vo_ransac_state* rs, int32_t* num_features);
+int vo_pipeline_get_rng_seq(vo_pipeline* p, int seq, vo_pcg64* rng);
+int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs);
 
 #ifdef __cplusplus
 }

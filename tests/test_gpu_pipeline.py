@@ -171,6 +171,69 @@ def test_pipeline_lookahead_and_host_recovery_match_blocking_steps(ctx):
             assert np.array_equal(st[k], st_ref[k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("lookahead,fault_every", [(False, 0), (True, 0), (True, 4)])
+def test_several_sequences_per_launch_equal_single_sequence_pipelines(ctx, lookahead, fault_every):
+    """vo_pipeline_config.sequences = S: S independent streams (different scenes, different starting feature
+    sets -- one of them below the re-detect limit) advance through the same launches.  Every record, every
+    carried array and every estimator generator must equal what S one-sequence pipelines give -- also when
+    steps are forced through the host path, where a sequence is redone alone while the others go on."""
+    from vo import synthetic
+    H, W, N, hyp, F, S = 240, 320, 300, 256, 5, 3
+    streams = [synthetic.Stream(F, H, W, seed=2023 + 7 * q, start=q) for q in range(S)]
+    starts = [start_state(streams[q], N, (1.0, 0.85, 0.7)[q]) for q in range(S)]
+    order = streams[0].order(9)
+    pairs = list(zip(order[:-1], order[1:]))
+
+    def finish(pipe, q):
+        g = np.random.default_rng(0)
+        pipe.rng_state_into(g, seq=q)
+        return pipe.get_state(seq=q), g.bit_generator.state
+
+    single = []
+    for q in range(S):
+        pipe = make_pipe(ctx, streams[q], N, hyp)
+        pipe.set_state(0, starts[q][0], starts[q][1], starts[q][1])
+        res = run_all(pipe, pairs, False)
+        single.append((res,) + finish(pipe, 0))
+        pipe.close()
+    assert any(r.redetected for r in single[2][0]), "one sequence was meant to re-detect"
+
+    from vo import _native
+    pipe = _native.Pipeline(ctx, H, W, F, streams[0].K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp,
+                            p3p_threshold=1.0, max_iterations=1000, refine_iters=20, sequences=S,
+                            debug_fault_every=fault_every)
+    for q in range(S):
+        for i in range(F):
+            pipe.set_frame(i, streams[q].image(i), seq=q)
+        pipe.set_state(0, starts[q][0], starts[q][1], starts[q][1], seq=q)
+    got = []
+    if lookahead:
+        pipe.submit(*pairs[0])
+        for k in range(len(pairs)):
+            if k + 1 < len(pairs):
+                pipe.submit(*pairs[k + 1])
+            got.append(pipe.collect_all())
+    else:
+        for a, b in pairs:
+            pipe.submit(a, b)
+            got.append(pipe.collect_all())
+    for q in range(S):
+        res, st_ref, g_ref = single[q]
+        for k in range(len(pairs)):
+            fa, fb = fields(got[k][q]), fields(res[k])
+            assert fa == fb, ("sequence", q, "step", k, [(i, fa[i], fb[i]) for i in range(len(fa)) if fa[i] != fb[i]][:3])
+        if fault_every:
+            # forced: steps 3 and 7; a step may also leave the device-only path by itself (it then does in the
+            # one-sequence run too)
+            for k in range(len(pairs)):
+                assert got[k][q].recovered == (1 if k % fault_every == fault_every - 1 else res[k].recovered), (q, k)
+        st, g = finish(pipe, q)
+        assert g == g_ref
+        for key in ("keypoints", "state", "candidate_mask", "landmarks", "tracks", "poses", "curr_pose", "n_iterations"):
+            assert np.array_equal(st[key], st_ref[key], equal_nan=True), (q, key)
+    pipe.close()
+
+
 def test_pipeline_at_configuration_size(ctx):
     """BASELINE.json configs[1] as a pipeline: 1376x1241, 2000 keypoints, 3-level 15x15 KLT, 1000 hypotheses,
     look-ahead AND device refinement, against the oracle loop on the same frames."""

@@ -3,16 +3,22 @@
 // State / RANSAC bookkeeping living in HBM (state.hip).  See include/vo_hip.h for the stage list.
 //
 // Streams of one step (frame k-1 -> k):
-//   main  : append(re-detect) -> KLT -> regroup -> P3P solve -> score -> RANSAC replay -> refine -> update
-//   pyr   : pyramid(k)                      (the tracker of this step waits for its event)
-//   det[] : Harris response + NMS on k      (two streams, alternating; consumed by the NEXT step's append)
+//   main   : regroup -> hypotheses+counts -> replay+refine+candidates -> landmarks+record
+//   tracker: pyramid(k) -> KLT(k)           needs regroup(k-1) only: runs beside the pose estimation of step k-1
+//   detect : Harris response + NMS on k     (enqueued by a worker thread; consumed by the NEXT step's re-detect)
 // Nothing on the main stream waits for the host: counts, the generator position, the accepted pose and
 // the inlier mask are words in HBM that the next kernel reads.  The host only enqueues (at most two
 // steps ahead: frame buffers rotate over three slots) and reads each step's result record from mapped
 // memory.  The rare step the device cannot finish alone (a bounded draw NumPy might have rejected, fewer
 // than 8 landmarks, the sequential rule not done after `hyp` samples) raises a sticky fault word: every
-// later kernel leaves the state untouched, and vo_pipeline_collect redoes that step with the sequential
-// host sampler (recover_step) before re-enqueueing what was behind it.
+// later kernel leaves that sequence's state untouched, and vo_pipeline_collect redoes the step with the
+// sequential host sampler (recover_step) before re-enqueueing what was behind it.
+//
+// Several sequences per GPU (vo_pipeline_config.sequences = S): S independent streams advance in lock
+// step through the SAME launches -- every per-sequence buffer is S consecutive blocks, the sequence is
+// the grid's extra dimension of every kernel.  The chain is latency-bound at one sequence
+// (single-workgroup kernels, 127 us per step with the chip almost empty); S sequences cost about the same
+// wall time per step until the image-wide kernels fill the chip.
 #include <time.h>
 
 #include <atomic>
@@ -26,49 +32,44 @@
 
 struct vo_pipeline {
   vo_ctx* ctx = nullptr;
-  vo_ctx* det[2] = {nullptr, nullptr};
-  vo_ctx* pyr = nullptr;             // (= trk)
-  vo_ctx* trk = nullptr;             // the tracker's stream: KLT of step k+1 runs beside the pose estimation of step k
+  vo_ctx* det = nullptr;             // detection stream (+ the NMS workspace of all sequences)
+  vo_ctx* trk = nullptr;             // tracker stream: pyramid and KLT of step k+1 run beside the pose estimation of step k
   hipEvent_t evKlt[2] = {nullptr, nullptr}, evRegroup[2] = {nullptr, nullptr};
   vo_pipeline_config cfg;
   vo_cam cam;
-  int n_levels = 1, cap = 0, words = 0;
-  size_t pyr_bytes = 0;
-  std::vector<uint8_t*> d_img;
-  // per-frame slots (frame count mod 3)
-  uint8_t* d_pyr[3] = {nullptr, nullptr, nullptr};
-  double* d_kp[3] = {nullptr, nullptr, nullptr};
-  float* d_kp_f32[3] = {nullptr, nullptr, nullptr};
-  double* d_scores[2] = {nullptr, nullptr};
+  int n_levels = 1, cap = 0, words = 0, S = 1;
+  size_t px = 0, pyr_bytes = 0;
+  // ---- per-sequence buffers: S consecutive blocks each ----
+  uint8_t* d_img = nullptr;          // [S][n_frames][px]
+  uint8_t* d_pyr = nullptr;          // [S][3][pyr_bytes]      (frame count mod 3)
+  double* d_kp = nullptr;            // [S][3][N * 2]          detector output per frame slot
+  double* d_scores[2] = {nullptr, nullptr};   // [S][px] each, alternating between consecutive detections
   hipEvent_t evPyr[3] = {nullptr, nullptr, nullptr}, evDet[3] = {nullptr, nullptr, nullptr};
   int slot = 0, det_flip = 0, prev_frame = -1;
   // Features double buffer: a step reads F[cur] (frame k-1) and writes F[1 - cur] (frame k)
   vo_feat F[2];
   void* feat_mem = nullptr;
   int cur = 0;
-  vo_seq_ctl* d_ctl = nullptr;
-  // tracker outputs
-  float *d_next = nullptr, *d_err = nullptr;
+  vo_seq_ctl* d_ctl = nullptr;       // [S]
+  float *d_next = nullptr, *d_err = nullptr;   // [S][cap * 2], [S][cap]
   uint8_t* d_status = nullptr;
-  // hypotheses
-  double *d_R = nullptr, *d_t = nullptr;
+  double *d_R = nullptr, *d_t = nullptr;       // [S][hyp * 9], [S][hyp * 3]
   uint8_t* d_valid = nullptr;
   int32_t *d_counts = nullptr, *d_samples = nullptr;
   uint64_t *d_masks = nullptr, *d_best_mask = nullptr;
   double* d_table = nullptr;
   std::vector<double> table;
   int table_len = 0;
-  // generator outputs: a power-of-two ring in HBM the host keeps filled ahead of the device
-  uint32_t* d_raws = nullptr;
+  // generator outputs: one power-of-two ring per sequence in HBM, kept filled ahead of the device by the host
+  uint32_t* d_raws = nullptr;        // [S][ring_len]
   uint32_t ring_len = 0;
   uint32_t* h_stage = nullptr;
   size_t stage_cap = 0;
-  uint64_t gen_upto = 0, pos_known = 0;
-  uint64_t pos_known_floor = 0;      // lower bound a fresh record's generator position must respect (wait_record)
-  vo_pcg64 raw_gen, rng;
+  std::vector<uint64_t> gen_upto, pos_known;
+  std::vector<vo_pcg64> raw_gen, rng;
   hipEvent_t evRaw = nullptr;
-  bool raw_pending = false, seeded = false, have_state = false;
-  // results: records in mapped host memory, one per step in flight (4 slots)
+  bool raw_pending = false, seeded = false, have_state = false, primed = false;
+  // results: records in mapped host memory, [4 slots][S]
   vo_step_result *h_res = nullptr, *m_res = nullptr;
   volatile unsigned* h_seq = nullptr;
   unsigned* m_seq = nullptr;
@@ -77,25 +78,34 @@ struct vo_pipeline {
   flight_t flight[2];
   int n_flight = 0;
   long steps_submitted = 0;
-  // last collected step (shared-map record)
+  std::vector<unsigned> slot_seq;    // [4][S]: the number sequence q's record in result slot r will carry
+  std::vector<char> seq_state;       // [S]: a state was handed over before (the RANSAC object persists, ransac.py:47-56)
   int last_fbuf = 0;
   hipEvent_t evA = nullptr, evB = nullptr;
-  // scratch for the bookkeeping entry point
-  double* d_newkp = nullptr;
+  double* d_newkp = nullptr;         // scratch of the bookkeeping entry point
   int32_t* d_pairs = nullptr;
   long n_recovered = 0;
   // Detection worker: a second host thread enqueues the detection of every step (6 launches) while the caller's
-  // thread enqueues pyramid, tracker and the main-stream chain (7 launches): ~14 launches and half a dozen event
+  // thread enqueues pyramid, tracker and the main-stream chain (6 launches): a dozen launches and half a dozen event
   // calls per step cost one thread 70-150 us on a loaded host, more than the GPU needs for the step.
   std::thread worker;
   std::atomic<unsigned> job_posted{0}, job_done{0};
   std::atomic<bool> quit{false};
-  struct job_t { flight_t f; bool pyramid, detection; };
-  job_t jobs[4];
+  flight_t jobs[4];
   int worker_rc = 0;
   double dbg_part[4] = {0, 0, 0, 0};   // VO_DEBUG_TIMING: submit split into worker wait / tracker / raws / chain
-  double dbg_submit = 0, dbg_wait = 0;   // VO_DEBUG_TIMING: host seconds inside submit / waiting for records
+  double dbg_submit = 0, dbg_wait = 0;
   long dbg_steps = 0;
+
+  // block q of the per-sequence arrays
+  uint8_t* img(int q, int idx) const { return d_img + ((size_t)q * cfg.n_frames + idx) * px; }
+  size_t img_stride() const { return (size_t)cfg.n_frames * px; }
+  uint8_t* pyr(int q, int s) const { return d_pyr + ((size_t)q * 3 + s) * pyr_bytes; }
+  size_t pyr_stride() const { return 3 * pyr_bytes; }
+  double* kp(int q, int s) const { return d_kp + ((size_t)q * 3 + s) * cfg.n_keypoints * 2; }
+  size_t det_stride() const { return (size_t)3 * cfg.n_keypoints * 2; }
+  vo_step_result* res_h(int rslot, int q) const { return h_res + (size_t)rslot * S + q; }
+  volatile unsigned* seq_h(int rslot, int q) const { return h_seq + (size_t)rslot * S + q; }
 };
 
 namespace {
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(256) void export_state_kernel(pose17 head, const do
 template <typename T>
 int dev_alloc(vo_ctx* ctx, T** p, size_t count) {
   hipError_t e = hipMalloc((void**)p, count * sizeof(T) ? count * sizeof(T) : 256);
-  if (e != hipSuccess) return vo_set_error(ctx, VO_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return vo_set_error(ctx, VO_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
   return VO_OK;
 }
 
@@ -161,11 +171,12 @@ void expand_pose(const double* p12, double* p16) {
   }
 }
 
-vo_feat carve(char*& q, int cap) {
+// one Features buffer for S sequences of `cap` features: every array S * cap entries
+vo_feat carve(char*& q, int cap, int S) {
   vo_feat f;
   auto take = [&](size_t bytes) {
     void* r = q;
-    q += (bytes + 255) & ~size_t(255);
+    q += (bytes * S + 255) & ~size_t(255);
     return r;
   };
   f.kp = (float*)take((size_t)cap * 8);
@@ -179,14 +190,14 @@ vo_feat carve(char*& q, int cap) {
   return f;
 }
 
-size_t feat_bytes(int cap) {
+size_t feat_bytes(int cap, int S) {
   char* q = nullptr;
-  carve(q, cap);
+  carve(q, cap, S);
   return (size_t)(q - (char*)nullptr);
 }
 
 void sync_prof(vo_pipeline* p) {
-  for (vo_ctx* q : {p->det[0], p->trk}) {
+  for (vo_ctx* q : {p->det, p->trk}) {
     q->prof_on = p->ctx->prof_on;
     q->prof_kernel = p->ctx->prof_kernel;
     q->prof_every = p->ctx->prof_every;
@@ -205,20 +216,17 @@ size_t vo_pyramid_bytes(int H, int W, int n_levels);
 void vo_pipeline_destroy(vo_pipeline* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
-  if (p->worker.joinable()) {          // the worker first: it enqueues on the side streams
+  if (p->worker.joinable()) {          // the worker first: it enqueues on the detection stream
     p->quit.store(true, std::memory_order_release);
     p->worker.join();
   }
   // every stream next: nothing may still read what is freed below
   (void)hipStreamSynchronize(p->ctx->stream);
-  for (vo_ctx* q : {p->det[0], p->trk})
+  for (vo_ctx* q : {p->det, p->trk})
     if (q) (void)hipStreamSynchronize(q->stream);
-  for (auto q : p->d_img)
-    if (q) (void)hipFree(q);
-  void* dev[] = {p->d_pyr[0], p->d_pyr[1], p->d_pyr[2], p->d_kp[0], p->d_kp[1], p->d_kp[2], p->d_kp_f32[0], p->d_kp_f32[1],
-                 p->d_kp_f32[2], p->d_scores[0], p->d_scores[1], p->feat_mem, p->d_ctl, p->d_next, p->d_err, p->d_status,
-                 p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_samples, p->d_masks, p->d_best_mask, p->d_table, p->d_raws,
-                 p->d_newkp, p->d_pairs};
+  void* dev[] = {p->d_img, p->d_pyr, p->d_kp, p->d_scores[0], p->d_scores[1], p->feat_mem, p->d_ctl, p->d_next, p->d_err,
+                 p->d_status, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_samples, p->d_masks, p->d_best_mask, p->d_table,
+                 p->d_raws, p->d_newkp, p->d_pairs};
   for (void* q : dev)
     if (q) (void)hipFree(q);
   void* pin[] = {p->h_stage, p->h_res, (void*)p->h_seq};
@@ -227,12 +235,12 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   for (hipEvent_t e : {p->evPyr[0], p->evPyr[1], p->evPyr[2], p->evDet[0], p->evDet[1], p->evDet[2], p->evRaw, p->evA, p->evB,
                        p->evKlt[0], p->evKlt[1], p->evRegroup[0], p->evRegroup[1]})
     if (e) (void)hipEventDestroy(e);
-  for (vo_ctx* q : {p->det[0], p->trk})
+  for (vo_ctx* q : {p->det, p->trk})
     if (q) vo_destroy(q);
   if (getenv("VO_DEBUG_TIMING") && p->dbg_steps > 0)
-    fprintf(stderr, "[vo_pipeline] %ld steps: host %.1f us enqueueing (worker wait %.1f, tracker %.1f, raws %.1f, chain %.1f), "
-            "%.1f us waiting per step; %ld finished through the host path\n",
-            p->dbg_steps, 1e6 * p->dbg_submit / p->dbg_steps, 1e6 * p->dbg_part[0] / p->dbg_steps,
+    fprintf(stderr, "[vo_pipeline] %ld steps x %d sequence(s): host %.1f us enqueueing (worker wait %.1f, tracker %.1f, raws %.1f, "
+            "chain %.1f), %.1f us waiting per step; %ld finished through the host path\n",
+            p->dbg_steps, p->S, 1e6 * p->dbg_submit / p->dbg_steps, 1e6 * p->dbg_part[0] / p->dbg_steps,
             1e6 * p->dbg_part[1] / p->dbg_steps, 1e6 * p->dbg_part[2] / p->dbg_steps, 1e6 * p->dbg_part[3] / p->dbg_steps,
             1e6 * p->dbg_wait / p->dbg_steps, p->n_recovered);
   delete p;
@@ -246,6 +254,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   VO_REQUIRE(ctx, cfg->hyp >= 1 && cfg->hyp <= (1 << 20), "pipeline: hyp must be in 1..2^20");
   VO_REQUIRE(ctx, cfg->K[0] != 0.0 && cfg->K[4] != 0.0, "pipeline: singular intrinsics");
   VO_REQUIRE(ctx, cfg->refine_iters >= 0 && cfg->refine_iters <= 100, "pipeline: refine_iters must be in 0..100");
+  VO_REQUIRE(ctx, cfg->sequences >= 0 && cfg->sequences <= 256, "pipeline: sequences must be in 1..256");
   const int cap = cfg->feature_cap > 0 ? cfg->feature_cap : 2 * cfg->n_keypoints;
   VO_REQUIRE(ctx, cap >= cfg->n_keypoints && cap <= 32768, "pipeline: feature_cap must be in n_keypoints..32768");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -255,6 +264,9 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   p->cfg = *cfg;
   p->cap = cap;
   p->words = vo_cdiv(cap, 64);
+  p->S = cfg->sequences > 0 ? cfg->sequences : 1;
+  p->cfg.sequences = p->S;
+  const int S = p->S;
   if (p->cfg.bearing_threshold == 0.0) p->cfg.bearing_threshold = 0.0075;    // state.py:8
   if (p->cfg.redetect_fraction == 0.0) p->cfg.redetect_fraction = 0.8;       // klt.py:212
   memcpy(p->cam.K, cfg->K, sizeof(p->cam.K));
@@ -270,55 +282,49 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     }
   }
   int rc = VO_OK;
-  if (vo_create(ctx->device, nullptr, &p->det[0]) != VO_OK || vo_create(ctx->device, nullptr, &p->trk) != VO_OK)
+  // Three streams -- main (the caller's), tracker, detection -- plus the null stream (the caller's synchronous
+  // copies, torch): the runtime spreads streams over four hardware queues and kernels of one queue run in order.
+  // A fifth stream shares a queue: with two detection streams the second sat on the tracker's queue and delayed
+  // it every other frame (rocprofv3 trace, same queue id; 8.2k vs 5.1k frames/s run to run).  Hence the next
+  // frame's pyramid on the tracker's stream, one detection stream, no hipMemcpy in here.
+  if (vo_create(ctx->device, nullptr, &p->det) != VO_OK || vo_create(ctx->device, nullptr, &p->trk) != VO_OK)
     rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
-  // The next frame's pyramid is built on the tracker's stream, in front of the tracker that needs it: four streams
-  // in all (main, tracker, two detection streams), one hardware queue each -- with a fifth stream two of them share a
-  // queue and run in order, and which two depends on creation order (measured: 8.2k vs 5.1k frames/s run to run).
-  // ... and ONE detection stream: the runtime spreads streams over four hardware queues, the null stream (the
-  // caller's synchronous copies, torch) holds one of them, and kernels of one queue run in order -- with two
-  // detection streams the second shared a queue with the tracker and delayed it every other frame (rocprofv3 trace).
-  p->pyr = p->trk;
-  p->det[1] = p->det[0];
   const int N = cfg->n_keypoints, Hyp = cfg->hyp;
-  const size_t px = (size_t)cfg->H * cfg->W;
+  const size_t px = (size_t)cfg->H * cfg->W, Sz = (size_t)S;
+  p->px = px;
   p->n_levels = vo_klt_num_levels(cfg->H, cfg->W, cfg->klt_win, cfg->klt_max_level);
   p->pyr_bytes = vo_pyramid_bytes(cfg->H, cfg->W, p->n_levels);
-  p->d_img.assign(cfg->n_frames, nullptr);
 #define PA(expr) do { if (rc == VO_OK) rc = (expr); } while (0)
-  for (int f = 0; f < cfg->n_frames; ++f) PA(dev_alloc(ctx, &p->d_img[f], px));
-  for (int k = 0; k < 3; ++k) {
-    PA(dev_alloc(ctx, &p->d_pyr[k], p->pyr_bytes));
-    PA(dev_alloc(ctx, &p->d_kp[k], (size_t)N * 2));
-    PA(dev_alloc(ctx, &p->d_kp_f32[k], (size_t)N * 2));
-  }
-  PA(dev_alloc(ctx, &p->d_scores[0], px));
-  PA(dev_alloc(ctx, &p->d_scores[1], px));
+  PA(dev_alloc(ctx, &p->d_img, Sz * cfg->n_frames * px));
+  PA(dev_alloc(ctx, &p->d_pyr, Sz * 3 * p->pyr_bytes));
+  PA(dev_alloc(ctx, &p->d_kp, Sz * 3 * N * 2));
+  PA(dev_alloc(ctx, &p->d_scores[0], Sz * px));
+  PA(dev_alloc(ctx, &p->d_scores[1], Sz * px));
   {
-    const size_t fb = feat_bytes(cap);
+    const size_t fb = feat_bytes(cap, S);
     char* mem = nullptr;
     PA(dev_alloc(ctx, &mem, 2 * fb));
     p->feat_mem = mem;
     if (mem) {
       char* q = mem;
-      p->F[0] = carve(q, cap);
-      p->F[1] = carve(q, cap);
+      p->F[0] = carve(q, cap, S);
+      p->F[1] = carve(q, cap, S);
     }
   }
-  PA(dev_alloc(ctx, &p->d_ctl, 1));
-  PA(dev_alloc(ctx, &p->d_next, (size_t)cap * 2));
-  PA(dev_alloc(ctx, &p->d_err, (size_t)cap));
-  PA(dev_alloc(ctx, &p->d_status, (size_t)cap));
-  PA(dev_alloc(ctx, &p->d_R, (size_t)Hyp * 9));
-  PA(dev_alloc(ctx, &p->d_t, (size_t)Hyp * 3));
-  PA(dev_alloc(ctx, &p->d_valid, (size_t)Hyp));
-  PA(dev_alloc(ctx, &p->d_counts, (size_t)Hyp));
+  PA(dev_alloc(ctx, &p->d_ctl, Sz));
+  PA(dev_alloc(ctx, &p->d_next, Sz * cap * 2));
+  PA(dev_alloc(ctx, &p->d_err, Sz * cap));
+  PA(dev_alloc(ctx, &p->d_status, Sz * cap));
+  PA(dev_alloc(ctx, &p->d_R, Sz * Hyp * 9));
+  PA(dev_alloc(ctx, &p->d_t, Sz * Hyp * 3));
+  PA(dev_alloc(ctx, &p->d_valid, Sz * Hyp));
+  PA(dev_alloc(ctx, &p->d_counts, Sz * Hyp));
   PA(dev_alloc(ctx, &p->d_samples, (size_t)Hyp * 4));
-  PA(dev_alloc(ctx, &p->d_masks, (size_t)Hyp * p->words));
-  PA(dev_alloc(ctx, &p->d_best_mask, (size_t)p->words));
+  PA(dev_alloc(ctx, &p->d_masks, Sz * Hyp * p->words));
+  PA(dev_alloc(ctx, &p->d_best_mask, Sz * p->words));
   PA(dev_alloc(ctx, &p->d_newkp, (size_t)cap * 2));
   PA(dev_alloc(ctx, &p->d_pairs, (size_t)cap * 2));
-  // n_iterations as a step function of the outlier ratio (state.hip, table_lookup): a batch of `hyp`
+  // n_iterations as a step function of the outlier ratio (state_device.h, table_lookup): a batch of `hyp`
   // samples cannot finish a rule that needs more than `hyp` iterations, so hyp + 1 thresholds suffice
   p->table_len = Hyp + 1;
   p->table.assign((size_t)p->table_len + 1, 0.0);
@@ -327,13 +333,13 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   const size_t need = (size_t)7 * Hyp;
   p->ring_len = next_pow2(32 * need);
   p->stage_cap = 16 * need;
-  PA(dev_alloc(ctx, &p->d_raws, (size_t)p->ring_len));
+  PA(dev_alloc(ctx, &p->d_raws, Sz * p->ring_len));
   PA(pin_alloc(ctx, &p->h_stage, p->stage_cap));
-  PA(pin_alloc(ctx, &p->h_res, 4));
+  PA(pin_alloc(ctx, &p->h_res, 4 * Sz));
   {
     unsigned* q = nullptr;
-    PA(pin_alloc(ctx, &q, 16));
-    if (q) memset(q, 0, 64);
+    PA(pin_alloc(ctx, &q, 4 * Sz + 16));
+    if (q) memset(q, 0, (4 * Sz + 16) * sizeof(unsigned));
     p->h_seq = q;
   }
   if (rc == VO_OK && (hipHostGetDevicePointer((void**)&p->m_res, (void*)p->h_res, 0) != hipSuccess ||
@@ -347,19 +353,24 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
       if (rc == VO_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
         rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   }
-  if (rc == VO_OK && (mcpy(p->ctx->stream, p->d_table, p->table.data(), p->table.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-                      mset(p->ctx->stream, p->d_ctl, 0, sizeof(vo_seq_ctl)) != hipSuccess))
+  if (rc == VO_OK && (mcpy(ctx->stream, p->d_table, p->table.data(), p->table.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                      mset(ctx->stream, p->d_ctl, 0, Sz * sizeof(vo_seq_ctl)) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "pipeline: initial uploads failed");
   if (rc != VO_OK) {
     vo_pipeline_destroy(p);
     return rc;
   }
-  memset(&p->rng, 0, sizeof(p->rng));
+  p->gen_upto.assign(Sz, 0);
+  p->pos_known.assign(Sz, 0);
+  p->raw_gen.resize(Sz);
+  p->rng.resize(Sz);
+  p->slot_seq.assign(4 * Sz, 0u);
+  p->seq_state.assign(Sz, 0);
+  for (auto& g : p->rng) memset(&g, 0, sizeof(g));
   // First use in a fixed order -- main, tracker, detection: the runtime attaches a stream to a hardware queue when it
-  // first runs, and the three streams of the frame loop should end up on three different queues (kernels of one
-  // hardware queue execute in order: tracker and pose estimation sharing one serialises them).
+  // first runs, and the three streams of the frame loop should end up on three different queues.
   {
-    hipStream_t order[3] = {ctx->stream, p->trk->stream, p->det[0]->stream};
+    hipStream_t order[3] = {ctx->stream, p->trk->stream, p->det->stream};
     for (hipStream_t q : order) {
       (void)hipMemsetAsync(p->d_status, 0, 4, q);
       (void)hipStreamSynchronize(q);
@@ -371,54 +382,66 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
 }
 
 int vo_pipeline_feature_cap(vo_pipeline* p) { return p ? p->cap : 0; }
+int vo_pipeline_sequences(vo_pipeline* p) { return p ? p->S : 0; }
 
 int64_t vo_pipeline_ransac_bound(vo_pipeline* p, double outlier_ratio) {
   if (!p) return -1;
   return vo_ransac_table_lookup(p->table.data(), p->table_len, p->cfg.ransac_max_iterations, outlier_ratio);
 }
 
-int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img) {
+int vo_pipeline_set_frame_seq(vo_pipeline* p, int seq, int idx, const uint8_t* img) {
   if (!p) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
-  VO_REQUIRE(ctx, idx >= 0 && idx < p->cfg.n_frames && img, "pipeline_set_frame: bad arguments");
+  VO_REQUIRE(ctx, seq >= 0 && seq < p->S && idx >= 0 && idx < p->cfg.n_frames && img, "pipeline_set_frame: bad arguments");
   for (int k = 0; k < p->n_flight; ++k)
     VO_REQUIRE(ctx, p->flight[k].prev_idx != idx && p->flight[k].next_idx != idx,
                "pipeline_set_frame: slot %d belongs to a step in flight", idx);
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t px = (size_t)p->cfg.H * p->cfg.W;
-  // on a side stream: steps in flight keep running; the caller's buffer is free on return
-  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_img[idx], img, px, hipMemcpyHostToDevice, p->pyr->stream));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(p->pyr->stream));
+  // on the tracker's stream: steps in flight keep running; the caller's buffer is free on return
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->img(seq, idx), img, p->px, hipMemcpyHostToDevice, p->trk->stream));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(p->trk->stream));
   return VO_OK;
 }
+
+int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img) { return vo_pipeline_set_frame_seq(p, 0, idx, img); }
 
 int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng) {
   if (!p || !rng) return VO_EINVAL;
   VO_REQUIRE(p->ctx, p->n_flight == 0, "pipeline_seed: %d submitted step(s) not collected", p->n_flight);
-  p->rng = *rng;
-  p->raw_gen = *rng;
-  // the device continues at the end of what has been generated so far; that look-ahead is dropped
-  p->pos_known = p->gen_upto;
-  VO_HIP_TRY(p->ctx, mcpy(p->ctx->stream, &p->d_ctl->raw_pos, &p->gen_upto, 8, hipMemcpyHostToDevice));
+  for (int q = 0; q < p->S; ++q) {     // every sequence has its own estimator object: each starts from this state
+    p->rng[q] = *rng;
+    p->raw_gen[q] = *rng;
+    // the device continues at the end of what has been generated so far; that look-ahead is dropped
+    p->pos_known[q] = p->gen_upto[q];
+    VO_HIP_TRY(p->ctx, mcpy(p->ctx->stream, &p->d_ctl[q].raw_pos, &p->gen_upto[q], 8, hipMemcpyHostToDevice));
+  }
   p->seeded = true;
   return VO_OK;
 }
 
-int vo_pipeline_get_rng(vo_pipeline* p, vo_pcg64* rng) {
-  if (!p || !rng) return VO_EINVAL;
-  *rng = p->rng;
+int vo_pipeline_get_rng_seq(vo_pipeline* p, int seq, vo_pcg64* rng) {
+  if (!p || !rng || seq < 0 || seq >= p->S) return VO_EINVAL;
+  *rng = p->rng[seq];
   return VO_OK;
 }
 
-// Harris + NMS of `frame` into keypoint slot `s` on a detection stream; evDet[s] when done
+int vo_pipeline_get_rng(vo_pipeline* p, vo_pcg64* rng) { return vo_pipeline_get_rng_seq(p, 0, rng); }
+
+}  // extern "C"
+
+// ---- launches; (q0, Sn): sequences q0 .. q0 + Sn - 1 (all of them, or one when a step is redone) ----
+
+// Harris + NMS of frame slot `frame` into keypoint slot `s` on the detection stream; evDet[s] when done
 static int enqueue_detection(vo_pipeline* p, int frame, int s) {
   const vo_pipeline_config& c = p->cfg;
   p->det_flip ^= 1;
-  vo_ctx* det = p->det[p->det_flip];
+  vo_ctx* det = p->det;
   double* scores = p->d_scores[p->det_flip];
-  det->nms_kp_f32 = p->d_kp_f32[s];
-  int rc = vo_harris_response_dev(det, p->d_img[frame], c.H, c.W, c.harris_patch, c.harris_kappa, scores);
-  if (rc == VO_OK) rc = vo_nms_keypoints_dev(det, scores, c.H, c.W, c.n_keypoints, c.nms_radius, p->d_kp[s]);
+  det->nms_kp_f32 = nullptr;
+  int rc = vo_harris_response_batch_dev(det, p->img(0, frame), p->img_stride(), p->S, c.H, c.W, c.harris_patch,
+                                        c.harris_kappa, scores);
+  if (rc == VO_OK)
+    rc = vo_nms_keypoints_batch_dev(det, scores, p->S, c.H, c.W, c.n_keypoints, c.nms_radius, p->kp(0, s), p->det_stride());
   if (rc == VO_OK && hipEventRecord(p->evDet[s], det->stream) != hipSuccess) rc = VO_EHIP;
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "detection: %s", vo_last_error(det));
   return VO_OK;
@@ -426,52 +449,55 @@ static int enqueue_detection(vo_pipeline* p, int frame, int s) {
 
 static int enqueue_pyramid(vo_pipeline* p, int frame, int s) {
   const vo_pipeline_config& c = p->cfg;
-  const int rc = vo_pyramid_build_dev(p->pyr, p->d_img[frame], c.H, c.W, p->n_levels, p->d_pyr[s]);
-  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "pyramid: %s", vo_last_error(p->pyr));
-  VO_HIP_TRY(p->ctx, hipEventRecord(p->evPyr[s], p->pyr->stream));
+  const int rc = vo_pyramid_build_batch_dev(p->trk, p->img(0, frame), p->img_stride(), p->S, c.H, c.W, p->n_levels,
+                                            p->pyr(0, s), p->pyr_stride());
+  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "pyramid: %s", vo_last_error(p->trk));
+  VO_HIP_TRY(p->ctx, hipEventRecord(p->evPyr[s], p->trk->stream));
   return VO_OK;
 }
 
-// keeps the ring of generator outputs filled ahead of every step that may be in flight
-static int ensure_raws(vo_pipeline* p) {
+// keeps sequence q's ring of generator outputs filled ahead of every step that may be in flight
+static int ensure_raws(vo_pipeline* p, int q) {
   vo_ctx* ctx = p->ctx;
   const uint64_t need = (uint64_t)7 * p->cfg.hyp;
-  if (p->gen_upto >= p->pos_known + 4 * need) return VO_OK;
-  const uint64_t target = p->pos_known + 16 * need;
-  const size_t m = (size_t)(target - p->gen_upto);        // <= stage_cap
+  if (p->gen_upto[q] >= p->pos_known[q] + 4 * need) return VO_OK;
+  const uint64_t target = p->pos_known[q] + 16 * need;
+  const size_t m = (size_t)(target - p->gen_upto[q]);        // <= stage_cap
   if (p->raw_pending) {
-    VO_HIP_TRY(ctx, hipEventSynchronize(p->evRaw));       // the staging buffer's last copy (long done)
+    VO_HIP_TRY(ctx, hipEventSynchronize(p->evRaw));          // the staging buffer's last copy (long done)
     p->raw_pending = false;
   }
-  vo_rng_raw32(&p->raw_gen, (int)m, p->h_stage);
-  const uint32_t off = (uint32_t)(p->gen_upto & (p->ring_len - 1));
+  vo_rng_raw32(&p->raw_gen[q], (int)m, p->h_stage);
+  uint32_t* ring = p->d_raws + (size_t)q * p->ring_len;
+  const uint32_t off = (uint32_t)(p->gen_upto[q] & (p->ring_len - 1));
   const size_t first = std::min(m, (size_t)(p->ring_len - off));
-  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_raws + off, p->h_stage, first * 4, hipMemcpyHostToDevice, ctx->stream));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(ring + off, p->h_stage, first * 4, hipMemcpyHostToDevice, ctx->stream));
   if (first < m)
-    VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_raws, p->h_stage + first, (m - first) * 4, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP_TRY(ctx, hipMemcpyAsync(ring, p->h_stage + first, (m - first) * 4, hipMemcpyHostToDevice, ctx->stream));
   VO_HIP_TRY(ctx, hipEventRecord(p->evRaw, ctx->stream));
   p->raw_pending = true;
-  p->gen_upto = target;
+  p->gen_upto[q] = target;
   return VO_OK;
 }
 
-static vo_pose_job make_pose_job(vo_pipeline* p, const vo_feat& B, int do_replay) {
+static vo_pose_job make_pose_job(vo_pipeline* p, const vo_feat& B, int do_replay, int q0) {
   const vo_pipeline_config& c = p->cfg;
+  const size_t q = (size_t)q0;
   vo_pose_job j;
-  j.ctl = p->d_ctl;
-  j.rp.valid = p->d_valid;
-  j.rp.counts = p->d_counts;
-  j.rp.R = p->d_R;
-  j.rp.t = p->d_t;
-  j.rp.masks = (const unsigned long long*)p->d_masks;
+  j.ctl = p->d_ctl + q;
+  j.rp.valid = p->d_valid + q * c.hyp;
+  j.rp.counts = p->d_counts + q * c.hyp;
+  j.rp.R = p->d_R + q * c.hyp * 9;
+  j.rp.t = p->d_t + q * c.hyp * 3;
+  j.rp.masks = (const unsigned long long*)p->d_masks + q * c.hyp * p->words;
   j.rp.words = p->words;
   j.rp.hyp = c.hyp;
   j.rp.table = p->d_table;
   j.rp.table_len = p->table_len;
   j.rp.max_it = c.ransac_max_iterations;
-  j.rp.best_mask = (unsigned long long*)p->d_best_mask;
+  j.rp.best_mask = (unsigned long long*)p->d_best_mask + q * p->words;
   j.do_replay = do_replay;
-  j.B = B;
+  j.B = vo_feat_seq(B, q);
   j.cam = p->cam;
   j.bearing_thr = c.bearing_threshold;
   j.max_iter = c.refine_iters;
@@ -480,26 +506,36 @@ static vo_pose_job make_pose_job(vo_pipeline* p, const vo_feat& B, int do_replay
 
 // tracker of one step, on its own stream: it needs the previous step's regroup (the features' positions) and this
 // frame's pyramid, nothing of the previous step's pose estimation, which runs beside it on the main stream
-static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool with_pyramid) {
+static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool with_pyramid, int q0, int Sn) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
-  const vo_feat A = p->F[f.fcur];
+  const vo_feat A = vo_feat_seq(p->F[f.fcur], (size_t)q0);
   hipStream_t ts = p->trk->stream;
   if (with_pyramid) VO_TRY(enqueue_pyramid(p, f.next_idx, f.b));
   if (f.k > 0 && hipEventQuery(p->evRegroup[(f.k - 1) & 1]) != hipSuccess)
     VO_HIP_TRY(ctx, hipStreamWaitEvent(ts, p->evRegroup[(f.k - 1) & 1], 0));
   if (hipEventQuery(p->evDet[f.a]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ts, p->evDet[f.a], 0));
+  vo_seq_ctl* ctl = p->d_ctl + q0;
   vo_klt_source src;
-  src.n = &p->d_ctl->n2;             // (= n once the previous step has closed; known as soon as its regroup has run)
-  src.num_features = &p->d_ctl->num_features;
+  src.n = &ctl->n2;                  // (= n once the previous step has closed; known as soon as its regroup has run)
+  src.num_features = &ctl->num_features;
   src.frac = c.redetect_fraction;
-  src.det_kp = p->d_kp[f.a];
+  src.det_kp = p->kp(q0, f.a);
   src.n_det = c.n_keypoints;
-  src.ts = &p->d_ctl->ts[0];
+  src.ts = &ctl->ts[0];
+  vo_klt_batch kb;
+  kb.S = Sn;
+  kb.pyr = p->pyr_stride();
+  kb.xy = (size_t)p->cap * 2;
+  kb.out = (size_t)p->cap;
+  kb.ctl = sizeof(vo_seq_ctl);
+  kb.det = p->det_stride();
   {
-    const int rc = vo_klt_track_ndev(p->trk, p->d_img[f.prev_idx], p->d_pyr[f.a], p->d_img[f.next_idx], p->d_pyr[f.b], c.H,
-                                     c.W, p->n_levels, A.kp, p->cap, nullptr, c.klt_win, c.klt_max_iter, c.klt_eps,
-                                     c.klt_min_eig, p->d_next, p->d_status, p->d_err, &src);
+    const size_t q = (size_t)q0;
+    const int rc = vo_klt_track_ndev(p->trk, p->img(q0, f.prev_idx), p->pyr(q0, f.a), p->img(q0, f.next_idx), p->pyr(q0, f.b),
+                                     c.H, c.W, p->n_levels, A.kp, p->cap, nullptr, c.klt_win, c.klt_max_iter, c.klt_eps,
+                                     c.klt_min_eig, p->d_next + q * p->cap * 2, p->d_status + q * p->cap,
+                                     p->d_err + q * p->cap, &src, &kb);
     if (rc != VO_OK) return vo_set_error(ctx, rc, "tracker: %s", vo_last_error(p->trk));
   }
   VO_HIP_TRY(ctx, hipEventRecord(p->evKlt[f.k & 1], ts));
@@ -508,30 +544,42 @@ static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool 
 
 // the main-stream chain of one step (the tracker's event must have been recorded);
 // first_half_only: stop behind the regroup (recover_step continues on the host)
-static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool first_half_only, int debug_fault_every) {
+static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool first_half_only, int debug_fault_every,
+                         int q0, int Sn, unsigned seq) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
-  const vo_feat A = p->F[f.fcur], B = p->F[1 - f.fcur];
+  const size_t q = (size_t)q0;
+  const vo_feat A = vo_feat_seq(p->F[f.fcur], q), B = vo_feat_seq(p->F[1 - f.fcur], q);
+  vo_seq_ctl* ctl = p->d_ctl + q0;
   VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evKlt[f.k & 1], 0));
   vo_append ap;
-  ap.det_kp = p->d_kp[f.a];
+  ap.det_kp = p->kp(q0, f.a);
+  ap.det_stride = p->det_stride();
   ap.n_det = c.n_keypoints;
   ap.frac = c.redetect_fraction;
   ap.pose_mode = c.redetect_start_pose;
   ap.debug_fault_every = debug_fault_every;
-  VO_TRY(vo_state_regroup_klt(ctx, p->d_ctl, A, B, p->d_next, p->d_status, p->d_err, (float)c.klt_err_threshold, ap, p->cap));
+  VO_TRY(vo_state_regroup_klt(ctx, ctl, A, B, p->d_next + q * p->cap * 2, p->d_status + q * p->cap, p->d_err + q * p->cap,
+                              (float)c.klt_err_threshold, ap, p->cap, Sn));
   VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], ctx->stream));
   if (first_half_only) return VO_OK;
-  VO_TRY(vo_p3p_hypotheses_ring_dev(ctx, B.land, B.kp64, &p->d_ctl->n_p3p, p->cap, c.K, p->d_raws, &p->d_ctl->raw_pos,
-                                    p->ring_len - 1, c.hyp, c.p3p_thr_sq, p->d_R, p->d_t, p->d_valid, p->d_counts,
-                                    p->d_masks, (uint32_t*)&p->d_ctl->solve_flag, (uint64_t*)&p->d_ctl->ts[2]));
-  VO_TRY(vo_frame_pose(ctx, make_pose_job(p, B, 1)));
-  VO_TRY(vo_state_landmarks(ctx, p->d_ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + f.rslot,
-                            p->m_seq + f.rslot, f.seq));
+  vo_hyp_batch hb;
+  hb.S = Sn;
+  hb.X = (size_t)p->cap * 3;
+  hb.x = (size_t)p->cap * 2;
+  hb.raws = p->ring_len;
+  hb.ctl = sizeof(vo_seq_ctl);
+  VO_TRY(vo_p3p_hypotheses_ring_dev(ctx, B.land, B.kp64, &ctl->n_p3p, p->cap, c.K, p->d_raws + q * p->ring_len, &ctl->raw_pos,
+                                    p->ring_len - 1, c.hyp, c.p3p_thr_sq, p->d_R + q * c.hyp * 9, p->d_t + q * c.hyp * 3,
+                                    p->d_valid + q * c.hyp, p->d_counts + q * c.hyp, p->d_masks + q * c.hyp * p->words,
+                                    (uint32_t*)&ctl->solve_flag, (uint64_t*)&ctl->ts[2], &hb));
+  VO_TRY(vo_frame_pose(ctx, make_pose_job(p, p->F[1 - f.fcur], 1, q0), Sn));
+  VO_TRY(vo_state_landmarks(ctx, ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + (size_t)f.rslot * p->S + q,
+                            p->m_seq + (size_t)f.rslot * p->S + q, seq, Sn));
   return VO_OK;
 }
 
-// ---- side-stream worker ----
+// ---- detection worker ----
 static void worker_main(vo_pipeline* p) {
   (void)hipSetDevice(p->ctx->device);
   unsigned seen = 0;
@@ -544,8 +592,8 @@ static void worker_main(vo_pipeline* p) {
       continue;
     }
     idle = 0;
-    const vo_pipeline::job_t j = p->jobs[seen & 3];
-    const int rc = enqueue_detection(p, j.f.next_idx, j.f.b);
+    const vo_pipeline::flight_t j = p->jobs[seen & 3];
+    const int rc = enqueue_detection(p, j.next_idx, j.b);
     if (rc != VO_OK) p->worker_rc = rc;
     ++seen;
     p->job_done.store(seen, std::memory_order_release);
@@ -568,11 +616,14 @@ static int worker_idle(vo_pipeline* p) {
   return worker_check(p);
 }
 
-int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, const uint8_t* state,
-                          const double* landmarks, const double* tracks, const double* poses, const double* T_wc,
-                          const double* T_cw, const double* T_wc_prev, const double* T_cw_prev, int num_features) {
+extern "C" {
+
+int vo_pipeline_set_state_seq(vo_pipeline* p, int seq, int idx, int n, const double* kp, const uint8_t* state,
+                              const double* landmarks, const double* tracks, const double* poses, const double* T_wc,
+                              const double* T_cw, const double* T_wc_prev, const double* T_cw_prev, int num_features) {
   if (!p) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, seq >= 0 && seq < p->S, "pipeline_set_state: bad sequence index");
   VO_REQUIRE(ctx, idx >= 0 && idx < p->cfg.n_frames, "pipeline_set_state: bad frame index");
   VO_REQUIRE(ctx, n >= 0 && n <= p->cap, "pipeline_set_state: %d features exceed the capacity %d", n, p->cap);
   VO_REQUIRE(ctx, (n == 0 || (kp && state && landmarks && tracks && poses)) && T_wc && T_cw && T_wc_prev && T_cw_prev,
@@ -582,7 +633,7 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
-  const vo_feat& F = p->F[p->cur];
+  const vo_feat F = vo_feat_seq(p->F[p->cur], (size_t)seq);
   std::vector<double> pose12((size_t)n * 12);
   std::vector<float> kp32((size_t)n * 2);
   std::vector<uint8_t> zeros((size_t)n, 0);
@@ -590,21 +641,21 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
   for (int i = 0; i < n; ++i)
     for (int k = 0; k < 12; ++k) pose12[(size_t)k * n + i] = poses[(size_t)16 * i + k];   // component-major on the device
   if (n > 0) {
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.kp, kp32.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.kp64, kp, (size_t)n * 16, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.state, state, (size_t)n, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.cand, zeros.data(), (size_t)n, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.land, landmarks, (size_t)n * 24, hipMemcpyHostToDevice));
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.track, tracks, (size_t)n * 16, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(st, F.kp, kp32.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(st, F.kp64, kp, (size_t)n * 16, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(st, F.state, state, (size_t)n, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(st, F.cand, zeros.data(), (size_t)n, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(st, F.land, landmarks, (size_t)n * 24, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(st, F.track, tracks, (size_t)n * 16, hipMemcpyHostToDevice));
     for (int k = 0; k < 12; ++k)
-      VO_HIP_TRY(ctx, mcpy(p->ctx->stream, F.pose + (size_t)k * F.pitch, &pose12[(size_t)k * n], (size_t)n * 8, hipMemcpyHostToDevice));
+      VO_HIP_TRY(ctx, mcpy(st, F.pose + (size_t)k * F.pitch, &pose12[(size_t)k * n], (size_t)n * 8, hipMemcpyHostToDevice));
   }
   vo_seq_ctl h;
-  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(st, &h, p->d_ctl + seq, sizeof(h), hipMemcpyDeviceToHost));
   const uint64_t raw_pos = h.raw_pos;
   const int64_t n_it = h.n_iterations;
   const double orat = h.outlier_ratio;
-  const bool keep_ransac = p->have_state;
+  const bool keep_ransac = p->seq_state[seq] != 0;
   memset(&h, 0, sizeof(h));
   h.n = n;
   h.n2 = n;
@@ -623,43 +674,63 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
   memcpy(h.T_cw, T_cw, 96);
   memcpy(h.T_wc_prev, T_wc_prev, 96);
   memcpy(h.T_cw_prev, T_cw_prev, 96);
-  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
-  // pyramid and detector output of the frame the state belongs to
+  VO_HIP_TRY(ctx, mcpy(st, p->d_ctl + seq, &h, sizeof(h), hipMemcpyHostToDevice));
+  // the pyramid and the detector's output of the frame the states belong to are made by the first submit
+  // (for all sequences at once: they share the frame slot, the last call's idx counts)
+  p->seq_state[seq] = 1;
   p->slot = 0;
-  sync_prof(p);
-  VO_TRY(enqueue_pyramid(p, idx, 0));
-  VO_TRY(enqueue_detection(p, idx, 0));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(p->pyr->stream));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(p->det[p->det_flip]->stream));
   p->prev_frame = idx;
   p->have_state = true;
+  p->primed = false;
   return VO_OK;
 }
 
-int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, double* kp, uint8_t* state, uint8_t* candidate_mask,
-                          double* landmarks, double* tracks, double* poses, double* T_wc, double* T_wc_prev,
-                          vo_ransac_state* rs, int32_t* num_features) {
+int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, const uint8_t* state,
+                          const double* landmarks, const double* tracks, const double* poses, const double* T_wc,
+                          const double* T_cw, const double* T_wc_prev, const double* T_cw_prev, int num_features) {
+  return vo_pipeline_set_state_seq(p, 0, idx, n, kp, state, landmarks, tracks, poses, T_wc, T_cw, T_wc_prev, T_cw_prev,
+                                   num_features);
+}
+
+// pyramid and detection of the frame the handed-over states belong to, all sequences, synchronously
+static int prime(vo_pipeline* p) {
+  vo_ctx* ctx = p->ctx;
+  VO_TRY(worker_idle(p));
+  sync_prof(p);
+  VO_TRY(enqueue_pyramid(p, p->prev_frame, 0));
+  VO_TRY(enqueue_detection(p, p->prev_frame, 0));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(p->trk->stream));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(p->det->stream));
+  p->primed = true;
+  return VO_OK;
+}
+
+int vo_pipeline_get_state_seq(vo_pipeline* p, int seq, int32_t* n_out, double* kp, uint8_t* state,
+                              uint8_t* candidate_mask, double* landmarks, double* tracks, double* poses, double* T_wc,
+                              double* T_wc_prev, vo_ransac_state* rs, int32_t* num_features) {
   if (!p) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, seq >= 0 && seq < p->S, "pipeline_get_state: bad sequence index");
   VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_get_state: %d submitted step(s) not collected", p->n_flight);
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  hipStream_t st = ctx->stream;
+  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   vo_seq_ctl h;
-  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(st, &h, p->d_ctl + seq, sizeof(h), hipMemcpyDeviceToHost));
   const int n = h.n;
-  const vo_feat& F = p->F[p->cur];
+  const vo_feat F = vo_feat_seq(p->F[p->cur], (size_t)seq);
   if (n_out) *n_out = n;
   if (num_features) *num_features = h.num_features;
   if (n > 0) {
-    if (kp) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, kp, F.kp64, (size_t)n * 16, hipMemcpyDeviceToHost));
-    if (state) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, state, F.state, (size_t)n, hipMemcpyDeviceToHost));
-    if (candidate_mask) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, candidate_mask, F.cand, (size_t)n, hipMemcpyDeviceToHost));
-    if (landmarks) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, landmarks, F.land, (size_t)n * 24, hipMemcpyDeviceToHost));
-    if (tracks) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, tracks, F.track, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (kp) VO_HIP_TRY(ctx, mcpy(st, kp, F.kp64, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (state) VO_HIP_TRY(ctx, mcpy(st, state, F.state, (size_t)n, hipMemcpyDeviceToHost));
+    if (candidate_mask) VO_HIP_TRY(ctx, mcpy(st, candidate_mask, F.cand, (size_t)n, hipMemcpyDeviceToHost));
+    if (landmarks) VO_HIP_TRY(ctx, mcpy(st, landmarks, F.land, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (tracks) VO_HIP_TRY(ctx, mcpy(st, tracks, F.track, (size_t)n * 16, hipMemcpyDeviceToHost));
     if (poses) {
       std::vector<double> p12((size_t)n * 12);
       for (int k = 0; k < 12; ++k)
-        VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &p12[(size_t)k * n], F.pose + (size_t)k * F.pitch, (size_t)n * 8, hipMemcpyDeviceToHost));
+        VO_HIP_TRY(ctx, mcpy(st, &p12[(size_t)k * n], F.pose + (size_t)k * F.pitch, (size_t)n * 8, hipMemcpyDeviceToHost));
       for (int i = 0; i < n; ++i) {
         double row[12];
         for (int k = 0; k < 12; ++k) row[k] = p12[(size_t)k * n + i];
@@ -680,14 +751,22 @@ int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, double* kp, uint8_t* s
   return VO_OK;
 }
 
+int vo_pipeline_get_state(vo_pipeline* p, int32_t* n_out, double* kp, uint8_t* state, uint8_t* candidate_mask,
+                          double* landmarks, double* tracks, double* poses, double* T_wc, double* T_wc_prev,
+                          vo_ransac_state* rs, int32_t* num_features) {
+  return vo_pipeline_get_state_seq(p, 0, n_out, kp, state, candidate_mask, landmarks, tracks, poses, T_wc, T_wc_prev, rs,
+                                   num_features);
+}
+
 int vo_pipeline_get_detection(vo_pipeline* p, double* kp_xy) {
   if (!p || !kp_xy) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
   VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_get_detection: %d submitted step(s) not collected", p->n_flight);
   VO_TRY(worker_idle(p));
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (p->have_state && !p->primed) VO_TRY(prime(p));
   VO_HIP_TRY(ctx, hipEventSynchronize(p->evDet[p->slot]));
-  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, kp_xy, p->d_kp[p->slot], (size_t)p->cfg.n_keypoints * 16, hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(ctx->stream, kp_xy, p->kp(0, p->slot), (size_t)p->cfg.n_keypoints * 16, hipMemcpyDeviceToHost));
   return VO_OK;
 }
 
@@ -701,6 +780,7 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
              prev_idx, p->prev_frame);
   VO_REQUIRE(ctx, p->n_flight < 2, "pipeline_submit: two steps are already in flight, collect one first");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!p->primed) VO_TRY(prime(p));
   const double t_in = now_s();
   vo_pipeline::flight_t f;
   f.prev_idx = prev_idx;
@@ -719,20 +799,21 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   double tq = now_s();
   while ((int)(p->job_done.load(std::memory_order_acquire) - my) < 0) __builtin_ia32_pause();
   VO_TRY(worker_check(p));
-  p->jobs[my & 3] = {f, false, true};
+  p->jobs[my & 3] = f;
   p->job_posted.store(my + 1, std::memory_order_release);
   double tn = now_s();
   p->dbg_part[0] += tn - tq;
   tq = tn;
-  VO_TRY(enqueue_tracker(p, f, true));
+  VO_TRY(enqueue_tracker(p, f, true, 0, p->S));
   tn = now_s();
   p->dbg_part[1] += tn - tq;
   tq = tn;
-  VO_TRY(ensure_raws(p));
+  for (int q = 0; q < p->S; ++q) VO_TRY(ensure_raws(p, q));
   tn = now_s();
   p->dbg_part[2] += tn - tq;
   tq = tn;
-  VO_TRY(enqueue_chain(p, f, false, c.debug_fault_every));
+  VO_TRY(enqueue_chain(p, f, false, c.debug_fault_every, 0, p->S, f.seq));
+  for (int q = 0; q < p->S; ++q) p->slot_seq[(size_t)f.rslot * p->S + q] = f.seq;
   p->dbg_part[3] += now_s() - tq;
   p->flight[p->n_flight++] = f;
   ++p->steps_submitted;
@@ -744,55 +825,64 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   return VO_OK;
 }
 
-// Waits for the record of step `seq` in slot rslot and copies it out.  The kernel writes the record, fences at
-// system scope, then the sequence word; the record also carries the number at both ends and the generator position
-// can only grow, so a copy taken while some of the record's lines were still on their way (seen twice in ~40k
-// steps: the sequence word visible, a field behind it not yet) is recognised and taken again.
-static int wait_record(vo_pipeline* p, int rslot, unsigned seq, vo_step_result* out) {
-  volatile unsigned* w = p->h_seq + rslot;
+}  // extern "C"
+
+// Waits for sequence q's record of step `seq` in slot rslot and copies it out.  The kernel writes the record,
+// fences at system scope, then the sequence word; the record also carries the number at both ends and the generator
+// position can only grow, so a copy taken while some of the record's lines were still on their way (seen twice in
+// ~40k steps: the sequence word visible, a field behind it not yet) is recognised and taken again.
+static int wait_record(vo_pipeline* p, int rslot, int q, unsigned seq, uint64_t floor, vo_step_result* out) {
+  volatile unsigned* w = p->seq_h(rslot, q);
   const double t0 = now_s();
   long it = 0;
   for (;;) {
     if (*w == seq) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      memcpy(out, (const void*)(p->h_res + rslot), sizeof(*out));
-      if (out->seq_head == seq && out->seq_tail == seq && out->raw_pos >= p->pos_known_floor) return VO_OK;
+      memcpy(out, (const void*)p->res_h(rslot, q), sizeof(*out));
+      if (out->seq_head == seq && out->seq_tail == seq && out->raw_pos >= floor) return VO_OK;
     }
     __builtin_ia32_pause();
     if ((++it & 0xffff) == 0 && now_s() - t0 > 5.0) {
       VO_HIP_TRY(p->ctx, hipStreamSynchronize(p->ctx->stream));
-      memcpy(out, (const void*)(p->h_res + rslot), sizeof(*out));
+      memcpy(out, (const void*)p->res_h(rslot, q), sizeof(*out));
       if (*w == seq && out->seq_head == seq && out->seq_tail == seq) return VO_OK;
-      return vo_set_error(p->ctx, VO_EHIP, "pipeline: the GPU never published the record of step %u", seq);
+      return vo_set_error(p->ctx, VO_EHIP, "pipeline: the GPU never published the record of step %u (sequence %d)", seq, q);
     }
   }
 }
 
-// The step of flight f raised a fault: nothing persistent was touched, so it is run again from its first
-// main-stream kernel with the sequential sampler and the reference's loop on the host (ransac.py:90-121),
-// then handed back to the device for the refinement and the bookkeeping.
-static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_result* out) {
+// Sequence q's step of flight f raised a fault: nothing persistent of that sequence was touched, so the step is run
+// again from its first main-stream kernel (for that sequence alone) with the sequential sampler and the reference's
+// loop on the host (ransac.py:90-121), then handed back to the device for the refinement and the bookkeeping.
+static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, vo_step_result* out) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
   hipStream_t st = ctx->stream;
   VO_TRY(worker_idle(p));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   VO_HIP_TRY(ctx, hipStreamSynchronize(p->trk->stream));
+  vo_seq_ctl* ctl = p->d_ctl + q;
   vo_seq_ctl h;
-  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(st, &h, ctl, sizeof(h), hipMemcpyDeviceToHost));
   if (h.fault & VO_FAULT_CAPACITY)
     return vo_set_error(ctx, VO_ECAPACITY, "pipeline: %d features + %d new keypoints exceed the capacity %d", h.n,
                         c.n_keypoints, p->cap);
   const int zero = 0;
-  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &p->d_ctl->fault, &zero, 4, hipMemcpyHostToDevice));
-  VO_TRY(enqueue_tracker(p, f, false));
-  VO_TRY(enqueue_chain(p, f, true, 0));
+  VO_HIP_TRY(ctx, mcpy(st, &ctl->fault, &zero, 4, hipMemcpyHostToDevice));
+  VO_TRY(enqueue_tracker(p, f, false, q, 1));
+  VO_TRY(enqueue_chain(p, f, true, 0, q, 1, 0u));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
-  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+  VO_HIP_TRY(ctx, mcpy(st, &h, ctl, sizeof(h), hipMemcpyDeviceToHost));
   const int n = h.n_tri;
   if (n < 4) return vo_set_error(ctx, VO_ETRACKING, "pipeline: only %d triangulated tracks survive, no pose", n);
-  if (h.fault) VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &p->d_ctl->fault, &zero, 4, hipMemcpyHostToDevice));   // (few landmarks)
-  const vo_feat B = p->F[1 - f.fcur];
+  if (h.fault) VO_HIP_TRY(ctx, mcpy(st, &ctl->fault, &zero, 4, hipMemcpyHostToDevice));   // (few landmarks)
+  const vo_feat B = vo_feat_seq(p->F[1 - f.fcur], (size_t)q);
+  double* dR = p->d_R + (size_t)q * c.hyp * 9;
+  double* dt = p->d_t + (size_t)q * c.hyp * 3;
+  uint8_t* dvalid = p->d_valid + (size_t)q * c.hyp;
+  int32_t* dcounts = p->d_counts + (size_t)q * c.hyp;
+  uint64_t* dmasks = p->d_masks + (size_t)q * c.hyp * p->words;
+  uint64_t* dbest = p->d_best_mask + (size_t)q * p->words;
   vo_ransac_state rs;
   rs.outlier_ratio = h.outlier_ratio;
   rs.confidence = c.ransac_confidence;
@@ -800,7 +890,7 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
   rs.n_iterations = h.n_iterations;
   rs.s = 4;
   rs.adaptive = 1;
-  vo_pcg64 g = p->rng;
+  vo_pcg64 g = p->rng[q];
   std::vector<int32_t> samples((size_t)4 * c.hyp), counts(c.hyp);
   std::vector<uint8_t> valid(c.hyp);
   int64_t n_done = 0;
@@ -810,10 +900,10 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
   while (!finished) {
     VO_TRY(vo_rng_choice(&g, n, 4, c.hyp, samples.data()));
     VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_samples, samples.data(), samples.size() * 4, hipMemcpyHostToDevice, st));
-    VO_TRY(vo_p3p_hypotheses_dev(ctx, B.land, B.kp64, n, c.K, p->d_samples, c.hyp, c.p3p_thr_sq, p->d_R, p->d_t,
-                                 p->d_valid, p->d_counts, p->d_masks));
-    VO_HIP_TRY(ctx, hipMemcpyAsync(valid.data(), p->d_valid, (size_t)c.hyp, hipMemcpyDeviceToHost, st));
-    VO_HIP_TRY(ctx, hipMemcpyAsync(counts.data(), p->d_counts, (size_t)c.hyp * 4, hipMemcpyDeviceToHost, st));
+    VO_TRY(vo_p3p_hypotheses_dev(ctx, B.land, B.kp64, n, c.K, p->d_samples, c.hyp, c.p3p_thr_sq, dR, dt, dvalid, dcounts,
+                                 dmasks));
+    VO_HIP_TRY(ctx, hipMemcpyAsync(valid.data(), dvalid, (size_t)c.hyp, hipMemcpyDeviceToHost, st));
+    VO_HIP_TRY(ctx, hipMemcpyAsync(counts.data(), dcounts, (size_t)c.hyp * 4, hipMemcpyDeviceToHost, st));
     VO_HIP_TRY(ctx, hipStreamSynchronize(st));
     int consumed = 0;
     const int32_t before = best_idx;
@@ -825,10 +915,10 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
       // the winner so far lives in this batch: take its pose and mask row before the buffers are reused
       // (vo_p3p_hypotheses_dev packs mask rows with ceil(n / 64) words)
       const int local = best_idx - batches * c.hyp;
-      VO_HIP_TRY(ctx, mcpy(p->ctx->stream, best_pose, p->d_R + (size_t)local * 9, 72, hipMemcpyDeviceToHost));
-      VO_HIP_TRY(ctx, mcpy(p->ctx->stream, best_pose + 9, p->d_t + (size_t)local * 3, 24, hipMemcpyDeviceToHost));
-      VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_best_mask, p->d_masks + (size_t)local * vo_cdiv(n, 64), (size_t)vo_cdiv(n, 64) * 8,
-                                hipMemcpyDeviceToDevice));
+      VO_HIP_TRY(ctx, mcpy(st, best_pose, dR + (size_t)local * 9, 72, hipMemcpyDeviceToHost));
+      VO_HIP_TRY(ctx, mcpy(st, best_pose + 9, dt + (size_t)local * 3, 24, hipMemcpyDeviceToHost));
+      VO_HIP_TRY(ctx, mcpy(st, dbest, dmasks + (size_t)local * vo_cdiv(n, 64), (size_t)vo_cdiv(n, 64) * 8,
+                           hipMemcpyDeviceToDevice));
     }
     if (++batches > 64 && !finished)
       return vo_set_error(ctx, VO_ETRACKING, "pipeline: the RANSAC rule is not done after %d samples", batches * c.hyp);
@@ -837,15 +927,15 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
   // the generator moves by exactly the samples the reference loop drew; the look-ahead restarts behind it
   {
     std::vector<int32_t> tmp((size_t)4 * (total_consumed > 0 ? total_consumed : 1));
-    VO_TRY(vo_rng_choice(&p->rng, n, 4, total_consumed, tmp.data()));
+    VO_TRY(vo_rng_choice(&p->rng[q], n, 4, total_consumed, tmp.data()));
   }
-  p->raw_gen = p->rng;
-  p->pos_known = p->gen_upto;
+  p->raw_gen[q] = p->rng[q];
+  p->pos_known[q] = p->gen_upto[q];
   h.fault = 0;
   h.n_p3p = n;
   h.n_iterations = rs.n_iterations;
   h.outlier_ratio = rs.outlier_ratio;
-  h.raw_pos = p->gen_upto;
+  h.raw_pos = p->gen_upto[q];
   h.best_idx = best_idx;
   h.best_count = best_count;
   h.consumed = total_consumed;
@@ -853,59 +943,72 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, vo_step_
   h.n_done = n_done;
   h.n_cand = h.n_dropped = h.n_land = h.done = 0;
   memcpy(h.best_pose, best_pose, 96);
-  VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
-  const unsigned seq = ++p->seq;
-  VO_TRY(vo_frame_pose(ctx, make_pose_job(p, B, 0)));
-  VO_TRY(vo_state_landmarks(ctx, p->d_ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + f.rslot,
-                            p->m_seq + f.rslot, seq));
-  p->pos_known_floor = 0;
-  VO_TRY(wait_record(p, f.rslot, seq, out));
+  VO_HIP_TRY(ctx, mcpy(st, ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+  const unsigned seq = ++p->seq;           // the fault record carried the step's number: the new record gets its own
+  p->slot_seq[(size_t)f.rslot * p->S + q] = seq;
+  VO_TRY(vo_frame_pose(ctx, make_pose_job(p, p->F[1 - f.fcur], 0, q), 1));
+  VO_TRY(vo_state_landmarks(ctx, ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + (size_t)f.rslot * p->S + q,
+                            p->m_seq + (size_t)f.rslot * p->S + q, seq, 1));
+  VO_TRY(wait_record(p, f.rslot, q, seq, 0, out));
   out->recovered = 1;
   ++p->n_recovered;
   return VO_OK;
 }
 
-int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
-  if (!p || !out) return VO_EINVAL;
+extern "C" {
+
+int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
+  if (!p || !outs) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
   VO_REQUIRE(ctx, p->n_flight > 0, "pipeline_collect: nothing submitted");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const vo_pipeline::flight_t f = p->flight[0];
   {
     const double t_in = now_s();
-    p->pos_known_floor = p->pos_known;
-    VO_TRY(wait_record(p, f.rslot, f.seq, out));
+    for (int q = 0; q < p->S; ++q)
+      VO_TRY(wait_record(p, f.rslot, q, p->slot_seq[(size_t)f.rslot * p->S + q], p->pos_known[q], &outs[q]));
     p->dbg_wait += now_s() - t_in;
   }
-  if (out->fault) {
-    const int rc = recover_step(p, f, out);
-    if (rc != VO_OK) {
-      // the pipeline cannot go on from here: drop what was in flight so the caller can reset the state
-      p->n_flight = 0;
-      return rc;
+  for (int q = 0; q < p->S; ++q) {
+    vo_step_result* out = &outs[q];
+    if (out->fault) {
+      int rc = recover_step(p, f, q, out);
+      // steps submitted behind it saw the fault and did nothing for this sequence: their main-stream chains are
+      // enqueued again for it alone (pyramids and detections are done and still in place)
+      for (int k = 1; rc == VO_OK && k < p->n_flight; ++k) {
+        const unsigned seq = ++p->seq;
+        p->slot_seq[(size_t)p->flight[k].rslot * p->S + q] = seq;
+        rc = ensure_raws(p, q);
+        if (rc == VO_OK) rc = enqueue_tracker(p, p->flight[k], false, q, 1);
+        if (rc == VO_OK) rc = enqueue_chain(p, p->flight[k], false, 0, q, 1, seq);
+      }
+      if (rc != VO_OK) {
+        // the pipeline cannot go on from here: drop what was in flight so the caller can reset the state
+        p->n_flight = 0;
+        return rc;
+      }
+    } else {
+      // the estimator's generator follows the device: 7 outputs per consumed sample
+      const uint64_t delta = out->raw_pos - p->pos_known[q];
+      if (delta > 0) {
+        std::vector<uint32_t> tmp((size_t)delta);
+        vo_rng_raw32(&p->rng[q], (int)delta, tmp.data());
+      }
+      p->pos_known[q] = out->raw_pos;
     }
-    // steps submitted behind it saw the fault and did nothing: enqueue their main-stream chains again
-    // (their pyramids and detections are done and still in place)
-    p->flight[0] = p->flight[1];
-    --p->n_flight;
-    for (int k = 0; k < p->n_flight; ++k) {
-      p->flight[k].seq = ++p->seq;
-      VO_TRY(ensure_raws(p));
-      VO_TRY(enqueue_tracker(p, p->flight[k], false));
-      VO_TRY(enqueue_chain(p, p->flight[k], false, 0));
-    }
-  } else {
-    // the estimator's generator follows the device: 7 outputs per consumed sample
-    const uint64_t delta = out->raw_pos - p->pos_known;
-    if (delta > 0) {
-      std::vector<uint32_t> tmp((size_t)delta);
-      vo_rng_raw32(&p->rng, (int)delta, tmp.data());
-    }
-    p->pos_known = out->raw_pos;
-    p->flight[0] = p->flight[1];
-    --p->n_flight;
   }
+  p->flight[0] = p->flight[1];
+  --p->n_flight;
   p->last_fbuf = 1 - f.fcur;
+  return VO_OK;
+}
+
+int vo_pipeline_collect(vo_pipeline* p, vo_step_result* out) {
+  if (!p || !out) return VO_EINVAL;
+  if (p->S == 1) return vo_pipeline_collect_all(p, out);
+  std::vector<vo_step_result> all((size_t)p->S);
+  VO_TRY(vo_pipeline_collect_all(p, all.data()));
+  *out = all[0];
   return VO_OK;
 }
 
@@ -933,16 +1036,16 @@ int vo_pipeline_bookkeeping(vo_pipeline* p, int phases, const double* new_kp, in
     VO_HIP_TRY(ctx, hipStreamSynchronize(st));
     p->cur = 1 - p->cur;
     vo_seq_ctl h;
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
+    VO_HIP_TRY(ctx, mcpy(st, &h, p->d_ctl, sizeof(h), hipMemcpyDeviceToHost));
     memcpy(h.T_in_wc, T_wc, 96);
     memcpy(h.T_in_cw, T_cw, 96);
     h.n_cand = h.n_dropped = h.n_land = h.done = 0;
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(st, p->d_ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     std::vector<uint64_t> bits((size_t)p->words, ~0ull);
     if (p3p_inliers)
       for (int i = 0; i < h.n_tri; ++i)
         if (!p3p_inliers[i]) bits[i >> 6] &= ~(1ull << (i & 63));
-    VO_HIP_TRY(ctx, mcpy(p->ctx->stream, p->d_best_mask, bits.data(), bits.size() * 8, hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(st, p->d_best_mask, bits.data(), bits.size() * 8, hipMemcpyHostToDevice));
   }
   if (phases & 1)
     VO_TRY(vo_state_candidates(ctx, p->d_ctl, p->F[p->cur], p->d_best_mask, p->cam, p->cfg.bearing_threshold, -1, p->cap));
@@ -952,10 +1055,10 @@ int vo_pipeline_bookkeeping(vo_pipeline* p, int phases, const double* new_kp, in
   return VO_OK;
 }
 
-int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record) {
+int vo_pipeline_export_state_post_seq(vo_pipeline* p, int seq, const vo_step_result* r, int cap, double* d_record) {
   if (!p || !r || !d_record) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
-  VO_REQUIRE(ctx, cap >= 0, "pipeline_export_state: bad capacity");
+  VO_REQUIRE(ctx, cap >= 0 && seq >= 0 && seq < p->S, "pipeline_export_state: bad capacity or sequence index");
   pose17 h;
   for (int row = 0; row < 3; ++row) {
     for (int c = 0; c < 3; ++c) h.v[4 * row + c] = r->R_refined[3 * row + c];
@@ -971,9 +1074,13 @@ int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int c
   {
     vo_prof_scope ps(ctx, VO_K_EXPORT);
     hipLaunchKernelGGL(export_state_kernel, dim3(vo_cdiv(threads, 256)), dim3(256), 0, ctx->stream, h,
-                       p->F[p->last_fbuf].land, n, cap, d_record);
+                       vo_feat_seq(p->F[p->last_fbuf], (size_t)seq).land, n, cap, d_record);
   }
   return vo_check_launch(ctx, "export_state_kernel");
+}
+
+int vo_pipeline_export_state_post(vo_pipeline* p, const vo_step_result* r, int cap, double* d_record) {
+  return vo_pipeline_export_state_post_seq(p, 0, r, cap, d_record);
 }
 
 int vo_pipeline_export_state_join(vo_pipeline* p, void* consumer) {
@@ -996,7 +1103,7 @@ int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64
   VO_TRY(worker_idle(p));
   double sum = 0;
   int64_t n = 0;
-  for (vo_ctx* q : {p->ctx, p->det[0], p->trk}) {
+  for (vo_ctx* q : {p->ctx, p->det, p->trk}) {
     double ms = 0;
     int64_t k = 0;
     const int rc = vo_prof_read(q, kernel_id, &ms, &k);
@@ -1012,7 +1119,7 @@ int vo_pipeline_prof_read(vo_pipeline* p, int kernel_id, double* total_ms, int64
 int vo_pipeline_prof_reset(vo_pipeline* p) {
   if (!p) return VO_EINVAL;
   VO_TRY(worker_idle(p));
-  for (vo_ctx* q : {p->ctx, p->det[0], p->trk}) VO_TRY(vo_prof_reset(q));
+  for (vo_ctx* q : {p->ctx, p->det, p->trk}) VO_TRY(vo_prof_reset(q));
   return VO_OK;
 }
 

@@ -68,7 +68,7 @@ class PipelineConfig(C.Structure):
                 ("ransac_max_iterations", C.c_int64),
                 ("K", C.c_double * 9), ("Kinv", C.c_double * 9), ("refine_iters", C.c_int32), ("feature_cap", C.c_int32),
                 ("bearing_threshold", C.c_double), ("redetect_fraction", C.c_double),
-                ("debug_fault_every", C.c_int32), ("redetect_start_pose", C.c_int32)]
+                ("debug_fault_every", C.c_int32), ("redetect_start_pose", C.c_int32), ("sequences", C.c_int32)]
 
 
 class StepResult(C.Structure):
@@ -153,6 +153,13 @@ _SIGS = {
     "vo_pipeline_prof_read": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_int64)]),
     "vo_pipeline_prof_reset": (_i, [_vp]),
     "vo_pipeline_ransac_bound": (C.c_int64, [_vp, _d]),
+    "vo_pipeline_sequences": (_i, [_vp]),
+    "vo_pipeline_set_frame_seq": (_i, [_vp, _i, _i, _vp]),
+    "vo_pipeline_set_state_seq": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "vo_pipeline_get_state_seq": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vo_pipeline_get_rng_seq": (_i, [_vp, _i, _vp]),
+    "vo_pipeline_collect_all": (_i, [_vp, _vp]),
+    "vo_pipeline_export_state_post_seq": (_i, [_vp, _i, _vp, _i, _vp]),
 }
 
 

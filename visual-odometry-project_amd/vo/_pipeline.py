@@ -1,7 +1,8 @@
 """Device-resident frame loop (vo_pipeline_*, include/vo_hip.h): the steady state of the reference
 driver (src/main.py:248-286, KLT tracker mode) with the Features / State / RANSAC bookkeeping kept in
 HBM.  The pipeline takes images only; `set_state` hands over what the bootstrap produced and
-`get_state` returns the reference's Features arrays of the current frame."""
+`get_state` returns the reference's Features arrays of the current frame.  With `sequences=S` the pipeline
+advances S independent streams per launch (`seq=` addresses one of them, `collect_all` returns all records)."""
 import ctypes as C
 
 import numpy as np
@@ -27,7 +28,7 @@ class Pipeline:
                  klt_win=15, klt_max_level=2, klt_max_iter=10, klt_eps=0.03, klt_min_eig=1e-4,
                  klt_err_threshold=100.0, hyp=1000, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99,
                  max_iterations=1000, seed=2023, refine_iters=0, feature_cap=0, bearing_threshold=0.0075,
-                 redetect_fraction=0.8, debug_fault_every=0, redetect_start_pose="identity"):
+                 redetect_fraction=0.8, debug_fault_every=0, redetect_start_pose="identity", sequences=1):
         from vo import _native
         self.ctx = ctx
         self.cfg = _native.PipelineConfig()
@@ -45,6 +46,8 @@ class Pipeline:
         c.redetect_fraction = float(redetect_fraction)
         c.debug_fault_every = int(debug_fault_every)
         c.redetect_start_pose = {"identity": 0, "current": 1}[redetect_start_pose]
+        c.sequences = int(sequences)
+        self.sequences = int(sequences)
         K = np.asarray(K, np.float64).reshape(3, 3)
         self.K = K
         for i, v in enumerate(K.reshape(9)):
@@ -71,10 +74,10 @@ class Pipeline:
             pass
 
     # ---- inputs ----
-    def set_frame(self, idx, img):
+    def set_frame(self, idx, img, seq=0):
         img = _c(img, np.uint8)
         assert img.shape == (self.cfg.H, self.cfg.W)
-        self.ctx._chk(self.ctx._lib.vo_pipeline_set_frame(self._h, int(idx), _ptr(img)))
+        self.ctx._chk(self.ctx._lib.vo_pipeline_set_frame_seq(self._h, int(seq), int(idx), _ptr(img)))
 
     def seed(self, generator):
         """The estimator's generator (RANSAC.rng, src/vo/algorithms/ransac.py:52)."""
@@ -82,14 +85,14 @@ class Pipeline:
         pcg = _native.Pcg64.from_generator(generator)
         self.ctx._chk(self.ctx._lib.vo_pipeline_seed(self._h, C.byref(pcg)))
 
-    def rng_state_into(self, generator):
+    def rng_state_into(self, generator, seq=0):
         """Writes the estimator generator's state after the last collected step into `generator`."""
         from vo import _native
         pcg = _native.Pcg64()
-        self.ctx._chk(self.ctx._lib.vo_pipeline_get_rng(self._h, C.byref(pcg)))
+        self.ctx._chk(self.ctx._lib.vo_pipeline_get_rng_seq(self._h, int(seq), C.byref(pcg)))
         pcg.to_generator(generator)
 
-    def set_state(self, idx, features, curr_pose, prev_pose=None, num_features=None):
+    def set_state(self, idx, features, curr_pose, prev_pose=None, num_features=None, seq=0):
         """Hands over `features` (a vo.primitives.Features: the current frame's, e.g. after the bootstrap) and
         State's poses (4x4 camera-to-world) for frame slot `idx`."""
         n = features.length
@@ -102,12 +105,12 @@ class Pipeline:
         T_wc_prev = _as_4x4(prev_pose if prev_pose is not None else curr_pose)
         T_cw, T_cw_prev = _c(np.linalg.inv(T_wc), np.float64), _c(np.linalg.inv(T_wc_prev), np.float64)
         nf = int(num_features if num_features is not None else self.cfg.n_keypoints)
-        self.ctx._chk(self.ctx._lib.vo_pipeline_set_state(self._h, int(idx), n, _ptr(kp), _ptr(state), _ptr(land),
-                                                          _ptr(tracks), _ptr(poses), _ptr(T_wc), _ptr(T_cw),
-                                                          _ptr(T_wc_prev), _ptr(T_cw_prev), nf))
+        self.ctx._chk(self.ctx._lib.vo_pipeline_set_state_seq(self._h, int(seq), int(idx), n, _ptr(kp), _ptr(state),
+                                                              _ptr(land), _ptr(tracks), _ptr(poses), _ptr(T_wc),
+                                                              _ptr(T_cw), _ptr(T_wc_prev), _ptr(T_cw_prev), nf))
 
     # ---- outputs ----
-    def get_state(self):
+    def get_state(self, seq=0):
         """dict with the reference's Features arrays of the current frame (shapes as in
         src/vo/primitives/features.py) plus curr_pose / prev_pose / RANSAC fields."""
         from vo import _native
@@ -122,9 +125,9 @@ class Pipeline:
         poses = np.empty((cap, 4, 4), np.float64)
         T, Tp = np.empty((4, 4)), np.empty((4, 4))
         rs = _native.RansacState()
-        self.ctx._chk(self.ctx._lib.vo_pipeline_get_state(self._h, C.byref(n), _ptr(kp), _ptr(state), _ptr(cand),
-                                                          _ptr(land), _ptr(tracks), _ptr(poses), _ptr(T), _ptr(Tp),
-                                                          C.byref(rs), C.byref(nf)))
+        self.ctx._chk(self.ctx._lib.vo_pipeline_get_state_seq(self._h, int(seq), C.byref(n), _ptr(kp), _ptr(state),
+                                                              _ptr(cand), _ptr(land), _ptr(tracks), _ptr(poses),
+                                                              _ptr(T), _ptr(Tp), C.byref(rs), C.byref(nf)))
         n = n.value
         return dict(n=n, keypoints=kp[:n].reshape(n, 2, 1).copy(), state=state[:n].astype(np.float64),
                     candidate_mask=cand[:n].astype(bool), landmarks=land[:n].reshape(n, 3, 1).copy(),
@@ -132,10 +135,10 @@ class Pipeline:
                     n_iterations=int(rs.n_iterations), outlier_ratio=float(rs.outlier_ratio),
                     num_features=nf.value)
 
-    def get_features(self):
+    def get_features(self, seq=0):
         """The current frame's features as a vo.primitives.Features object."""
         from vo.primitives import Features
-        s = self.get_state()
+        s = self.get_state(seq)
         f = Features(keypoints=s["keypoints"], landmarks=s["landmarks"])
         f.state, f.tracks, f.poses, f.candidate_mask = s["state"], s["tracks"], s["poses"], s["candidate_mask"]
         return f
@@ -163,6 +166,13 @@ class Pipeline:
         self.ctx._chk(self.ctx._lib.vo_pipeline_collect(self._h, C.byref(r)))
         return r
 
+    def collect_all(self):
+        """Wait for the oldest submitted frame's records of all sequences (a list of StepResult)."""
+        from vo import _native
+        rs = (_native.StepResult * self.sequences)()
+        self.ctx._chk(self.ctx._lib.vo_pipeline_collect_all(self._h, rs))
+        return list(rs)
+
     def bookkeeping(self, phases, new_keypoints=None, pairs=None, pose_world_cam=None, p3p_inliers=None):
         """One frame's bookkeeping with the estimators' outputs given by the caller (vo_pipeline_bookkeeping)."""
         if phases & 1:
@@ -188,9 +198,10 @@ class Pipeline:
     def prof_reset(self):
         self.ctx._chk(self.ctx._lib.vo_pipeline_prof_reset(self._h))
 
-    def export_state_post(self, result, cap, d_record):
+    def export_state_post(self, result, cap, d_record, seq=0):
         """Queues the shared-map record of the last collected step on the pipeline's stream (no synchronisation)."""
-        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_post(self._h, C.byref(result), int(cap), C.c_void_p(d_record)))
+        self.ctx._chk(self.ctx._lib.vo_pipeline_export_state_post_seq(self._h, int(seq), C.byref(result), int(cap),
+                                                                      C.c_void_p(d_record)))
 
     def export_state_join(self, consumer_stream=None):
         """Orders the records posted so far before later work of `consumer_stream`, and later records after
