@@ -77,7 +77,7 @@ ROCPROF_NAMES = {"klt_track": "klt_track16_kernel<15, 16>", "nms_round": "nms_ro
                  "nms_candidates": "nms_candidates_kernel<5>", "harris_response": "harris_response_kernel<9>",
                  "p3p_solve": "p3p_solve_kernel<true>", "p3p_score": "p3p_score_kernel", "nms_compact": "nms_compact_kernel",
                  "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel", "refine_pose": "refine_pose_kernel",
-                 "pyr_down": "pyramid3_kernel", "state_regroup": "state_regroup_klt_kernel",
+                 "pyr_down": "pyramid3_tiled_kernel", "state_regroup": "state_regroup_klt_kernel",
                  "ransac_replay": "ransac_replay_kernel", "state_candidates": "state_candidates_kernel",
                  "state_landmarks": "state_landmarks_kernel"}
 
@@ -307,6 +307,9 @@ def main():
     ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
                     help="one blocking vo_pipeline_step per frame instead of submitting frame k+1 before "
                          "collecting frame k (vo_pipeline_submit / _collect)")
+    ap.add_argument("--sequences", type=int, default=int(os.environ.get("VO_BENCH_SEQUENCES", "1")),
+                    help="independent sequences per GPU advancing through the same launches (vo_pipeline_config.sequences); "
+                         "the headline stays at 1, profiles/ holds the lines for 4 and 16")
     ap.add_argument("--exchange", action="store_true",
                     help="run the all-gather of {pose, landmarks} records even on one GPU (always on for --gpus > 1)")
     args = ap.parse_args()
@@ -335,23 +338,28 @@ def main():
     # torch's own (null-stream) work first, then the pipeline's streams: a stream is attached to one of the four
     # hardware queues when it first runs, and the frame loop's four streams should not share one among themselves
     cap = N_KP
+    S = max(1, args.sequences)
     rec_len = sharding.record_length(cap)
-    recs = [torch.zeros(EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
-    gathered = [torch.zeros(world * EXCHANGE_EVERY * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
+    recs = [torch.zeros(EXCHANGE_EVERY * S * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
+    gathered = [torch.zeros(world * EXCHANGE_EVERY * S * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
     torch.cuda.synchronize()
     comp = torch.cuda.Stream()
     comm = torch.cuda.Stream()
     os.environ["VO_DEVICE"] = str(local)
     ctx = _native.Context(local, stream=comp.cuda_stream)
     _native.set_default_context(ctx)      # the host classes of the bootstrap run on the same context / stream
-    stream = synthetic.Stream(N_FRAMES, H, W, seed=2023 + rank)
+    # every sequence of every rank is its own scene (its own texture seed), bootstrapped by itself
+    streams = [synthetic.Stream(N_FRAMES, H, W, seed=2023 + rank * S + q) for q in range(S)]
+    stream = streams[0]
     pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
                             hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
-                            refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE)
-    state = bootstrap_state(stream)
-    for i in range(N_FRAMES):
-        pipe.set_frame(i, stream.image(i))
-    pipe.set_state(2, state.curr_frame.features, state.curr_pose, state.prev_pose, num_features=N_KP)
+                            refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, sequences=S)
+    states = [bootstrap_state(st) for st in streams]
+    state = states[0]
+    for q in range(S):
+        for i in range(N_FRAMES):
+            pipe.set_frame(i, streams[q].image(i), seq=q)
+        pipe.set_state(2, states[q].curr_frame.features, states[q].curr_pose, states[q].prev_pose, num_features=N_KP, seq=q)
     n_boot = int((state.curr_frame.features.state == 2).sum())
 
     batch_fill, batch_buf = 0, 0
@@ -375,22 +383,24 @@ def main():
             if la:
                 if k + 1 < n:
                     pipe.submit(order[pos], order[pos + 1])
-                r = pipe.collect()
+                rs = pipe.collect_all()
             else:
-                r = pipe.step(a, b)
+                pipe.submit(a, b)
+                rs = pipe.collect_all()
             if exchange:
                 # The record of every collected step is queued on the pipeline's stream (no host synchronisation);
                 # every EXCHANGE_EVERY frames the records gathered so far go to all ranks in ONE all-gather on the
                 # side stream (fewer, larger collectives: issuing one costs the host ~45 us, a third of a step).
-                pipe.export_state_post(r, cap, recs[batch_buf].data_ptr() + batch_fill * rec_len * 8)
-                batch_fill += 1
-                if batch_fill == EXCHANGE_EVERY or k == n - 1:
+                for q in range(S):
+                    pipe.export_state_post(rs[q], cap, recs[batch_buf].data_ptr() + batch_fill * rec_len * 8, seq=q)
+                    batch_fill += 1
+                if batch_fill == EXCHANGE_EVERY * S or k == n - 1:
                     pipe.export_state_join(comm.cuda_stream)
                     sharding.allgather_records(recs[batch_buf], gathered[batch_buf])
                     batch_buf ^= 1
                     batch_fill = 0
             if record:
-                out.append((b, r))
+                out.append((b, rs))
         return out
 
     def fence():
@@ -448,15 +458,21 @@ def main():
     dt_max = float(dt_t.item())
 
     if rank == 0:
-        res = [r for _, r in timed]
-        n_in = int(np.median([r.n_features_in for r in res]))
-        n_trk = int(np.median([r.n_tracked for r in res]))
-        n_tri = int(np.median([r.n_triangulated for r in res]))
+        every = [r for _, rs in timed for r in rs]           # all sequences' records
+        res = [rs[0] for _, rs in timed]                     # sequence 0: chain stamps, ground truth, oracle
+        n_in = int(np.median([r.n_features_in for r in every]))
+        n_trk = int(np.median([r.n_tracked for r in every]))
+        n_tri = int(np.median([r.n_triangulated for r in every]))
         avg_us = dom_ms / max(dom_n, 1) * 1e3
-        ab = algorithmic_bytes(dom_name, n_in, n_trk, n_tri)
+
+        def abytes(k):                                       # one launch processes all S sequences
+            v = algorithmic_bytes(k, n_in, n_trk, n_tri)
+            return None if v is None else v * S
+
+        ab = abytes(dom_name)
         roof = {"bound": "hbm", "kernel": dom_name, "avg_launch_us": round(avg_us, 3), "launches": dom_n,
-                "algorithmic_bytes_per_launch": ab, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "traffic": pmc_traffic(dom_name)}
+                "algorithmic_bytes_per_launch": ab, "sequences_per_launch": S, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "traffic": pmc_traffic(dom_name) if S == 1 else None}
         if ab and avg_us > 0:
             ach = ab / (avg_us * 1e-6) / 1e9
             roof["achieved"] = round(ach, 2)
@@ -472,7 +488,8 @@ def main():
         # frames 0 and 2, 1.6 m apart), positions compared after that one scale
         scale = 2 * synthetic.STEP_Z / max(np.linalg.norm(state.curr_pose[:3, 3]), 1e-12)
         gt_err = []
-        for b, r in early:
+        for b, rs in early:
+            r = rs[0]
             Twc = r.pose_world_cam()
             gt = np.linalg.inv(stream.T_world_cam(0)) @ stream.T_world_cam(b)
             gt_err.append((float(np.linalg.norm(Twc[:3, :3] - gt[:3, :3])), float(np.linalg.norm(scale * Twc[:3, 3] - gt[:3, 3]))))
@@ -497,7 +514,7 @@ def main():
                  "unit": "us, medians over the timed steps, from wall_clock64() stamps of each kernel's first work item"}
         out = {
             "metric": "VO frames/sec at 1376x1241, 2k keypoints; pose err vs reference",
-            "value": round(world * args.steps / dt_max, 2),
+            "value": round(world * S * args.steps / dt_max, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -514,26 +531,26 @@ def main():
                                    "candidate DLT, cheirality; one independent sequence per GPU",
                        "step_contains": "all of the above, device-resident (Features/State/RANSAC never leave HBM); "
                                         "landmarks are the loop's own triangulations after a host two-view bootstrap",
-                       "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP, "sequences_per_gpu": 1,
+                       "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP, "sequences_per_gpu": S,
                        "frame_lookahead": 1 if args.lookahead else 0, "redetect_start_pose": REDETECT_POSE,
                        "rccl_world_size": dist.get_world_size() if exchange else 1,
-                       "parallelism": "sequence-sharded x%d%s" % (world, ", RCCL all-gather of the {pose, landmarks} records of %d frames every %d frames" % (EXCHANGE_EVERY, EXCHANGE_EVERY) if exchange else "")},
+                       "parallelism": "sequence-sharded x%d%s%s" % (world, ", %d sequences per GPU per launch" % S if S > 1 else "", ", RCCL all-gather of the {pose, landmarks} records of %d frames every %d frames" % (EXCHANGE_EVERY, EXCHANGE_EVERY) if exchange else "")},
             "roofline": roof,
             # the image-wide (streaming) kernels against the same HBM peak, from the untimed all-kernel event pass
             "roofline_streaming": {k: {"avg_launch_us": round(us(k), 2),
-                                       "algorithmic_bytes_per_launch": algorithmic_bytes(k, n_in, n_trk, n_tri),
-                                       "achieved": round(algorithmic_bytes(k, n_in, n_trk, n_tri) / (us(k) * 1e-6) / 1e9, 1),
-                                       "frac": round(algorithmic_bytes(k, n_in, n_trk, n_tri) / (us(k) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                                       "algorithmic_bytes_per_launch": abytes(k),
+                                       "achieved": round(abytes(k) / (us(k) * 1e-6) / 1e9, 1),
+                                       "frac": round(abytes(k) / (us(k) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                                    for k in ("harris_response", "nms_candidates", "pyr_down") if k in per_kernel},
             "per_kernel_us": {k: round(us(k), 2) for k in sorted(per_kernel)},
             "chain_us": chain,
             "loop": {"features_in_median": n_in, "tracked_median": n_trk, "landmarks_p3p_median": n_tri,
-                     "inliers_median": float(np.median([r.n_inliers for r in res])),
-                     "candidates_median": float(np.median([r.n_candidates for r in res])),
-                     "ransac_iters_median": float(np.median([r.ransac_iterations for r in res])),
-                     "redetect_fraction_of_steps": float(np.mean([r.redetected for r in res])),
-                     "steps_finished_by_host_path": int(sum(r.recovered for r in res)),
-                     "refine_steps_median": float(np.median([r.refine_iterations for r in res])),
+                     "inliers_median": float(np.median([r.n_inliers for r in every])),
+                     "candidates_median": float(np.median([r.n_candidates for r in every])),
+                     "ransac_iters_median": float(np.median([r.ransac_iterations for r in every])),
+                     "redetect_fraction_of_steps": float(np.mean([r.redetected for r in every])),
+                     "steps_finished_by_host_path": int(sum(r.recovered for r in every)),
+                     "refine_steps_median": float(np.median([r.refine_iterations for r in every])),
                      "bootstrap_landmarks": n_boot},
             "pose_err_vs_ground_truth": {"rot_fro_median": float(np.median([e[0] for e in gt_err])),
                                          "trans_m_median": float(np.median([e[1] for e in gt_err])),
@@ -543,7 +560,7 @@ def main():
                                                  "monocular scale fixed once by the bootstrap baseline"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            parity, base = oracle_leg(stream, state, [r for _, r in first], first_state, ORACLE_FRAMES)
+            parity, base = oracle_leg(stream, state, [rs[0] for _, rs in first], first_state, ORACLE_FRAMES)
             out["pose_vs_oracle"] = parity
             out["cpu_baseline"] = base
         if world == 1 and not args.no_api:

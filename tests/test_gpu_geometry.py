@@ -102,6 +102,37 @@ def test_pyr_down_bit_exact(ctx, shape):
     assert np.array_equal(ctx.pyr_down(img), native.pyr_down(img))
 
 
+@pytest.mark.parametrize("shape,levels", [((240, 320), 3), ((200, 264), 3), ((203, 262), 3), ((1241, 1376), 3),
+                                          ((621, 700), 4), ((130, 132), 2)])
+def test_bordered_pyramid_bit_exact(ctx, shape, levels):
+    """vo_pyramid_build_dev: every level with its 32-pixel reflect-101 border, as the tracker reads it.  Widths that
+    are multiples of 4 take the word-wide tiled kernel (levels 0..2 in one launch), the others the byte kernels;
+    both must equal pyrDown level by level, and the border must mirror the interior (np.pad 'reflect')."""
+    PAD = 32
+    H, W = shape
+    rng = np.random.default_rng(H * 7 + W)
+    img = rng.integers(0, 256, size=shape).astype(np.uint8)
+    nbytes = ctx.pyramid_bytes(H, W, levels)
+    d_img = ctx.to_device(img)
+    d_pyr = ctx.to_device(np.full(nbytes, 0xAB, np.uint8))
+    ctx.pyramid_build_dev(d_img, H, W, levels, d_pyr)
+    ctx.sync()
+    got = ctx.download(d_pyr, (nbytes,), np.uint8)
+    ctx.free(d_img)
+    ctx.free(d_pyr)
+    off, lvl, h, w = 0, img, H, W
+    for l in range(levels):
+        pitch = (w + 2 * PAD + 3) & ~3
+        rows = h + 2 * PAD
+        g = got[off:off + rows * pitch].reshape(rows, pitch)[:, :w + 2 * PAD]
+        ref = np.pad(lvl, PAD, mode="reflect")
+        assert np.array_equal(g[PAD:PAD + h, PAD:PAD + w], lvl), "level %d interior" % l
+        assert np.array_equal(g, ref), "level %d border" % l
+        off += (rows * pitch + 255) & ~255
+        lvl = native.pyr_down(lvl)
+        h, w = (h + 1) // 2, (w + 1) // 2
+
+
 @pytest.mark.parametrize("dx,dy,win,lvl", [(1.3, -0.7, 17, 2), (5.6, 3.2, 17, 2), (-9.5, 6.25, 15, 2),
                                            (2.0, 1.0, 21, 3), (0.4, 0.2, 9, 0), (1.3, -0.7, 15, 2),
                                            (1.3, -0.7, 21, 2), (-0.37, 0.81, 17, 3)])

@@ -255,6 +255,175 @@ __global__ __launch_bounds__(256) void pyramid3_kernel(const uint8_t* __restrict
   }
 }
 
+// ---- the same three levels, word-wide: one workgroup per 64x32 tile of level 1 ----
+// pyramid3_kernel moves single bytes (global loads, LDS, stores) and spends a workgroup per 16x16 tile of level
+// 2 on a 35x35 level-1 patch of its own: 20 us per frame however many frames a launch holds.  Here a workgroup
+//   A  stages the frame patch under its level-1 tile + the 2-pixel ring level 2 needs (144 x 75 bytes) as aligned
+//      dwords, every load issued before the first LDS store; out-of-frame bytes are reflected while staging;
+//   B  copies the patch's centre into the bordered level 0 (dword stores);
+//   C  makes the 68x36 level-1 region, two neighbours per work item from three dwords per patch row, into LDS;
+//   D  stores its 64x32 centre to level 1 (dwords) and E makes the 32x16 tile of level 2 from the region.
+// Border pixels are written by the owner of the interior pixel they mirror (edge tiles only).
+// Needs W % 4 == 0 and a 4-byte aligned frame (the host picks the byte kernel otherwise).
+constexpr int PT_X = 64, PT_Y = 32;                 // level-1 tile
+constexpr int PT_RX = PT_X + 4, PT_RY = PT_Y + 4;   // level-1 region (ring of 2)
+constexpr int PT_FD = (2 * PT_X + 16) / 4;          // frame patch: dwords per row (virtual columns 2 x1a - 8 ..)
+constexpr int PT_FR = 2 * PT_Y + 11;                // frame patch rows (virtual rows 2 y1a - 6 ..)
+constexpr int PT_L1P = PT_RX + 4;                   // level-1 region pitch in bytes; entry lx sits at byte lx + 2
+
+// seven bytes starting at byte 2 of dword a: two neighbouring 5-tap row sums
+__device__ __forceinline__ void tap_pair(unsigned a, unsigned b, unsigned c, int& ra, int& rb) {
+  const int p0 = (a >> 16) & 255, p1 = a >> 24, p2 = b & 255, p3 = (b >> 8) & 255, p4 = (b >> 16) & 255, p5 = b >> 24,
+            p6 = c & 255;
+  ra = p0 + 4 * p1 + 6 * p2 + 4 * p3 + p4;
+  rb = p2 + 4 * p3 + 6 * p4 + 4 * p5 + p6;
+}
+
+__device__ __forceinline__ int reflect_once(int c, int n) {
+  c = c < 0 ? -c : (c >= n ? 2 * (n - 1) - c : c);
+  return min(max(c, 0), n - 1);
+}
+
+__global__ __launch_bounds__(256) void pyramid3_tiled_kernel(const uint8_t* __restrict__ src, int H0, int W0,
+                                                             uint8_t* __restrict__ d0, int p0, uint8_t* __restrict__ d1,
+                                                             int p1, int H1, int W1, uint8_t* __restrict__ d2, int p2,
+                                                             int H2, int W2, int tiles_x, size_t img_stride,
+                                                             size_t pyr_stride) {
+  src += (size_t)blockIdx.y * img_stride;
+  d0 += (size_t)blockIdx.y * pyr_stride;
+  d1 += (size_t)blockIdx.y * pyr_stride;
+  d2 += (size_t)blockIdx.y * pyr_stride;
+  __shared__ unsigned s_f[PT_FR * PT_FD];
+  __shared__ __attribute__((aligned(4))) uint8_t s_l1[PT_RY * PT_L1P];
+  const int tid = threadIdx.x;
+  const int x1a = ((int)blockIdx.x % tiles_x) * PT_X, y1a = ((int)blockIdx.x / tiles_x) * PT_Y;
+  const int gx0 = 2 * x1a - 8, gy0 = 2 * y1a - 6;
+  // ---- A: frame patch ----
+  {
+    constexpr int PER = (PT_FR * PT_FD + 255) / 256;
+    unsigned v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * 256;
+      const int r = i / PT_FD, d = i - r * PT_FD;
+      const int gy = reflect_once(gy0 + r, H0);
+      const int gx = gx0 + 4 * d;
+      const uint8_t* row = src + (size_t)gy * W0;
+      if (gx >= 0 && gx + 3 < W0) {
+        v[k] = *reinterpret_cast<const unsigned*>(row + gx);
+      } else {
+        unsigned w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w |= (unsigned)row[reflect_once(gx + b, W0)] << (8 * b);
+        v[k] = w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * 256;
+      if (i < PT_FR * PT_FD) s_f[i] = v[k];
+    }
+  }
+  __syncthreads();
+  // ---- B: level 0 = the patch's centre (rows 6 .., dwords 2 ..) ----
+  {
+    const bool edge0 = 2 * x1a <= PYR_PAD || 2 * x1a + 2 * PT_X >= W0 - 1 - PYR_PAD || 2 * y1a <= PYR_PAD ||
+                       2 * y1a + 2 * PT_Y >= H0 - 1 - PYR_PAD;
+    for (int i = tid; i < 2 * PT_Y * (2 * PT_X / 4); i += 256) {
+      const int r = i / (2 * PT_X / 4), d = i - r * (2 * PT_X / 4);
+      const int y0 = 2 * y1a + r, x0 = 2 * x1a + 4 * d;
+      if (y0 >= H0 || x0 >= W0) continue;                       // (W0 % 4 == 0: a dword is inside or outside)
+      const unsigned w = s_f[(r + 6) * PT_FD + d + 2];
+      *reinterpret_cast<unsigned*>(d0 + (size_t)(y0 + PYR_PAD) * p0 + x0 + PYR_PAD) = w;
+      if (edge0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) store_with_mirrors(d0, p0, H0, W0, x0 + b, y0, (uint8_t)(w >> (8 * b)), true);
+      }
+    }
+  }
+  // ---- C: level-1 region ----
+  {
+    const int lox = max(x1a - 2, 0), hix = min(x1a + PT_X + 1, W1 - 1);
+    const int loy = max(y1a - 2, 0), hiy = min(y1a + PT_Y + 1, H1 - 1);
+    const bool plain_x = x1a - 2 >= 0 && x1a + PT_X + 1 < W1;   // no reflection along x: neighbours are neighbours
+    for (int i = tid; i < PT_RY * (PT_RX / 2); i += 256) {
+      const int ly = i / (PT_RX / 2), j = i - ly * (PT_RX / 2);
+      int yr = reflect101(y1a - 2 + ly, H1);
+      yr = min(max(yr, loy), hiy);                              // (only entries no stored pixel uses are clamped)
+      const unsigned* prow = s_f + (2 * (yr - y1a) + 4) * PT_FD;
+      int sa = 0, sb = 0;
+      if (plain_x) {
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+          const unsigned* q = prow + jj * PT_FD + j;
+          int ra, rb;
+          tap_pair(q[0], q[1], q[2], ra, rb);
+          const int wj = (jj == 0 || jj == 4) ? 1 : ((jj == 2) ? 6 : 4);
+          sa += wj * ra;
+          sb += wj * rb;
+        }
+      } else {
+        const uint8_t* pb = reinterpret_cast<const uint8_t*>(prow);
+        int xa = reflect101(x1a - 2 + 2 * j, W1), xb = reflect101(x1a - 1 + 2 * j, W1);
+        xa = min(max(xa, lox), hix);
+        xb = min(max(xb, lox), hix);
+        const uint8_t* qa = pb + 2 * (xa - x1a) + 6;
+        const uint8_t* qb = pb + 2 * (xb - x1a) + 6;
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+          const uint8_t* ra = qa + jj * PT_FD * 4;
+          const uint8_t* rb = qb + jj * PT_FD * 4;
+          const int wj = (jj == 0 || jj == 4) ? 1 : ((jj == 2) ? 6 : 4);
+          sa += wj * (ra[0] + 4 * ra[1] + 6 * ra[2] + 4 * ra[3] + ra[4]);
+          sb += wj * (rb[0] + 4 * rb[1] + 6 * rb[2] + 4 * rb[3] + rb[4]);
+        }
+      }
+      const unsigned va = (unsigned)((sa + 128) >> 8), vb = (unsigned)((sb + 128) >> 8);
+      *reinterpret_cast<unsigned short*>(s_l1 + ly * PT_L1P + 2 + 2 * j) = (unsigned short)(va | (vb << 8));
+    }
+  }
+  __syncthreads();
+  // ---- D: level 1 = the region's centre (entries 2 .., bytes 4 ..) ----
+  {
+    const bool edge1 = x1a <= PYR_PAD || x1a + PT_X >= W1 - 1 - PYR_PAD || y1a <= PYR_PAD || y1a + PT_Y >= H1 - 1 - PYR_PAD;
+    for (int i = tid; i < PT_Y * (PT_X / 4); i += 256) {
+      const int r = i / (PT_X / 4), d = i - r * (PT_X / 4);
+      const int y1 = y1a + r, x1 = x1a + 4 * d;
+      if (y1 >= H1 || x1 >= W1) continue;
+      const unsigned w = *reinterpret_cast<const unsigned*>(s_l1 + (r + 2) * PT_L1P + 4 + 4 * d);
+      uint8_t* own = d1 + (size_t)(y1 + PYR_PAD) * p1 + x1 + PYR_PAD;
+      if (x1 + 3 < W1) {
+        *reinterpret_cast<unsigned*>(own) = w;
+      } else {
+        for (int b = 0; x1 + b < W1; ++b) own[b] = (uint8_t)(w >> (8 * b));
+      }
+      if (edge1) {
+        for (int b = 0; b < 4 && x1 + b < W1; ++b) store_with_mirrors(d1, p1, H1, W1, x1 + b, y1, (uint8_t)(w >> (8 * b)), true);
+      }
+    }
+  }
+  // ---- E: level 2 from the region: pixel (x1a / 2 + lx, y1a / 2 + ly) taps region entries 2 lx .. 2 lx + 4 ----
+  {
+    const int j = tid & (PT_X / 4 - 1), ly = tid / (PT_X / 4);           // 16 pairs x 16 rows
+    const int x2 = x1a / 2 + 2 * j, y2 = y1a / 2 + ly;
+    if (x2 < W2 && y2 < H2) {
+      int sa = 0, sb = 0;
+#pragma unroll
+      for (int jj = 0; jj < 5; ++jj) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(s_l1 + (2 * ly + jj) * PT_L1P) + j;
+        int ra, rb;
+        tap_pair(q[0], q[1], q[2], ra, rb);
+        const int wj = (jj == 0 || jj == 4) ? 1 : ((jj == 2) ? 6 : 4);
+        sa += wj * ra;
+        sb += wj * rb;
+      }
+      store_with_mirrors(d2, p2, H2, W2, x2, y2, (uint8_t)((sa + 128) >> 8));
+      if (x2 + 1 < W2) store_with_mirrors(d2, p2, H2, W2, x2 + 1, y2, (uint8_t)((sb + 128) >> 8));
+    }
+  }
+}
+static_assert(PT_Y * (PT_X / 4) == 512 && (PT_Y / 2) * (PT_X / 4) == 256, "level-2 pass: one pair per work item");
+
 // Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic), result in
 // every lane.  Steps: within quads, within half rows, within rows of 16, then the two
 // row broadcasts that gfx9 provides for wave64.
@@ -989,9 +1158,15 @@ int vo_pyramid_build_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_str
     // levels 0..2 in one launch
     uint8_t* d1 = dst;
     uint8_t* d2 = d1 + pyr_level_bytes(h1, w1);
-    const int tiles2_x = vo_cdiv(w2, 16), nB = tiles2_x * vo_cdiv(h2, 16);
-    const int blocks1_x = vo_cdiv(w1, 32), nA = blocks1_x * vo_cdiv(h1, 8);
-    {
+    if (W % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && (img_stride & 3) == 0 && (pyr_stride & 3) == 0 && ((uintptr_t)d_pyr & 3) == 0) {
+      const int tiles_x = vo_cdiv(w1, PT_X);
+      vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
+      hipLaunchKernelGGL(pyramid3_tiled_kernel, dim3(tiles_x * vo_cdiv(h1, PT_Y), S), dim3(256), 0, ctx->stream, d_img, H, W,
+                         d_pyr, pyr_pitch(W), d1, pyr_pitch(w1), h1, w1, d2, pyr_pitch(w2), h2, w2, tiles_x, img_stride,
+                         pyr_stride);
+    } else {
+      const int tiles2_x = vo_cdiv(w2, 16), nB = tiles2_x * vo_cdiv(h2, 16);
+      const int blocks1_x = vo_cdiv(w1, 32), nA = blocks1_x * vo_cdiv(h1, 8);
       vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
       hipLaunchKernelGGL(pyramid3_kernel, dim3(nB + nA, S), dim3(256), 0, ctx->stream, d_img, H, W, d_pyr, pyr_pitch(W), d1,
                          pyr_pitch(w1), h1, w1, d2, pyr_pitch(w2), h2, w2, nB, tiles2_x, blocks1_x, img_stride, pyr_stride);
