@@ -108,6 +108,22 @@ def test_bordered_pyramid_bit_exact(ctx, shape, levels):
     """vo_pyramid_build_dev: every level with its 32-pixel reflect-101 border, as the tracker reads it.  Widths that
     are multiples of 4 take the word-wide tiled kernel (levels 0..2 in one launch), the others the byte kernels;
     both must equal pyrDown level by level, and the border must mirror the interior (np.pad 'reflect')."""
+    run_pyramid_case(ctx, shape, levels)
+
+
+def test_bordered_pyramid_large_tiles_bit_exact():
+    """The 64x32-tile variant the batched launches take (VO_PYR_TILE is read once per process: own process)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path[:0] = %r; import test_gpu_geometry as t; from vo import _native; c = _native.Context(0); "
+            "[t.run_pyramid_case(c, s, 3) for s in ((240, 320), (200, 264), (1241, 1376), (621, 700))]; c.close(); print('ok')"
+            % [p for p in sys.path if p])
+    env = dict(os.environ, VO_PYR_TILE="64")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def run_pyramid_case(ctx, shape, levels):
     PAD = 32
     H, W = shape
     rng = np.random.default_rng(H * 7 + W)

@@ -265,11 +265,8 @@ __global__ __launch_bounds__(256) void pyramid3_kernel(const uint8_t* __restrict
 //   D  stores its 64x32 centre to level 1 (dwords) and E makes the 32x16 tile of level 2 from the region.
 // Border pixels are written by the owner of the interior pixel they mirror (edge tiles only).
 // Needs W % 4 == 0 and a 4-byte aligned frame (the host picks the byte kernel otherwise).
-constexpr int PT_X = 64, PT_Y = 32;                 // level-1 tile
-constexpr int PT_RX = PT_X + 4, PT_RY = PT_Y + 4;   // level-1 region (ring of 2)
-constexpr int PT_FD = (2 * PT_X + 16) / 4;          // frame patch: dwords per row (virtual columns 2 x1a - 8 ..)
-constexpr int PT_FR = 2 * PT_Y + 11;                // frame patch rows (virtual rows 2 y1a - 6 ..)
-constexpr int PT_L1P = PT_RX + 4;                   // level-1 region pitch in bytes; entry lx sits at byte lx + 2
+// Tile size: 64x32 when a launch holds several frames (less halo work per pixel), 32x16 for a single frame (four
+// times the workgroups, each a third of the latency: the launch is on the tracker's critical path then).
 
 // seven bytes starting at byte 2 of dword a: two neighbouring 5-tap row sums
 __device__ __forceinline__ void tap_pair(unsigned a, unsigned b, unsigned c, int& ra, int& rb) {
@@ -284,11 +281,17 @@ __device__ __forceinline__ int reflect_once(int c, int n) {
   return min(max(c, 0), n - 1);
 }
 
+template <int PT_X, int PT_Y>
 __global__ __launch_bounds__(256) void pyramid3_tiled_kernel(const uint8_t* __restrict__ src, int H0, int W0,
                                                              uint8_t* __restrict__ d0, int p0, uint8_t* __restrict__ d1,
                                                              int p1, int H1, int W1, uint8_t* __restrict__ d2, int p2,
                                                              int H2, int W2, int tiles_x, size_t img_stride,
                                                              size_t pyr_stride) {
+  constexpr int PT_RX = PT_X + 4, PT_RY = PT_Y + 4;   // level-1 region (ring of 2)
+  constexpr int PT_FD = (2 * PT_X + 16) / 4;          // frame patch: dwords per row (virtual columns 2 x1a - 8 ..)
+  constexpr int PT_FR = 2 * PT_Y + 11;                // frame patch rows (virtual rows 2 y1a - 6 ..)
+  constexpr int PT_L1P = PT_RX + 4;                   // level-1 region pitch in bytes; entry lx sits at byte lx + 2
+  static_assert(PT_X % 4 == 0 && PT_Y % 2 == 0, "tile: whole dwords per row, whole level-2 rows");
   src += (size_t)blockIdx.y * img_stride;
   d0 += (size_t)blockIdx.y * pyr_stride;
   d1 += (size_t)blockIdx.y * pyr_stride;
@@ -403,8 +406,8 @@ __global__ __launch_bounds__(256) void pyramid3_tiled_kernel(const uint8_t* __re
     }
   }
   // ---- E: level 2 from the region: pixel (x1a / 2 + lx, y1a / 2 + ly) taps region entries 2 lx .. 2 lx + 4 ----
-  {
-    const int j = tid & (PT_X / 4 - 1), ly = tid / (PT_X / 4);           // 16 pairs x 16 rows
+  for (int i = tid; i < (PT_Y / 2) * (PT_X / 4); i += 256) {
+    const int ly = i / (PT_X / 4), j = i - ly * (PT_X / 4);
     const int x2 = x1a / 2 + 2 * j, y2 = y1a / 2 + ly;
     if (x2 < W2 && y2 < H2) {
       int sa = 0, sb = 0;
@@ -422,7 +425,6 @@ __global__ __launch_bounds__(256) void pyramid3_tiled_kernel(const uint8_t* __re
     }
   }
 }
-static_assert(PT_Y * (PT_X / 4) == 512 && (PT_Y / 2) * (PT_X / 4) == 256, "level-2 pass: one pair per work item");
 
 // Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic), result in
 // every lane.  Steps: within quads, within half rows, within rows of 16, then the two
@@ -1159,11 +1161,19 @@ int vo_pyramid_build_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_str
     uint8_t* d1 = dst;
     uint8_t* d2 = d1 + pyr_level_bytes(h1, w1);
     if (W % 4 == 0 && ((uintptr_t)d_img & 3) == 0 && (img_stride & 3) == 0 && (pyr_stride & 3) == 0 && ((uintptr_t)d_pyr & 3) == 0) {
-      const int tiles_x = vo_cdiv(w1, PT_X);
       vo_prof_scope ps(ctx, VO_K_PYR_DOWN);
-      hipLaunchKernelGGL(pyramid3_tiled_kernel, dim3(tiles_x * vo_cdiv(h1, PT_Y), S), dim3(256), 0, ctx->stream, d_img, H, W,
-                         d_pyr, pyr_pitch(W), d1, pyr_pitch(w1), h1, w1, d2, pyr_pitch(w2), h2, w2, tiles_x, img_stride,
-                         pyr_stride);
+      static const int forced = getenv("VO_PYR_TILE") ? atoi(getenv("VO_PYR_TILE")) : 0;     // tests: 64 / 32
+      if (forced == 64 || (forced != 32 && (long)S * vo_cdiv(w1, 64) * vo_cdiv(h1, 32) >= 1024)) {
+        const int tiles_x = vo_cdiv(w1, 64);
+        hipLaunchKernelGGL((pyramid3_tiled_kernel<64, 32>), dim3(tiles_x * vo_cdiv(h1, 32), S), dim3(256), 0, ctx->stream,
+                           d_img, H, W, d_pyr, pyr_pitch(W), d1, pyr_pitch(w1), h1, w1, d2, pyr_pitch(w2), h2, w2, tiles_x,
+                           img_stride, pyr_stride);
+      } else {
+        const int tiles_x = vo_cdiv(w1, 32);
+        hipLaunchKernelGGL((pyramid3_tiled_kernel<32, 16>), dim3(tiles_x * vo_cdiv(h1, 16), S), dim3(256), 0, ctx->stream,
+                           d_img, H, W, d_pyr, pyr_pitch(W), d1, pyr_pitch(w1), h1, w1, d2, pyr_pitch(w2), h2, w2, tiles_x,
+                           img_stride, pyr_stride);
+      }
     } else {
       const int tiles2_x = vo_cdiv(w2, 16), nB = tiles2_x * vo_cdiv(h2, 16);
       const int blocks1_x = vo_cdiv(w1, 32), nA = blocks1_x * vo_cdiv(h1, 8);

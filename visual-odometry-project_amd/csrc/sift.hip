@@ -123,8 +123,15 @@ struct oct_t {
   const float* d[NG - 1];
   int H, W, o;
 };
+struct octs_t {
+  oct_t o[MAX_OCT];
+};
 
-__global__ __launch_bounds__(256) void extrema_kernel(oct_t O, int layer, float threshold, int* __restrict__ cand,
+// counters of one vo_sift call (device): [0] extrema candidates, [1] keypoints, [2] overflow flag,
+// [3] refined survivors, [4] rows selected for description
+enum { C_CAND = 0, C_KP = 1, C_OVER = 2, C_SURV = 3, C_SEL = 4 };
+
+__global__ __launch_bounds__(256) void extrema_kernel(oct_t O, int layer, float threshold, int4* __restrict__ cand,
                                                       unsigned* __restrict__ n_cand, unsigned cap) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (c < BORDER || c >= O.W - BORDER || r < BORDER || r >= O.H - BORDER) return;
@@ -143,11 +150,7 @@ __global__ __launch_bounds__(256) void extrema_kernel(oct_t O, int layer, float 
     }
   if (!ext) return;
   const unsigned pos = atomicAdd(n_cand, 1u);
-  if (pos < cap) {
-    cand[3 * pos] = layer;
-    cand[3 * pos + 1] = r;
-    cand[3 * pos + 2] = c;
-  }
+  if (pos < cap) cand[pos] = make_int4(O.o, layer, r, c);
 }
 
 __device__ bool solve3(float A[3][3], float b[3], float x[3]) {
@@ -187,127 +190,265 @@ __device__ bool solve3(float A[3][3], float b[3], float x[3]) {
   return true;
 }
 
-__global__ __launch_bounds__(64) void refine_orient_kernel(oct_t O, const int* __restrict__ cand,
-                                                           const unsigned* __restrict__ n_cand, unsigned cap,
-                                                           float contrast_thr, float edge_thr, float sigma,
-                                                           skp_t* __restrict__ out, unsigned* __restrict__ n_out,
-                                                           unsigned cap_out) {
-  const unsigned k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= min(*n_cand, cap)) return;
-  int layer = cand[3 * k], r = cand[3 * k + 1], c = cand[3 * k + 2];
-  const int W = O.W, H = O.H;
-  const float img_scale = 1.f / 255.f, deriv_scale = img_scale * 0.5f, second = img_scale, cross = img_scale * 0.25f;
-  float xi = 0, xr = 0, xc = 0;
-  int i;
-  for (i = 0; i < 5; ++i) {
-    const float* img = O.d[layer];
-    const float* prv = O.d[layer - 1];
-    const float* nxt = O.d[layer + 1];
-    const size_t p = (size_t)r * W + c;
-    float dD[3] = {(img[p + 1] - img[p - 1]) * deriv_scale, (img[p + W] - img[p - W]) * deriv_scale,
-                   (nxt[p] - prv[p]) * deriv_scale};
-    const float v2 = img[p] * 2;
-    const float dxx = (img[p + 1] + img[p - 1] - v2) * second, dyy = (img[p + W] + img[p - W] - v2) * second,
-                dss = (nxt[p] + prv[p] - v2) * second;
-    const float dxy = (img[p + W + 1] - img[p + W - 1] - img[p - W + 1] + img[p - W - 1]) * cross;
-    const float dxs = (nxt[p + 1] - nxt[p - 1] - prv[p + 1] + prv[p - 1]) * cross;
-    const float dys = (nxt[p + W] - nxt[p - W] - prv[p + W] + prv[p - W]) * cross;
-    float Hm[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
-    float X[3];
-    if (!solve3(Hm, dD, X)) return;
-    xi = -X[2];
-    xr = -X[1];
-    xc = -X[0];
-    if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
-    if (fabsf(xi) > 7e8f || fabsf(xr) > 7e8f || fabsf(xc) > 7e8f) return;
-    c += (int)rintf(xc);
-    r += (int)rintf(xr);
-    layer += (int)rintf(xi);
-    if (layer < 1 || layer > NOL || c < BORDER || c >= W - BORDER || r < BORDER || r >= H - BORDER) return;
-  }
-  if (i >= 5) return;
+// a refined extremum before its orientations are known
+struct surv_t {
   skp_t kp;
-  {
-    const float* img = O.d[layer];
-    const float* prv = O.d[layer - 1];
-    const float* nxt = O.d[layer + 1];
-    const size_t p = (size_t)r * W + c;
-    const float d0 = (img[p + 1] - img[p - 1]) * deriv_scale, d1 = (img[p + W] - img[p - W]) * deriv_scale,
-                d2 = (nxt[p] - prv[p]) * deriv_scale;
-    const float t = d0 * xc + d1 * xr + d2 * xi;
-    const float contr = img[p] * img_scale + t * 0.5f;
-    if (fabsf(contr) * NOL < contrast_thr) return;
-    const float v2 = img[p] * 2.f;
-    const float dxx = (img[p + 1] + img[p - 1] - v2) * second, dyy = (img[p + W] + img[p - W] - v2) * second;
-    const float dxy = (img[p + W + 1] - img[p + W - 1] - img[p - W + 1] + img[p - W - 1]) * cross;
-    const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
-    if (det <= 0 || tr * tr * edge_thr >= (edge_thr + 1) * (edge_thr + 1) * det) return;
-    const float po = (float)(1 << O.o);
-    kp.oct_x = c + xc;
-    kp.oct_y = r + xr;
-    kp.x = (c + xc) * po;
-    kp.y = (r + xr) * po;
-    kp.oct = O.o;
-    kp.layer = layer;
-    kp.size = sigma * sift_exp(((layer + xi) / NOL) * 0.6931471805599453f) * po * 2;
-    kp.response = fabsf(contr);
-  }
-  // ---- orientation histogram (raster order, sequential) ----
-  const float scl_octv = kp.size * 0.5f / (float)(1 << O.o);
-  const int radius = (int)rintf(4.5f * scl_octv);
-  const float osig = 1.5f * scl_octv;
-  const float* g = O.g[layer];
-  float tmp[36];
-#pragma unroll
-  for (int b = 0; b < 36; ++b) tmp[b] = 0.f;
-  const float expf_scale = -1.f / (2.f * osig * osig);
-  for (int ii = -radius; ii <= radius; ++ii) {
-    const int y = r + ii;
-    if (y <= 0 || y >= H - 1) continue;
-    for (int jj = -radius; jj <= radius; ++jj) {
-      const int x = c + jj;
-      if (x <= 0 || x >= W - 1) continue;
-      const float dx = g[(size_t)y * W + x + 1] - g[(size_t)y * W + x - 1];
-      const float dy = g[(size_t)(y - 1) * W + x] - g[(size_t)(y + 1) * W + x];
-      const float w = sift_exp((float)(ii * ii + jj * jj) * expf_scale);
-      const float ori = sift_atan2(dy, dx);
-      const float mag = sqrtf(dx * dx + dy * dy);
-      int bin = (int)rintf(0.1f * ori);
-      if (bin >= 36) bin -= 36;
-      if (bin < 0) bin += 36;
-      const float add = w * mag;
-      // static-index accumulate keeps the histogram in registers
-#pragma unroll
-      for (int b = 0; b < 36; ++b)
-        if (b == bin) tmp[b] += add;
-    }
-  }
-  float hist[36];
-  float mx = 0.f;
-#pragma unroll
-  for (int b = 0; b < 36; ++b) {
-    const float h = (tmp[(b + 34) % 36] + tmp[(b + 2) % 36]) * (1.f / 16.f) +
-                    (tmp[(b + 35) % 36] + tmp[(b + 1) % 36]) * (4.f / 16.f) + tmp[b] * (6.f / 16.f);
-    hist[b] = h;
-    if (h > mx) mx = h;
-  }
-  const float mag_thr = mx * 0.8f;
-#pragma unroll
-  for (int j = 0; j < 36; ++j) {
-    const int l = j > 0 ? j - 1 : 35, rr = j < 35 ? j + 1 : 0;
-    if (hist[j] > hist[l] && hist[j] > hist[rr] && hist[j] >= mag_thr) {
-      float bin = j + 0.5f * (hist[l] - hist[rr]) / (hist[l] - 2 * hist[j] + hist[rr]);
-      bin = bin < 0 ? 36 + bin : (bin >= 36 ? bin - 36 : bin);
-      float angle = 360.f - (360.f / 36) * bin;
-      if (fabsf(angle - 360.f) < 1.1920929e-07f) angle = 0.f;
-      const unsigned pos = atomicAdd(n_out, 1u);
-      if (pos < cap_out) {
-        skp_t q = kp;
-        q.angle = angle;
-        out[pos] = q;
+  int r, c;
+};
+
+// Quadratic-fit refinement, contrast and edge tests: one lane per candidate of any octave (grid-stride).  Candidates
+// that converge to the same (octave, layer, row, column) produce identical keypoints, which the reference removes
+// after sorting (KeyPointsFilter::removeDuplicatedSorted): only the first to claim the cell in the hash table goes on.
+__global__ __launch_bounds__(256) void refine_kernel(octs_t OS, const int4* __restrict__ cand,
+                                                     const unsigned* __restrict__ n_cand, unsigned cap,
+                                                     float contrast_thr, float edge_thr, float sigma,
+                                                     unsigned long long* __restrict__ table, unsigned table_mask,
+                                                     surv_t* __restrict__ out, unsigned* __restrict__ n_out,
+                                                     unsigned cap_out) {
+  const unsigned n = min(*n_cand, cap);
+  for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+    const int4 cd = cand[k];
+    const oct_t& O = OS.o[cd.x];
+    int layer = cd.y, r = cd.z, c = cd.w;
+    const int W = O.W, H = O.H;
+    const float img_scale = 1.f / 255.f, deriv_scale = img_scale * 0.5f, second = img_scale, cross = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0;
+    int i;
+    bool dead = false;
+    for (i = 0; i < 5; ++i) {
+      const float* img = O.d[layer];
+      const float* prv = O.d[layer - 1];
+      const float* nxt = O.d[layer + 1];
+      const size_t p = (size_t)r * W + c;
+      float dD[3] = {(img[p + 1] - img[p - 1]) * deriv_scale, (img[p + W] - img[p - W]) * deriv_scale,
+                     (nxt[p] - prv[p]) * deriv_scale};
+      const float v2 = img[p] * 2;
+      const float dxx = (img[p + 1] + img[p - 1] - v2) * second, dyy = (img[p + W] + img[p - W] - v2) * second,
+                  dss = (nxt[p] + prv[p] - v2) * second;
+      const float dxy = (img[p + W + 1] - img[p + W - 1] - img[p - W + 1] + img[p - W - 1]) * cross;
+      const float dxs = (nxt[p + 1] - nxt[p - 1] - prv[p + 1] + prv[p - 1]) * cross;
+      const float dys = (nxt[p + W] - nxt[p - W] - prv[p + W] + prv[p - W]) * cross;
+      float Hm[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+      float X[3];
+      if (!solve3(Hm, dD, X)) {
+        dead = true;
+        break;
+      }
+      xi = -X[2];
+      xr = -X[1];
+      xc = -X[0];
+      if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+      if (fabsf(xi) > 7e8f || fabsf(xr) > 7e8f || fabsf(xc) > 7e8f) {
+        dead = true;
+        break;
+      }
+      c += (int)rintf(xc);
+      r += (int)rintf(xr);
+      layer += (int)rintf(xi);
+      if (layer < 1 || layer > NOL || c < BORDER || c >= W - BORDER || r < BORDER || r >= H - BORDER) {
+        dead = true;
+        break;
       }
     }
+    if (dead || i >= 5) continue;
+    surv_t sv;
+    {
+      const float* img = O.d[layer];
+      const float* prv = O.d[layer - 1];
+      const float* nxt = O.d[layer + 1];
+      const size_t p = (size_t)r * W + c;
+      const float d0 = (img[p + 1] - img[p - 1]) * deriv_scale, d1 = (img[p + W] - img[p - W]) * deriv_scale,
+                  d2 = (nxt[p] - prv[p]) * deriv_scale;
+      const float t = d0 * xc + d1 * xr + d2 * xi;
+      const float contr = img[p] * img_scale + t * 0.5f;
+      if (fabsf(contr) * NOL < contrast_thr) continue;
+      const float v2 = img[p] * 2.f;
+      const float dxx = (img[p + 1] + img[p - 1] - v2) * second, dyy = (img[p + W] + img[p - W] - v2) * second;
+      const float dxy = (img[p + W + 1] - img[p + W - 1] - img[p - W + 1] + img[p - W - 1]) * cross;
+      const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+      if (det <= 0 || tr * tr * edge_thr >= (edge_thr + 1) * (edge_thr + 1) * det) continue;
+      const float po = (float)(1 << O.o);
+      sv.kp.oct_x = c + xc;
+      sv.kp.oct_y = r + xr;
+      sv.kp.x = (c + xc) * po;
+      sv.kp.y = (r + xr) * po;
+      sv.kp.oct = O.o;
+      sv.kp.layer = layer;
+      sv.kp.size = sigma * sift_exp(((layer + xi) / NOL) * 0.6931471805599453f) * po * 2;
+      sv.kp.response = fabsf(contr);
+      sv.kp.angle = 0.f;
+      sv.kp.octave = 0.f;
+      sv.r = r;
+      sv.c = c;
+    }
+    // claim (octave, layer, row, column): key never 0
+    {
+      const unsigned long long key = 1ull | ((unsigned long long)O.o << 1) | ((unsigned long long)layer << 5) |
+                                     ((unsigned long long)r << 8) | ((unsigned long long)c << 32);
+      unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & table_mask;
+      bool mine = false;
+      for (unsigned probe = 0; probe <= table_mask; ++probe) {
+        const unsigned long long old = atomicCAS(&table[h], 0ull, key);
+        if (old == 0ull) {
+          mine = true;
+          break;
+        }
+        if (old == key) break;
+        h = (h + 1) & table_mask;
+      }
+      if (!mine) continue;
+    }
+    const unsigned pos = atomicAdd(n_out, 1u);
+    if (pos < cap_out) out[pos] = sv;
   }
+}
+
+// Orientation histogram of every refined extremum: one wave per extremum.  The reference accumulates the 36 bins
+// in pixel raster order; here 64 lanes evaluate 64 consecutive raster positions (gradient, exp, atan2: the
+// expensive part), their (bin, weight) pairs are compacted in raster order into LDS, and lane b adds the pairs of
+// bin b in that order -- every bin sees exactly the sequence of additions of the sequential loop.
+__global__ __launch_bounds__(64) void orient_kernel(octs_t OS, const surv_t* __restrict__ surv,
+                                                    const unsigned* __restrict__ n_surv, unsigned cap_surv,
+                                                    skp_t* __restrict__ out, unsigned* __restrict__ n_out,
+                                                    unsigned cap_out) {
+  __shared__ int s_bin[64];
+  __shared__ float s_add[64];
+  __shared__ float s_tmp[36];
+  const int lane = threadIdx.x;
+  const unsigned n = min(*n_surv, cap_surv);
+  for (unsigned k = blockIdx.x; k < n; k += gridDim.x) {
+    const surv_t sv = surv[k];
+    const oct_t& O = OS.o[sv.kp.oct];
+    const int W = O.W, H = O.H, r = sv.r, c = sv.c;
+    const float scl_octv = sv.kp.size * 0.5f / (float)(1 << O.o);
+    const int radius = (int)rintf(4.5f * scl_octv);
+    const float osig = 1.5f * scl_octv;
+    const float* g = O.g[sv.kp.layer];
+    const float expf_scale = -1.f / (2.f * osig * osig);
+    const int side = 2 * radius + 1, total = side * side;
+    float acc = 0.f;                                  // lane b < 36: bin b
+    for (int base = 0; base < total; base += 64) {
+      const int p = base + lane;
+      bool on = false;
+      int bin = 0;
+      float add = 0.f;
+      if (p < total) {
+        const int ii = p / side - radius, jj = p - (p / side) * side - radius;
+        const int y = r + ii, x = c + jj;
+        if (y > 0 && y < H - 1 && x > 0 && x < W - 1) {
+          const float dx = g[(size_t)y * W + x + 1] - g[(size_t)y * W + x - 1];
+          const float dy = g[(size_t)(y - 1) * W + x] - g[(size_t)(y + 1) * W + x];
+          const float w = sift_exp((float)(ii * ii + jj * jj) * expf_scale);
+          const float ori = sift_atan2(dy, dx);
+          const float mag = sqrtf(dx * dx + dy * dy);
+          bin = (int)rintf(0.1f * ori);
+          if (bin >= 36) bin -= 36;
+          if (bin < 0) bin += 36;
+          add = w * mag;
+          on = true;
+        }
+      }
+      const unsigned long long m = __ballot(on);
+      if (on) {
+        const int slot = __popcll(m & ((1ull << lane) - 1ull));
+        s_bin[slot] = bin;
+        s_add[slot] = add;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const int cnt = __popcll(m);
+      for (int e = 0; e < cnt; ++e)
+        if (s_bin[e] == lane) acc += s_add[e];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < 36) s_tmp[lane] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float h = 0.f;
+    if (lane < 36) {
+      const int b = lane;
+      h = (s_tmp[(b + 34) % 36] + s_tmp[(b + 2) % 36]) * (1.f / 16.f) +
+          (s_tmp[(b + 35) % 36] + s_tmp[(b + 1) % 36]) * (4.f / 16.f) + s_tmp[b] * (6.f / 16.f);
+    }
+    float mx = h;                                      // (lanes >= 36 hold 0; the reference's maximum starts at 0)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    const float mag_thr = mx * 0.8f;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) s_add[lane] = h;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 36) {
+      const int j = lane;
+      const int l = j > 0 ? j - 1 : 35, rr = j < 35 ? j + 1 : 0;
+      const float hl = s_add[l], hr = s_add[rr];
+      if (h > hl && h > hr && h >= mag_thr) {
+        float bin = j + 0.5f * (hl - hr) / (hl - 2 * h + hr);
+        bin = bin < 0 ? 36 + bin : (bin >= 36 ? bin - 36 : bin);
+        float angle = 360.f - (360.f / 36) * bin;
+        if (fabsf(angle - 360.f) < 1.1920929e-07f) angle = 0.f;
+        const unsigned pos = atomicAdd(n_out, 1u);
+        if (pos < cap_out) {
+          skp_t q = sv.kp;
+          q.angle = angle;
+          out[pos] = q;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// retainBest (KeyPointsFilter::retainBest): the keypoints whose response is at least the cap-th largest go on to
+// description (ties at the bound are settled on the host, in sorted order, as the reference settles them).  One
+// workgroup: three radix passes over the response bits (positive floats order like their bit patterns).
+__global__ __launch_bounds__(1024) void select_kernel(const skp_t* __restrict__ kps, const unsigned* __restrict__ n_kp,
+                                                      unsigned cap_kp, unsigned cap, unsigned* __restrict__ sel,
+                                                      unsigned* __restrict__ n_sel) {
+  __shared__ unsigned s_hist[2048];
+  __shared__ unsigned s_prefix, s_need, s_cnt;
+  const int tid = threadIdx.x;
+  const unsigned n = min(*n_kp, cap_kp);
+  unsigned thr_bits = 0u;
+  if (n > cap) {
+    if (tid == 0) {
+      s_prefix = 0u;
+      s_need = cap;
+    }
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+      for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0u;
+      __syncthreads();
+      const unsigned prefix = s_prefix, need = s_need;
+      const int sh = shifts[pass], wd = widths[pass];
+      const unsigned hi_mask = pass == 0 ? 0u : ~0u << (sh + wd);
+      for (unsigned i = tid; i < n; i += 1024) {
+        const unsigned b = __float_as_uint(kps[i].response);
+        if ((b & hi_mask) == prefix) atomicAdd(&s_hist[(b >> sh) & ((1u << wd) - 1u)], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned run = 0;
+        int d = (1 << wd) - 1;
+        for (; d > 0; --d) {
+          if (run + s_hist[d] >= need) break;
+          run += s_hist[d];
+        }
+        s_prefix = prefix | ((unsigned)d << sh);
+        s_need = need - run;
+      }
+      __syncthreads();
+    }
+    thr_bits = s_prefix;
+  }
+  if (tid == 0) s_cnt = 0u;
+  __syncthreads();
+  for (unsigned i = tid; i < n; i += 1024)
+    if (__float_as_uint(kps[i].response) >= thr_bits) sel[atomicAdd(&s_cnt, 1u)] = i;
+  __syncthreads();
+  if (tid == 0) *n_sel = s_cnt;
 }
 
 // ---------------- description ----------------
@@ -316,118 +457,172 @@ struct pyr_ptrs {
   int H[MAX_OCT], W[MAX_OCT];
 };
 
-__global__ __launch_bounds__(64) void descriptor_kernel(pyr_ptrs P, const skp_t* __restrict__ kps, unsigned n,
+// One wave per selected keypoint.  The reference adds every sample's eight trilinear shares into the
+// (4+2) x (4+2) x (8+2) histogram in pixel raster order; here the 64 lanes evaluate 64 consecutive raster positions
+// (gradient, rotation, exp, atan2, the eight shares), the samples that pass the window test are compacted in raster
+// order into LDS, and lane L < 36 owns spatial cell L: it walks the compacted samples in order and adds the two
+// orientation shares of every sample that touches its cell -- each bin receives the additions of the sequential
+// loop in the sequential loop's order.  The closing normalisation is the sequential code on one lane.
+__global__ __launch_bounds__(64) void descriptor_kernel(pyr_ptrs P, const skp_t* __restrict__ kps,
+                                                        const unsigned* __restrict__ sel,
+                                                        const unsigned* __restrict__ n_sel,
                                                         float* __restrict__ rows /* n x 134 */) {
-  const unsigned k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= n) return;
-  const skp_t q = kps[k];
-  const float* g = P.g[q.oct][q.layer];
-  const int H = P.H[q.oct], W = P.W[q.oct];
-  float* row = rows + (size_t)k * 134;
-  row[0] = q.x * 0.5f;
-  row[1] = q.y * 0.5f;
-  row[2] = q.size * 0.5f;
-  row[3] = q.angle;
-  row[4] = q.response;
-  row[5] = (float)(q.oct - 1);
-  const float scl = q.size * 0.5f / (float)(1 << q.oct);
-  float ori_deg = 360.f - q.angle;
-  if (fabsf(ori_deg - 360.f) < 1.1920929e-07f) ori_deg = 0.f;
+  __shared__ float s_v[64][8];
+  __shared__ int s_cell[64];          // (r0 + 1) | (c0 + 1) << 8 | o0 << 16
+  __shared__ float s_hist[36][10];
+  const int lane = threadIdx.x;
+  const unsigned n = *n_sel;
   const int d = 4, n8 = 8;
-  const int pxi = (int)rintf(q.oct_x), pyi = (int)rintf(q.oct_y);
-  float cos_t, sin_t;
-  {
-    float a = ori_deg * 0.017453292519943295f;
-    while (a > 3.14159265358979f) a -= 6.28318530717959f;
-    while (a < -3.14159265358979f) a += 6.28318530717959f;
-    float sgn = 1.f;
-    if (a > 1.5707963267949f) {
-      a = 3.14159265358979f - a;
-      sgn = -1.f;
-    } else if (a < -1.5707963267949f) {
-      a = -3.14159265358979f - a;
-      sgn = -1.f;
+  for (unsigned k = blockIdx.x; k < n; k += gridDim.x) {
+    const skp_t q = kps[sel[k]];
+    const float* g = P.g[q.oct][q.layer];
+    const int H = P.H[q.oct], W = P.W[q.oct];
+    float* row = rows + (size_t)k * 134;
+    const float scl = q.size * 0.5f / (float)(1 << q.oct);
+    float ori_deg = 360.f - q.angle;
+    if (fabsf(ori_deg - 360.f) < 1.1920929e-07f) ori_deg = 0.f;
+    const int pxi = (int)rintf(q.oct_x), pyi = (int)rintf(q.oct_y);
+    float cos_t, sin_t;
+    {
+      float a = ori_deg * 0.017453292519943295f;
+      while (a > 3.14159265358979f) a -= 6.28318530717959f;
+      while (a < -3.14159265358979f) a += 6.28318530717959f;
+      float sgn = 1.f;
+      if (a > 1.5707963267949f) {
+        a = 3.14159265358979f - a;
+        sgn = -1.f;
+      } else if (a < -1.5707963267949f) {
+        a = -3.14159265358979f - a;
+        sgn = -1.f;
+      }
+      const float a2 = a * a;
+      sin_t = a * (1.f + a2 * (-1.f / 6 + a2 * (1.f / 120 + a2 * (-1.f / 5040 + a2 * (1.f / 362880 + a2 * (-1.f / 39916800))))));
+      cos_t = sgn * (1.f + a2 * (-0.5f + a2 * (1.f / 24 + a2 * (-1.f / 720 + a2 * (1.f / 40320 + a2 * (-1.f / 3628800 + a2 * (1.f / 479001600)))))));
     }
-    const float a2 = a * a;
-    sin_t = a * (1.f + a2 * (-1.f / 6 + a2 * (1.f / 120 + a2 * (-1.f / 5040 + a2 * (1.f / 362880 + a2 * (-1.f / 39916800))))));
-    cos_t = sgn * (1.f + a2 * (-0.5f + a2 * (1.f / 24 + a2 * (-1.f / 720 + a2 * (1.f / 40320 + a2 * (-1.f / 3628800 + a2 * (1.f / 479001600)))))));
-  }
-  const float bins_per_deg = n8 / 360.f;
-  const float exp_scale = -1.f / (d * d * 0.5f);
-  const float hist_width = 3.f * scl;
-  int radius = (int)rintf(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
-  const int maxr = (int)sqrt((double)H * H + (double)W * W);
-  if (radius > maxr) radius = maxr;
-  cos_t /= hist_width;
-  sin_t /= hist_width;
-  // the (d+2) x (d+2) x (n+2) histogram lives in the output row's scratch tail (global memory,
-  // private to this lane): 360 floats
-  float* hist = rows + (size_t)n * 134 + (size_t)k * 360;
-  for (int i = 0; i < 360; ++i) hist[i] = 0.f;
-  for (int i = -radius; i <= radius; ++i)
-    for (int j = -radius; j <= radius; ++j) {
-      const float c_rot = j * cos_t - i * sin_t;
-      const float r_rot = j * sin_t + i * cos_t;
-      float rbin = r_rot + d / 2 - 0.5f;
-      float cbin = c_rot + d / 2 - 0.5f;
-      const int r = pyi + i, c = pxi + j;
-      if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < H - 1 && c > 0 && c < W - 1)) continue;
-      const float dx = g[(size_t)r * W + c + 1] - g[(size_t)r * W + c - 1];
-      const float dy = g[(size_t)(r - 1) * W + c] - g[(size_t)(r + 1) * W + c];
-      const float wgt = sift_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-      const float ang = sift_atan2(dy, dx);
-      const float mag = sqrtf(dx * dx + dy * dy) * wgt;
-      float obin = (ang - ori_deg) * bins_per_deg;
-      const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
-      int o0 = (int)floorf(obin);
-      rbin -= r0;
-      cbin -= c0;
-      obin -= o0;
-      if (o0 < 0) o0 += n8;
-      if (o0 >= n8) o0 -= n8;
-      const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-      const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-      const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-      const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
-      const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-      const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
-      const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-      const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n8 + 2) + o0;
-      hist[idx] += v_rco000;
-      hist[idx + 1] += v_rco001;
-      hist[idx + (n8 + 2)] += v_rco010;
-      hist[idx + (n8 + 3)] += v_rco011;
-      hist[idx + (d + 2) * (n8 + 2)] += v_rco100;
-      hist[idx + (d + 2) * (n8 + 2) + 1] += v_rco101;
-      hist[idx + (d + 3) * (n8 + 2)] += v_rco110;
-      hist[idx + (d + 3) * (n8 + 2) + 1] += v_rco111;
+    const float bins_per_deg = n8 / 360.f;
+    const float exp_scale = -1.f / (d * d * 0.5f);
+    const float hist_width = 3.f * scl;
+    int radius = (int)rintf(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+    const int maxr = (int)sqrt((double)H * H + (double)W * W);
+    if (radius > maxr) radius = maxr;
+    cos_t /= hist_width;
+    sin_t /= hist_width;
+    for (int i = lane; i < 360; i += 64) (&s_hist[0][0])[i] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int cr = lane / 6, cc = lane - cr * 6;       // the cell lane < 36 owns
+    const long long side = 2LL * radius + 1, total = side * side;
+    for (long long base = 0; base < total; base += 64) {
+      const long long p = base + lane;
+      bool on = false;
+      float v[8];
+      int cell = 0;
+      if (p < total) {
+        const int i = (int)(p / side) - radius, j = (int)(p - (p / side) * side) - radius;
+        const float c_rot = j * cos_t - i * sin_t;
+        const float r_rot = j * sin_t + i * cos_t;
+        float rbin = r_rot + d / 2 - 0.5f;
+        float cbin = c_rot + d / 2 - 0.5f;
+        const int r = pyi + i, c = pxi + j;
+        if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < H - 1 && c > 0 && c < W - 1) {
+          const float dx = g[(size_t)r * W + c + 1] - g[(size_t)r * W + c - 1];
+          const float dy = g[(size_t)(r - 1) * W + c] - g[(size_t)(r + 1) * W + c];
+          const float wgt = sift_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+          const float ang = sift_atan2(dy, dx);
+          const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+          float obin = (ang - ori_deg) * bins_per_deg;
+          const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+          int o0 = (int)floorf(obin);
+          rbin -= r0;
+          cbin -= c0;
+          obin -= o0;
+          if (o0 < 0) o0 += n8;
+          if (o0 >= n8) o0 -= n8;
+          const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+          const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+          const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+          const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111;
+          const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+          const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
+          const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+          v[0] = v_rco000;
+          v[1] = v_rco001;
+          v[2] = v_rco010;
+          v[3] = v_rco011;
+          v[4] = v_rco100;
+          v[5] = v_rco101;
+          v[6] = v_rco110;
+          v[7] = v_rco111;
+          cell = (r0 + 1) | ((c0 + 1) << 8) | (o0 << 16);
+          on = true;
+        }
+      }
+      const unsigned long long m = __ballot(on);
+      if (on) {
+        const int slot = __popcll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_v[slot][e] = v[e];
+        s_cell[slot] = cell;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      const int cnt = __popcll(m);
+      if (lane < 36) {
+        for (int e = 0; e < cnt; ++e) {
+          const int ce = s_cell[e];
+          const int dr = cr - (ce & 255), dc = cc - ((ce >> 8) & 255), o0 = ce >> 16;
+          if ((unsigned)dr <= 1u && (unsigned)dc <= 1u) {
+            const float* vv = &s_v[e][dr * 4 + dc * 2];
+            s_hist[lane][o0] += vv[0];
+            s_hist[lane][o0 + 1] += vv[1];
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
     }
-  float* raw = row + 6;
-  for (int i = 0; i < d; ++i)
-    for (int j = 0; j < d; ++j) {
-      const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n8 + 2);
-      hist[idx] += hist[idx + n8];
-      hist[idx + 1] += hist[idx + n8 + 1];
-      for (int b = 0; b < n8; ++b) raw[(i * d + j) * n8 + b] = hist[idx + b];
+    // fold the orientation wrap, then threshold / normalise as the sequential code does (one lane: the two norms are
+    // sums in index order)
+    if (lane == 0) {
+      row[0] = q.x * 0.5f;
+      row[1] = q.y * 0.5f;
+      row[2] = q.size * 0.5f;
+      row[3] = q.angle;
+      row[4] = q.response;
+      row[5] = (float)(q.oct - 1);
+      float* raw = row + 6;
+      float nrm2 = 0;
+      for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+          float* hc = s_hist[(i + 1) * (d + 2) + (j + 1)];
+          hc[0] += hc[n8];
+          hc[1] += hc[n8 + 1];
+          for (int b = 0; b < n8; ++b) {
+            const float t = hc[b];
+            raw[(i * d + j) * n8 + b] = t;
+            nrm2 += t * t;
+          }
+        }
+      const float thr = sqrtf(nrm2) * 0.2f;
+      nrm2 = 0;
+      for (int b = 0; b < 128; ++b) {
+        const float t = raw[b] < thr ? raw[b] : thr;
+        raw[b] = t;
+        nrm2 += t * t;
+      }
+      const float s = 512.f / fmaxf(sqrtf(nrm2), 1.1920929e-07f);
+      for (int b = 0; b < 128; ++b) {
+        const float t = rintf(raw[b] * s);
+        raw[b] = t < 0 ? 0.f : (t > 255.f ? 255.f : t);
+      }
     }
-  float nrm2 = 0;
-  for (int b = 0; b < 128; ++b) nrm2 += raw[b] * raw[b];
-  const float thr = sqrtf(nrm2) * 0.2f;
-  nrm2 = 0;
-  for (int b = 0; b < 128; ++b) {
-    const float v = raw[b] < thr ? raw[b] : thr;
-    raw[b] = v;
-    nrm2 += v * v;
-  }
-  const float s = 512.f / fmaxf(sqrtf(nrm2), 1.1920929e-07f);
-  for (int b = 0; b < 128; ++b) {
-    const float v = rintf(raw[b] * s);
-    raw[b] = v < 0 ? 0.f : (v > 255.f ? 255.f : v);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-__global__ void overflow_kernel(const unsigned* n, unsigned cap, unsigned* flag) {
-  if (*n > cap) *flag = 1u;
+__global__ void overflow_kernel(const unsigned* cnt, unsigned cap_cand, unsigned cap_kp, unsigned* flag) {
+  if (cnt[C_CAND] > cap_cand || cnt[C_SURV] > cap_kp || cnt[C_KP] > cap_kp) *flag = 1u;
 }
 
 taps_t make_taps(double sigma) {
@@ -501,13 +696,19 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   const unsigned cap_kp = (unsigned)vo_sift_capacity(H, W), cap_cand = 4u * cap_kp;
   VO_TRY(vo_ensure(ctx, ctx->img, (size_t)H * W));
   VO_TRY(vo_ensure(ctx, ctx->sift_arena, total * 4));
-  VO_TRY(vo_ensure(ctx, ctx->scratch[0], (size_t)cap_cand * 12));
+  unsigned table_len = 1;
+  while (table_len < 4u * cap_kp) table_len <<= 1;
+  VO_TRY(vo_ensure(ctx, ctx->scratch[0], (size_t)cap_cand * 16));
   VO_TRY(vo_ensure(ctx, ctx->scratch[1], (size_t)cap_kp * sizeof(skp_t)));
   VO_TRY(vo_ensure(ctx, ctx->scratch[2], 64));
-  VO_TRY(vo_ensure(ctx, ctx->scratch[3], (size_t)cap_kp * (134 + 360) * 4));
+  VO_TRY(vo_ensure(ctx, ctx->scratch[3], (size_t)cap_kp * 134 * 4));
+  VO_TRY(vo_ensure(ctx, ctx->scratch[4], (size_t)cap_kp * sizeof(surv_t)));
+  VO_TRY(vo_ensure(ctx, ctx->scratch[5], (size_t)table_len * 8));
+  VO_TRY(vo_ensure(ctx, ctx->scratch[6], (size_t)cap_kp * 4));
   VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, img, (size_t)H * W, hipMemcpyHostToDevice, st));
-  unsigned* d_cnt = (unsigned*)ctx->scratch[2].p;   // [0] candidates of the current octave, [1] keypoints
+  unsigned* d_cnt = (unsigned*)ctx->scratch[2].p;   // counters of this call, see C_CAND ..
   VO_HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 64, st));
+  VO_HIP_TRY(ctx, hipMemsetAsync(ctx->scratch[5].p, 0, (size_t)table_len * 8, st));
 
   float* arena = (float*)ctx->sift_arena.p;
   float* tmp = arena;
@@ -573,33 +774,40 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   VO_TRY(vo_check_launch(ctx, "sift scale space"));
   const float threshold = std::floor(0.5f * contrast_thr / NOL * 255.f);
   skp_t* d_kps = (skp_t*)ctx->scratch[1].p;
-  for (int o = 0; o < n_oct; ++o) {
-    VO_HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 4, st));
-    {
-      vo_prof_scope ps(ctx, VO_K_SIFT_DETECT);
+  surv_t* d_surv = (surv_t*)ctx->scratch[4].p;
+  unsigned* d_sel = (unsigned*)ctx->scratch[6].p;
+  float* d_rows = (float*)ctx->scratch[3].p;
+  octs_t OS;
+  memset(&OS, 0, sizeof(OS));
+  for (int o = 0; o < n_oct; ++o) OS.o[o] = oct[o];
+  {
+    vo_prof_scope ps(ctx, VO_K_SIFT_DETECT);
+    for (int o = 0; o < n_oct; ++o)
       for (int layer = 1; layer <= NOL; ++layer)
         hipLaunchKernelGGL(extrema_kernel, grid2(oct[o].W, oct[o].H), dim3(256), 0, st, oct[o], layer, threshold,
-                           (int*)ctx->scratch[0].p, d_cnt, cap_cand);
-      // the candidate count stays on the device: launch for the capacity, surplus lanes exit
-      hipLaunchKernelGGL(refine_orient_kernel, dim3(cap_cand / 64), dim3(64), 0, st, oct[o],
-                         (const int*)ctx->scratch[0].p, d_cnt, cap_cand, contrast_thr, edge_thr, sigma, d_kps,
-                         d_cnt + 1, cap_kp);
-      hipLaunchKernelGGL(overflow_kernel, dim3(1), dim3(1), 0, st, d_cnt, cap_cand, d_cnt + 2);
-    }
-    VO_TRY(vo_check_launch(ctx, "sift detection"));
+                           (int4*)ctx->scratch[0].p, d_cnt + C_CAND, cap_cand);
+    // counts stay on the device: fixed grids, every kernel strides over what the one before it produced
+    hipLaunchKernelGGL(refine_kernel, dim3(1024), dim3(256), 0, st, OS, (const int4*)ctx->scratch[0].p, d_cnt + C_CAND,
+                       cap_cand, contrast_thr, edge_thr, sigma, (unsigned long long*)ctx->scratch[5].p, table_len - 1,
+                       d_surv, d_cnt + C_SURV, cap_kp);
+    hipLaunchKernelGGL(orient_kernel, dim3(4096), dim3(64), 0, st, OS, d_surv, d_cnt + C_SURV, cap_kp, d_kps, d_cnt + C_KP,
+                       cap_kp);
+    hipLaunchKernelGGL(overflow_kernel, dim3(1), dim3(1), 0, st, d_cnt, cap_cand, cap_kp, d_cnt + C_OVER);
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, st, d_kps, d_cnt + C_KP, cap_kp, (unsigned)cap, d_sel,
+                       d_cnt + C_SEL);
   }
-  unsigned cnt[3] = {0, 0, 0};
-  VO_HIP_TRY(ctx, hipMemcpyAsync(cnt, d_cnt, 12, hipMemcpyDeviceToHost, st));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
-  if (cnt[2] || cnt[1] > cap_kp) return vo_set_error(ctx, VO_ECAPACITY, "sift: candidate / keypoint list overflow");
-  const unsigned n_all = cnt[1];
-  if (n_all == 0) return VO_OK;
-  float* d_rows = (float*)ctx->scratch[3].p;
+  VO_TRY(vo_check_launch(ctx, "sift detection"));
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_DESCRIBE);
-    hipLaunchKernelGGL(descriptor_kernel, dim3(vo_cdiv((int)n_all, 64)), dim3(64), 0, st, P, d_kps, n_all, d_rows);
+    hipLaunchKernelGGL(descriptor_kernel, dim3(4096), dim3(64), 0, st, P, d_kps, d_sel, d_cnt + C_SEL, d_rows);
   }
   VO_TRY(vo_check_launch(ctx, "sift descriptor_kernel"));
+  unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  VO_HIP_TRY(ctx, hipMemcpyAsync(cnt, d_cnt, 32, hipMemcpyDeviceToHost, st));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (cnt[C_OVER]) return vo_set_error(ctx, VO_ECAPACITY, "sift: candidate / keypoint list overflow");
+  const unsigned n_all = cnt[C_SEL];      // rows described: all keypoints, or those at or above the cap's response bound
+  if (n_all == 0) return VO_OK;
   std::vector<float> rows((size_t)n_all * 134);
   VO_HIP_TRY(ctx, hipMemcpyAsync(rows.data(), d_rows, rows.size() * 4, hipMemcpyDeviceToHost, st));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
