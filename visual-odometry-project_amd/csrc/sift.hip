@@ -111,18 +111,18 @@ __global__ __launch_bounds__(256) void decimate_kernel(const float* __restrict__
   if (x < W && y < H) dst[(size_t)y * W + x] = src[(size_t)(2 * y) * pw + 2 * x];
 }
 
-__global__ __launch_bounds__(256) void dog_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
-                                                  float* __restrict__ d) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) d[i] = b[i] - a[i];
-}
-
 // ---------------- detection ----------------
 struct oct_t {
   const float* g[NG];
-  const float* d[NG - 1];
   int H, W, o;
 };
+// DoG layer l at pixel p.  The difference images are never stored: every reader takes the difference of the two
+// Gaussian layers itself (one subtraction, the value a stored image would hold).
+struct dog_t {
+  const float *a, *b;
+  __device__ __forceinline__ float operator[](size_t p) const { return b[p] - a[p]; }
+};
+__device__ __forceinline__ dog_t dog_layer(const oct_t& O, int l) { return dog_t{O.g[l], O.g[l + 1]}; }
 struct octs_t {
   oct_t o[MAX_OCT];
 };
@@ -131,26 +131,32 @@ struct octs_t {
 // [3] refined survivors, [4] rows selected for description
 enum { C_CAND = 0, C_KP = 1, C_OVER = 2, C_SURV = 3, C_SEL = 4 };
 
-__global__ __launch_bounds__(256) void extrema_kernel(oct_t O, int layer, float threshold, int4* __restrict__ cand,
+// 26-neighbour extrema of the three inner DoG layers of one octave in one pass over its six Gaussian layers: the
+// centre differences first (six coalesced loads per pixel), the neighbourhood only where a centre passes the threshold.
+__global__ __launch_bounds__(256) void extrema_kernel(oct_t O, float threshold, int4* __restrict__ cand,
                                                       unsigned* __restrict__ n_cand, unsigned cap) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (c < BORDER || c >= O.W - BORDER || r < BORDER || r >= O.H - BORDER) return;
-  const float* img = O.d[layer];
-  const float* prv = O.d[layer - 1];
-  const float* nxt = O.d[layer + 1];
   const size_t p = (size_t)r * O.W + c;
-  const float val = img[p];
-  if (!(fabsf(val) > threshold)) return;
-  bool ext = true;
-  for (int dy = -1; dy <= 1; ++dy)
-    for (int dx = -1; dx <= 1; ++dx) {
-      const size_t q = p + dy * O.W + dx;
-      if (val > 0 ? (val < img[q] || val < prv[q] || val < nxt[q]) : (val > img[q] || val > prv[q] || val > nxt[q]))
-        ext = false;
-    }
-  if (!ext) return;
-  const unsigned pos = atomicAdd(n_cand, 1u);
-  if (pos < cap) cand[pos] = make_int4(O.o, layer, r, c);
+  float gv[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) gv[i] = O.g[i][p];
+#pragma unroll
+  for (int layer = 1; layer <= NOL; ++layer) {
+    const float val = gv[layer + 1] - gv[layer];
+    if (!(fabsf(val) > threshold)) continue;
+    const dog_t img = dog_layer(O, layer), prv = dog_layer(O, layer - 1), nxt = dog_layer(O, layer + 1);
+    bool ext = true;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const size_t q = p + dy * O.W + dx;
+        const float vi = img[q], vp = prv[q], vn = nxt[q];
+        if (val > 0 ? (val < vi || val < vp || val < vn) : (val > vi || val > vp || val > vn)) ext = false;
+      }
+    if (!ext) continue;
+    const unsigned pos = atomicAdd(n_cand, 1u);
+    if (pos < cap) cand[pos] = make_int4(O.o, layer, r, c);
+  }
 }
 
 __device__ bool solve3(float A[3][3], float b[3], float x[3]) {
@@ -216,9 +222,7 @@ __global__ __launch_bounds__(256) void refine_kernel(octs_t OS, const int4* __re
     int i;
     bool dead = false;
     for (i = 0; i < 5; ++i) {
-      const float* img = O.d[layer];
-      const float* prv = O.d[layer - 1];
-      const float* nxt = O.d[layer + 1];
+      const dog_t img = dog_layer(O, layer), prv = dog_layer(O, layer - 1), nxt = dog_layer(O, layer + 1);
       const size_t p = (size_t)r * W + c;
       float dD[3] = {(img[p + 1] - img[p - 1]) * deriv_scale, (img[p + W] - img[p - W]) * deriv_scale,
                      (nxt[p] - prv[p]) * deriv_scale};
@@ -253,9 +257,7 @@ __global__ __launch_bounds__(256) void refine_kernel(octs_t OS, const int4* __re
     if (dead || i >= 5) continue;
     surv_t sv;
     {
-      const float* img = O.d[layer];
-      const float* prv = O.d[layer - 1];
-      const float* nxt = O.d[layer + 1];
+      const dog_t img = dog_layer(O, layer), prv = dog_layer(O, layer - 1), nxt = dog_layer(O, layer + 1);
       const size_t p = (size_t)r * W + c;
       const float d0 = (img[p + 1] - img[p - 1]) * deriv_scale, d1 = (img[p + W] - img[p - W]) * deriv_scale,
                   d2 = (nxt[p] - prv[p]) * deriv_scale;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(64) void orient_kernel(octs_t OS, const surv_t* __r
 __global__ __launch_bounds__(1024) void select_kernel(const skp_t* __restrict__ kps, const unsigned* __restrict__ n_kp,
                                                       unsigned cap_kp, unsigned cap, unsigned* __restrict__ sel,
                                                       unsigned* __restrict__ n_sel) {
-  __shared__ unsigned s_hist[2048];
+  __shared__ unsigned s_hist[2048], s_scan[1024];
   __shared__ unsigned s_prefix, s_need, s_cnt;
   const int tid = threadIdx.x;
   const unsigned n = min(*n_kp, cap_kp);
@@ -429,17 +431,31 @@ __global__ __launch_bounds__(1024) void select_kernel(const skp_t* __restrict__ 
         if ((b & hi_mask) == prefix) atomicAdd(&s_hist[(b >> sh) & ((1u << wd) - 1u)], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        unsigned run = 0;
-        int d = (1 << wd) - 1;
-        for (; d > 0; --d) {
-          if (run + s_hist[d] >= need) break;
-          run += s_hist[d];
+      // the digit d with  sum(hist[d+1 ..]) < need <= sum(hist[d ..])  (0 when even the whole count falls short):
+      // suffix sums of bin pairs, one pair per work item
+      {
+        const unsigned pair = s_hist[2 * tid] + s_hist[2 * tid + 1];
+        s_scan[tid] = pair;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+          const unsigned add = tid + off < 1024 ? s_scan[tid + off] : 0u;
+          __syncthreads();
+          s_scan[tid] += add;
+          __syncthreads();
         }
-        s_prefix = prefix | ((unsigned)d << sh);
-        s_need = need - run;
+        const unsigned incl = s_scan[tid], above = incl - pair;          // bins >= 2 tid; bins >= 2 tid + 2
+        if (above < need && need <= incl) {
+          const unsigned hi = s_hist[2 * tid + 1];
+          const int d = above + hi >= need ? 2 * tid + 1 : 2 * tid;
+          s_prefix = prefix | ((unsigned)d << sh);
+          s_need = need - (d == 2 * tid + 1 ? above : above + hi);
+        }
+        if (tid == 0 && incl < need) {
+          s_prefix = prefix;
+          s_need = need - incl;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     thr_bits = s_prefix;
   }
@@ -688,7 +704,7 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   {
     int w = W0, h = H0;
     for (int o = 0; o < n_oct; ++o) {
-      total += (size_t)(2 * NG - 1) * w * h;
+      total += (size_t)NG * w * h;
       w /= 2;
       h /= 2;
     }
@@ -729,10 +745,6 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
         P.g[o][i] = cur;
         cur += (size_t)w * h;
       }
-      for (int i = 0; i < NG - 1; ++i) {
-        oct[o].d[i] = cur;
-        cur += (size_t)w * h;
-      }
       w /= 2;
       h /= 2;
     }
@@ -765,10 +777,6 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
         hipLaunchKernelGGL(blur_kernel<false>, grid2(w, h), dim3(256), 0, st, tmp, h, w, taps[i],
                            const_cast<float*>(oct[o].g[i]));
       }
-      const size_t n = (size_t)w * h;
-      for (int i = 0; i < NG - 1; ++i)
-        hipLaunchKernelGGL(dog_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, oct[o].g[i],
-                           oct[o].g[i + 1], n, const_cast<float*>(oct[o].d[i]));
     }
   }
   VO_TRY(vo_check_launch(ctx, "sift scale space"));
@@ -783,9 +791,8 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_DETECT);
     for (int o = 0; o < n_oct; ++o)
-      for (int layer = 1; layer <= NOL; ++layer)
-        hipLaunchKernelGGL(extrema_kernel, grid2(oct[o].W, oct[o].H), dim3(256), 0, st, oct[o], layer, threshold,
-                           (int4*)ctx->scratch[0].p, d_cnt + C_CAND, cap_cand);
+      hipLaunchKernelGGL(extrema_kernel, grid2(oct[o].W, oct[o].H), dim3(256), 0, st, oct[o], threshold,
+                         (int4*)ctx->scratch[0].p, d_cnt + C_CAND, cap_cand);
     // counts stay on the device: fixed grids, every kernel strides over what the one before it produced
     hipLaunchKernelGGL(refine_kernel, dim3(1024), dim3(256), 0, st, OS, (const int4*)ctx->scratch[0].p, d_cnt + C_CAND,
                        cap_cand, contrast_thr, edge_thr, sigma, (unsigned long long*)ctx->scratch[5].p, table_len - 1,
