@@ -90,19 +90,39 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const uint8_t* __restric
   out[(size_t)y * W0 + x] = top * (1.f - fy) + bot * fy;
 }
 
-template <bool ROWS>
-__global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ src, int H, int W, taps_t k,
-                                                   float* __restrict__ dst) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= W || y >= H) return;
-  float s = 0.f;
-  if (ROWS) {
-    const float* row = src + (size_t)y * W;
-    for (int j = -k.r; j <= k.r; ++j) s += k.w[j + k.r] * row[refl(x + j, W)];
-  } else {
-    for (int j = -k.r; j <= k.r; ++j) s += k.w[j + k.r] * src[(size_t)refl(y + j, H) * W + x];
+// Row pass and column pass of one Gaussian in one launch: a 64x32 output tile, its input with `r` pixels of halo and
+// the row-blurred intermediate live in LDS (the image-wide version reads every input 2 (2r + 1) times through the
+// cache hierarchy and round-trips the intermediate through HBM).  Each sum runs in tap order without FMA, as above.
+constexpr int BT_W = 64, BT_H = 32;
+__global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ src, int H, int W, taps_t k,
+                                                     float* __restrict__ dst) {
+  extern __shared__ float blur_smem[];
+  const int r = k.r, PI = BT_W + 2 * r, RH = BT_H + 2 * r;
+  float* s_in = blur_smem;                 // RH x PI
+  float* s_mid = blur_smem + RH * PI;      // RH x BT_W
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+  for (int ky = ty; ky < RH; ky += 4) {
+    const float* row = src + (size_t)refl(y0 - r + ky, H) * W;
+    for (int kx = tx; kx < PI; kx += 64) s_in[ky * PI + kx] = row[refl(x0 - r + kx, W)];
   }
-  dst[(size_t)y * W + x] = s;
+  __syncthreads();
+  for (int ky = ty; ky < RH; ky += 4) {
+    const float* q = s_in + ky * PI + tx;
+    float s = 0.f;
+    for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j];
+    s_mid[ky * BT_W + tx] = s;
+  }
+  __syncthreads();
+  const int x = x0 + tx;
+  for (int ly = ty; ly < BT_H; ly += 4) {
+    const int y = y0 + ly;
+    if (x >= W || y >= H) continue;
+    const float* q = s_mid + ly * BT_W + tx;
+    float s = 0.f;
+    for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j * BT_W];
+    dst[(size_t)y * W + x] = s;
+  }
 }
 
 __global__ __launch_bounds__(256) void decimate_kernel(const float* __restrict__ src, int pw, int H, int W,
@@ -305,6 +325,34 @@ __global__ __launch_bounds__(256) void refine_kernel(octs_t OS, const int4* __re
   }
 }
 
+// The (2 R + 3)^2 pixels around (cy, cx) of an octave image -> LDS (zeros outside the image), all loads of a batch in
+// flight together: the sample loops below then run out of LDS instead of paying a global round trip per 64 samples.
+template <int BATCH>
+__device__ __forceinline__ void stage_patch(const float* __restrict__ g, int H, int W, int cy, int cx, int R,
+                                            float* __restrict__ s_patch, int lane) {
+  const int PW = 2 * R + 3, n = PW * PW;
+  const int y0 = cy - R - 1, x0 = cx - R - 1;
+  for (int base = 0; base < n; base += 64 * BATCH) {
+    float v[BATCH];
+#pragma unroll
+    for (int b = 0; b < BATCH; ++b) {
+      const int i = base + b * 64 + lane;
+      const int yy = i / PW, xx = i - yy * PW;
+      const int gy = y0 + yy, gx = x0 + xx;
+      const bool in = i < n && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      v[b] = in ? g[(size_t)(in ? gy : 0) * W + (in ? gx : 0)] : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < BATCH; ++b) {
+      const int i = base + b * 64 + lane;
+      if (i < n) s_patch[i] = v[b];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+constexpr int ORI_RMAX = 17, DESC_RMAX = 39;   // radii cv2's default parameters reach: 16 and 38 (larger: global reads)
+
 // Orientation histogram of every refined extremum: one wave per extremum.  The reference accumulates the 36 bins
 // in pixel raster order; here 64 lanes evaluate 64 consecutive raster positions (gradient, exp, atan2: the
 // expensive part), their (bin, weight) pairs are compacted in raster order into LDS, and lane b adds the pairs of
@@ -313,9 +361,9 @@ __global__ __launch_bounds__(64) void orient_kernel(octs_t OS, const surv_t* __r
                                                     const unsigned* __restrict__ n_surv, unsigned cap_surv,
                                                     skp_t* __restrict__ out, unsigned* __restrict__ n_out,
                                                     unsigned cap_out) {
-  __shared__ int s_bin[64];
   __shared__ float s_add[64];
   __shared__ float s_tmp[36];
+  __shared__ float s_patch[(2 * ORI_RMAX + 3) * (2 * ORI_RMAX + 3)];
   const int lane = threadIdx.x;
   const unsigned n = min(*n_surv, cap_surv);
   for (unsigned k = blockIdx.x; k < n; k += gridDim.x) {
@@ -328,6 +376,9 @@ __global__ __launch_bounds__(64) void orient_kernel(octs_t OS, const surv_t* __r
     const float* g = O.g[sv.kp.layer];
     const float expf_scale = -1.f / (2.f * osig * osig);
     const int side = 2 * radius + 1, total = side * side;
+    const bool staged = radius <= ORI_RMAX;
+    const int PW = 2 * radius + 3;
+    if (staged) stage_patch<8>(g, H, W, r, c, radius, s_patch, lane);
     float acc = 0.f;                                  // lane b < 36: bin b
     for (int base = 0; base < total; base += 64) {
       const int p = base + lane;
@@ -338,8 +389,15 @@ __global__ __launch_bounds__(64) void orient_kernel(octs_t OS, const surv_t* __r
         const int ii = p / side - radius, jj = p - (p / side) * side - radius;
         const int y = r + ii, x = c + jj;
         if (y > 0 && y < H - 1 && x > 0 && x < W - 1) {
-          const float dx = g[(size_t)y * W + x + 1] - g[(size_t)y * W + x - 1];
-          const float dy = g[(size_t)(y - 1) * W + x] - g[(size_t)(y + 1) * W + x];
+          float dx, dy;
+          if (staged) {
+            const float* q = s_patch + (ii + radius + 1) * PW + (jj + radius + 1);
+            dx = q[1] - q[-1];
+            dy = q[-PW] - q[PW];
+          } else {
+            dx = g[(size_t)y * W + x + 1] - g[(size_t)y * W + x - 1];
+            dy = g[(size_t)(y - 1) * W + x] - g[(size_t)(y + 1) * W + x];
+          }
           const float w = sift_exp((float)(ii * ii + jj * jj) * expf_scale);
           const float ori = sift_atan2(dy, dx);
           const float mag = sqrtf(dx * dx + dy * dy);
@@ -350,19 +408,17 @@ __global__ __launch_bounds__(64) void orient_kernel(octs_t OS, const surv_t* __r
           on = true;
         }
       }
-      const unsigned long long m = __ballot(on);
-      if (on) {
-        const int slot = __popcll(m & ((1ull << lane) - 1ull));
-        s_bin[slot] = bin;
-        s_add[slot] = add;
+      // lane b adds the samples of bin b in lane order = raster order; the samples come through scalar registers
+      // (v_readlane), no LDS round trip per sample
+      if (!on) bin = -1;
+      if (__ballot(on) != 0ull) {
+#pragma unroll
+        for (int e = 0; e < 64; ++e) {
+          const int be = __builtin_amdgcn_readlane(bin, e);
+          const float ae = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, add), e));
+          if (be == lane) acc += ae;
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      const int cnt = __popcll(m);
-      for (int e = 0; e < cnt; ++e)
-        if (s_bin[e] == lane) acc += s_add[e];
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
     }
     if (lane < 36) s_tmp[lane] = acc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -473,22 +529,29 @@ struct pyr_ptrs {
   int H[MAX_OCT], W[MAX_OCT];
 };
 
-// One wave per selected keypoint.  The reference adds every sample's eight trilinear shares into the
-// (4+2) x (4+2) x (8+2) histogram in pixel raster order; here the 64 lanes evaluate 64 consecutive raster positions
-// (gradient, rotation, exp, atan2, the eight shares), the samples that pass the window test are compacted in raster
-// order into LDS, and lane L < 36 owns spatial cell L: it walks the compacted samples in order and adds the two
-// orientation shares of every sample that touches its cell -- each bin receives the additions of the sequential
-// loop in the sequential loop's order.  The closing normalisation is the sequential code on one lane.
-__global__ __launch_bounds__(64) void descriptor_kernel(pyr_ptrs P, const skp_t* __restrict__ kps,
-                                                        const unsigned* __restrict__ sel,
-                                                        const unsigned* __restrict__ n_sel,
-                                                        float* __restrict__ rows /* n x 134 */) {
-  __shared__ float s_v[64][8];
-  __shared__ int s_cell[64];          // (r0 + 1) | (c0 + 1) << 8 | o0 << 16
-  __shared__ float s_hist[36][10];
-  const int lane = threadIdx.x;
+// One workgroup (four waves) per selected keypoint.  The reference adds every sample's eight trilinear shares into
+// the (4+2) x (4+2) x (8+2) histogram in pixel raster order.  Here 256 work items evaluate 256 consecutive raster
+// positions per round (gradient from the staged patch, rotation, exp, atan2, the eight shares) and leave the shares in
+// LDS together with ballots of each sample's first cell row, first cell column and first orientation bin.  The 16 x 9
+// histogram bins that reach the output (inner cells; orientation bin 9 never receives anything) are owned by one
+// work item each: it intersects the ballots into the set of samples that add to its bin -- and which of their eight
+// shares -- and adds them in ascending position = raster order.  Every bin receives the additions of the sequential
+// loop in the sequential loop's order; the closing normalisation is the sequential code on one work item.
+constexpr int DESC_T = 256, DESC_VP = 9;           // work items; pitch of a sample's shares (odd: no bank conflicts)
+__global__ __launch_bounds__(DESC_T) void descriptor_kernel(pyr_ptrs P, const skp_t* __restrict__ kps,
+                                                            const unsigned* __restrict__ sel,
+                                                            const unsigned* __restrict__ n_sel,
+                                                            float* __restrict__ rows /* n x 134 */) {
+  __shared__ float s_v[DESC_T * DESC_VP];
+  __shared__ unsigned long long s_m[DESC_T / 64][18];   // per wave: 5 row ballots, 5 column ballots, 8 orientation ballots
+  __shared__ float s_hist[16][10];
+  __shared__ float s_patch[(2 * DESC_RMAX + 3) * (2 * DESC_RMAX + 3)];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const unsigned n = *n_sel;
   const int d = 4, n8 = 8;
+  // the bin work item tid < 144 owns: inner cell (cr, cc) in 1..4, orientation bin ob in 0..8
+  const int ci = tid / 9, ob = tid - ci * 9;
+  const int cr = 1 + (ci >> 2), cc = 1 + (ci & 3);
   for (unsigned k = blockIdx.x; k < n; k += gridDim.x) {
     const skp_t q = kps[sel[k]];
     const float* g = P.g[q.oct][q.layer];
@@ -523,26 +586,52 @@ __global__ __launch_bounds__(64) void descriptor_kernel(pyr_ptrs P, const skp_t*
     if (radius > maxr) radius = maxr;
     cos_t /= hist_width;
     sin_t /= hist_width;
-    for (int i = lane; i < 360; i += 64) (&s_hist[0][0])[i] = 0.f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const int cr = lane / 6, cc = lane - cr * 6;       // the cell lane < 36 owns
-    const long long side = 2LL * radius + 1, total = side * side;
-    for (long long base = 0; base < total; base += 64) {
-      const long long p = base + lane;
-      bool on = false;
-      float v[8];
-      int cell = 0;
+    const bool staged = radius <= DESC_RMAX;
+    const int PW = 2 * radius + 3;
+    if (staged) {
+      const int np = PW * PW, y0 = pyi - radius - 1, x0 = pxi - radius - 1;
+      for (int base = 0; base < np; base += DESC_T * 4) {
+        float v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int i = base + b * DESC_T + tid;
+          const int yy = i / PW, xx = i - yy * PW;
+          const int gy = y0 + yy, gx = x0 + xx;
+          const bool in = i < np && gy >= 0 && gy < H && gx >= 0 && gx < W;
+          v[b] = in ? g[(size_t)(in ? gy : 0) * W + (in ? gx : 0)] : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int i = base + b * DESC_T + tid;
+          if (i < np) s_patch[i] = v[b];
+        }
+      }
+    }
+    __syncthreads();
+    float acc = 0.f;
+    const int side = 2 * radius + 1;
+    const long long total = (long long)side * side;
+    for (long long base = 0; base < total; base += DESC_T) {
+      const long long p = base + tid;
+      int ca = -8, cb = -8, co = -8;                   // first cell row / column / orientation bin (none: matches nothing)
       if (p < total) {
-        const int i = (int)(p / side) - radius, j = (int)(p - (p / side) * side) - radius;
+        const int pi = (int)(p / side);
+        const int i = pi - radius, j = (int)(p - (long long)pi * side) - radius;
         const float c_rot = j * cos_t - i * sin_t;
         const float r_rot = j * sin_t + i * cos_t;
         float rbin = r_rot + d / 2 - 0.5f;
         float cbin = c_rot + d / 2 - 0.5f;
         const int r = pyi + i, c = pxi + j;
         if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < H - 1 && c > 0 && c < W - 1) {
-          const float dx = g[(size_t)r * W + c + 1] - g[(size_t)r * W + c - 1];
-          const float dy = g[(size_t)(r - 1) * W + c] - g[(size_t)(r + 1) * W + c];
+          float dx, dy;
+          if (staged) {
+            const float* qq = s_patch + (i + radius + 1) * PW + (j + radius + 1);
+            dx = qq[1] - qq[-1];
+            dy = qq[-PW] - qq[PW];
+          } else {
+            dx = g[(size_t)r * W + c + 1] - g[(size_t)r * W + c - 1];
+            dy = g[(size_t)(r - 1) * W + c] - g[(size_t)(r + 1) * W + c];
+          }
           const float wgt = sift_exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
           const float ang = sift_atan2(dy, dx);
           const float mag = sqrtf(dx * dx + dy * dy) * wgt;
@@ -561,45 +650,58 @@ __global__ __launch_bounds__(64) void descriptor_kernel(pyr_ptrs P, const skp_t*
           const float v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
           const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011;
           const float v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-          v[0] = v_rco000;
-          v[1] = v_rco001;
-          v[2] = v_rco010;
-          v[3] = v_rco011;
-          v[4] = v_rco100;
-          v[5] = v_rco101;
-          v[6] = v_rco110;
-          v[7] = v_rco111;
-          cell = (r0 + 1) | ((c0 + 1) << 8) | (o0 << 16);
-          on = true;
+          float* vv = s_v + tid * DESC_VP;
+          vv[0] = v_rco000;
+          vv[1] = v_rco001;
+          vv[2] = v_rco010;
+          vv[3] = v_rco011;
+          vv[4] = v_rco100;
+          vv[5] = v_rco101;
+          vv[6] = v_rco110;
+          vv[7] = v_rco111;
+          ca = r0 + 1;
+          cb = c0 + 1;
+          co = o0;
         }
       }
-      const unsigned long long m = __ballot(on);
-      if (on) {
-        const int slot = __popcll(m & ((1ull << lane) - 1ull));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_v[slot][e] = v[e];
-        s_cell[slot] = cell;
+      for (int x = 0; x < 5; ++x) {
+        const unsigned long long ra = __ballot(ca == x), cbm = __ballot(cb == x);
+        if (lane == 0) {
+          s_m[wid][x] = ra;
+          s_m[wid][5 + x] = cbm;
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      const int cnt = __popcll(m);
-      if (lane < 36) {
-        for (int e = 0; e < cnt; ++e) {
-          const int ce = s_cell[e];
-          const int dr = cr - (ce & 255), dc = cc - ((ce >> 8) & 255), o0 = ce >> 16;
-          if ((unsigned)dr <= 1u && (unsigned)dc <= 1u) {
-            const float* vv = &s_v[e][dr * 4 + dc * 2];
-            s_hist[lane][o0] += vv[0];
-            s_hist[lane][o0 + 1] += vv[1];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const unsigned long long om = __ballot(co == x);
+        if (lane == 0) s_m[wid][10 + x] = om;
+      }
+      __syncthreads();
+      if (tid < 144) {
+#pragma unroll
+        for (int w = 0; w < DESC_T / 64; ++w) {
+          const unsigned long long* m = s_m[w];
+          const unsigned long long r1 = m[cr - 1], c1 = m[5 + cc - 1];            // second row / column of the sample's block
+          const unsigned long long o1 = ob >= 1 ? m[10 + ob - 1] : 0ull;          // its second orientation bin
+          const unsigned long long o0m = ob <= 7 ? m[10 + ob] : 0ull;
+          unsigned long long mine = (m[cr] | r1) & (m[5 + cc] | c1) & (o0m | o1);
+          const float* vw = s_v + w * 64 * DESC_VP;
+          while (mine) {
+            const int e = __builtin_ctzll(mine);
+            mine &= mine - 1ull;
+            const int share = (int)((r1 >> e) & 1ull) * 4 + (int)((c1 >> e) & 1ull) * 2 + (int)((o1 >> e) & 1ull);
+            acc += vw[e * DESC_VP + share];
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
     }
-    // fold the orientation wrap, then threshold / normalise as the sequential code does (one lane: the two norms are
-    // sums in index order)
-    if (lane == 0) {
+    if (tid < 144) s_hist[ci][ob] = acc;
+    __syncthreads();
+    // fold the orientation wrap, then threshold / normalise as the sequential code does (one work item: the two norms
+    // are sums in index order)
+    if (tid == 0) {
       row[0] = q.x * 0.5f;
       row[1] = q.y * 0.5f;
       row[2] = q.size * 0.5f;
@@ -610,9 +712,8 @@ __global__ __launch_bounds__(64) void descriptor_kernel(pyr_ptrs P, const skp_t*
       float nrm2 = 0;
       for (int i = 0; i < d; ++i)
         for (int j = 0; j < d; ++j) {
-          float* hc = s_hist[(i + 1) * (d + 2) + (j + 1)];
-          hc[0] += hc[n8];
-          hc[1] += hc[n8 + 1];
+          float* hc = s_hist[i * d + j];
+          hc[0] += hc[n8];                       // (hc[1] += bin 9, which is never written: + 0)
           for (int b = 0; b < n8; ++b) {
             const float t = hc[b];
             raw[(i * d + j) * n8 + b] = t;
@@ -632,8 +733,7 @@ __global__ __launch_bounds__(64) void descriptor_kernel(pyr_ptrs P, const skp_t*
         raw[b] = t < 0 ? 0.f : (t > 255.f ? 255.f : t);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
 }
 
@@ -699,8 +799,8 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
     }
     n_oct = k;
   }
-  // one arena for the whole scale space: per octave NG Gaussian + NG-1 DoG images, plus one temp
-  size_t total = (size_t)W0 * H0;   // temp
+  // one arena for the whole scale space: per octave NG Gaussian images
+  size_t total = 0;
   {
     int w = W0, h = H0;
     for (int o = 0; o < n_oct; ++o) {
@@ -727,8 +827,7 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   VO_HIP_TRY(ctx, hipMemsetAsync(ctx->scratch[5].p, 0, (size_t)table_len * 8, st));
 
   float* arena = (float*)ctx->sift_arena.p;
-  float* tmp = arena;
-  float* cur = arena + (size_t)W0 * H0;
+  float* cur = arena;
   oct_t oct[MAX_OCT];
   pyr_ptrs P;
   memset(&P, 0, sizeof(P));
@@ -759,24 +858,22 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
     }
   }
   auto grid2 = [](int w, int h) { return dim3(vo_cdiv(w, 64), vo_cdiv(h, 4)); };
+  auto blur = [&](const float* src, int h, int w, const taps_t& t, float* dst) {
+    const size_t lds = (size_t)(BT_H + 2 * t.r) * (2 * BT_W + 2 * t.r) * 4;
+    hipLaunchKernelGGL(blur2d_kernel, dim3(vo_cdiv(w, BT_W), vo_cdiv(h, BT_H)), dim3(256), lds, st, src, h, w, t, dst);
+  };
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_SCALESPACE);
     // base image: doubled, blurred to sigma
     float* up = const_cast<float*>(oct[0].g[1]);   // scratch until g[1] is produced
     hipLaunchKernelGGL(upsample2_kernel, grid2(W0, H0), dim3(256), 0, st, (const uint8_t*)ctx->img.p, H, W, up);
-    hipLaunchKernelGGL(blur_kernel<true>, grid2(W0, H0), dim3(256), 0, st, up, H0, W0, taps[0], tmp);
-    hipLaunchKernelGGL(blur_kernel<false>, grid2(W0, H0), dim3(256), 0, st, tmp, H0, W0, taps[0],
-                       const_cast<float*>(oct[0].g[0]));
+    blur(up, H0, W0, taps[0], const_cast<float*>(oct[0].g[0]));
     for (int o = 0; o < n_oct; ++o) {
       const int w = oct[o].W, h = oct[o].H;
       if (o > 0)
         hipLaunchKernelGGL(decimate_kernel, grid2(w, h), dim3(256), 0, st, oct[o - 1].g[NOL], oct[o - 1].W, h, w,
                            const_cast<float*>(oct[o].g[0]));
-      for (int i = 1; i < NG; ++i) {
-        hipLaunchKernelGGL(blur_kernel<true>, grid2(w, h), dim3(256), 0, st, oct[o].g[i - 1], h, w, taps[i], tmp);
-        hipLaunchKernelGGL(blur_kernel<false>, grid2(w, h), dim3(256), 0, st, tmp, h, w, taps[i],
-                           const_cast<float*>(oct[o].g[i]));
-      }
+      for (int i = 1; i < NG; ++i) blur(oct[o].g[i - 1], h, w, taps[i], const_cast<float*>(oct[o].g[i]));
     }
   }
   VO_TRY(vo_check_launch(ctx, "sift scale space"));
@@ -797,7 +894,7 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
     hipLaunchKernelGGL(refine_kernel, dim3(1024), dim3(256), 0, st, OS, (const int4*)ctx->scratch[0].p, d_cnt + C_CAND,
                        cap_cand, contrast_thr, edge_thr, sigma, (unsigned long long*)ctx->scratch[5].p, table_len - 1,
                        d_surv, d_cnt + C_SURV, cap_kp);
-    hipLaunchKernelGGL(orient_kernel, dim3(4096), dim3(64), 0, st, OS, d_surv, d_cnt + C_SURV, cap_kp, d_kps, d_cnt + C_KP,
+    hipLaunchKernelGGL(orient_kernel, dim3(8192), dim3(64), 0, st, OS, d_surv, d_cnt + C_SURV, cap_kp, d_kps, d_cnt + C_KP,
                        cap_kp);
     hipLaunchKernelGGL(overflow_kernel, dim3(1), dim3(1), 0, st, d_cnt, cap_cand, cap_kp, d_cnt + C_OVER);
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, st, d_kps, d_cnt + C_KP, cap_kp, (unsigned)cap, d_sel,
@@ -806,7 +903,7 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   VO_TRY(vo_check_launch(ctx, "sift detection"));
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_DESCRIBE);
-    hipLaunchKernelGGL(descriptor_kernel, dim3(4096), dim3(64), 0, st, P, d_kps, d_sel, d_cnt + C_SEL, d_rows);
+    hipLaunchKernelGGL(descriptor_kernel, dim3(2048), dim3(DESC_T), 0, st, P, d_kps, d_sel, d_cnt + C_SEL, d_rows);
   }
   VO_TRY(vo_check_launch(ctx, "sift descriptor_kernel"));
   unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
