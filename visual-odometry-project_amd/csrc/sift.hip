@@ -93,11 +93,14 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const uint8_t* __restric
 // Row pass and column pass of one Gaussian in one launch: a 64x32 output tile, its input with `r` pixels of halo and
 // the row-blurred intermediate live in LDS (the image-wide version reads every input 2 (2r + 1) times through the
 // cache hierarchy and round-trips the intermediate through HBM).  Each sum runs in tap order without FMA, as above.
+// R_T > 0: radius known at compile time -- the tap loops unroll, so a sum's LDS reads are all in flight before its
+// first addition (with a runtime trip count every tap waits for its own read: 15-25 us for a single tile).
 constexpr int BT_W = 64, BT_H = 32;
+template <int R_T>
 __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ src, int H, int W, taps_t k,
                                                      float* __restrict__ dst) {
   extern __shared__ float blur_smem[];
-  const int r = k.r, PI = BT_W + 2 * r, RH = BT_H + 2 * r;
+  const int r = R_T > 0 ? R_T : k.r, PI = BT_W + 2 * r, RH = BT_H + 2 * r;
   float* s_in = blur_smem;                 // RH x PI
   float* s_mid = blur_smem + RH * PI;      // RH x BT_W
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -110,7 +113,12 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ s
   for (int ky = ty; ky < RH; ky += 4) {
     const float* q = s_in + ky * PI + tx;
     float s = 0.f;
-    for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j];
+    if (R_T > 0) {
+#pragma unroll
+      for (int j = 0; j <= 2 * R_T; ++j) s += k.w[j] * q[j];
+    } else {
+      for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j];
+    }
     s_mid[ky * BT_W + tx] = s;
   }
   __syncthreads();
@@ -120,7 +128,12 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ s
     if (x >= W || y >= H) continue;
     const float* q = s_mid + ly * BT_W + tx;
     float s = 0.f;
-    for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j * BT_W];
+    if (R_T > 0) {
+#pragma unroll
+      for (int j = 0; j <= 2 * R_T; ++j) s += k.w[j] * q[j * BT_W];
+    } else {
+      for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j * BT_W];
+    }
     dst[(size_t)y * W + x] = s;
   }
 }
@@ -611,12 +624,13 @@ __global__ __launch_bounds__(DESC_T) void descriptor_kernel(pyr_ptrs P, const sk
     float acc = 0.f;
     const int side = 2 * radius + 1;
     const long long total = (long long)side * side;
+    // raster position of this work item: (pi, pj), advanced by DESC_T positions per round without a division
+    int pi = tid / side, pj = tid - pi * side;
+    const int step_i = DESC_T / side, step_j = DESC_T - step_i * side;
     for (long long base = 0; base < total; base += DESC_T) {
-      const long long p = base + tid;
       int ca = -8, cb = -8, co = -8;                   // first cell row / column / orientation bin (none: matches nothing)
-      if (p < total) {
-        const int pi = (int)(p / side);
-        const int i = pi - radius, j = (int)(p - (long long)pi * side) - radius;
+      if (pi < side) {
+        const int i = pi - radius, j = pj - radius;
         const float c_rot = j * cos_t - i * sin_t;
         const float r_rot = j * sin_t + i * cos_t;
         float rbin = r_rot + d / 2 - 0.5f;
@@ -677,6 +691,12 @@ __global__ __launch_bounds__(DESC_T) void descriptor_kernel(pyr_ptrs P, const sk
         const unsigned long long om = __ballot(co == x);
         if (lane == 0) s_m[wid][10 + x] = om;
       }
+      pi += step_i;
+      pj += step_j;
+      if (pj >= side) {
+        pj -= side;
+        ++pi;
+      }
       __syncthreads();
       if (tid < 144) {
 #pragma unroll
@@ -701,37 +721,41 @@ __global__ __launch_bounds__(DESC_T) void descriptor_kernel(pyr_ptrs P, const sk
     __syncthreads();
     // fold the orientation wrap, then threshold / normalise as the sequential code does (one work item: the two norms
     // are sums in index order)
+    // (everything elementwise in parallel out of LDS; the two norms are sums in index order on one work item, their
+    //  128 terms read before the first addition)
+    float* s_raw = s_v;                                  // 128 entries (the samples are done with)
+    if (tid < 16) s_hist[tid][0] += s_hist[tid][n8];     // (hist[1] += bin 9, which is never written: + 0)
+    __syncthreads();
+    if (tid < 128) s_raw[tid] = s_hist[tid >> 3][tid & 7];
+    __syncthreads();
     if (tid == 0) {
+      float nrm2 = 0;
+#pragma unroll
+      for (int b = 0; b < 128; ++b) nrm2 += s_raw[b] * s_raw[b];
+      s_raw[128] = sqrtf(nrm2) * 0.2f;
+    }
+    __syncthreads();
+    const float thr = s_raw[128];
+    __syncthreads();
+    if (tid < 128) s_raw[tid] = s_raw[tid] < thr ? s_raw[tid] : thr;
+    __syncthreads();
+    if (tid == 0) {
+      float nrm2 = 0;
+#pragma unroll
+      for (int b = 0; b < 128; ++b) nrm2 += s_raw[b] * s_raw[b];
+      s_raw[129] = 512.f / fmaxf(sqrtf(nrm2), 1.1920929e-07f);
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const float t = rintf(s_raw[tid] * s_raw[129]);
+      row[6 + tid] = t < 0 ? 0.f : (t > 255.f ? 255.f : t);
+    } else if (tid == 128) {
       row[0] = q.x * 0.5f;
       row[1] = q.y * 0.5f;
       row[2] = q.size * 0.5f;
       row[3] = q.angle;
       row[4] = q.response;
       row[5] = (float)(q.oct - 1);
-      float* raw = row + 6;
-      float nrm2 = 0;
-      for (int i = 0; i < d; ++i)
-        for (int j = 0; j < d; ++j) {
-          float* hc = s_hist[i * d + j];
-          hc[0] += hc[n8];                       // (hc[1] += bin 9, which is never written: + 0)
-          for (int b = 0; b < n8; ++b) {
-            const float t = hc[b];
-            raw[(i * d + j) * n8 + b] = t;
-            nrm2 += t * t;
-          }
-        }
-      const float thr = sqrtf(nrm2) * 0.2f;
-      nrm2 = 0;
-      for (int b = 0; b < 128; ++b) {
-        const float t = raw[b] < thr ? raw[b] : thr;
-        raw[b] = t;
-        nrm2 += t * t;
-      }
-      const float s = 512.f / fmaxf(sqrtf(nrm2), 1.1920929e-07f);
-      for (int b = 0; b < 128; ++b) {
-        const float t = rintf(raw[b] * s);
-        raw[b] = t < 0 ? 0.f : (t > 255.f ? 255.f : t);
-      }
     }
     __syncthreads();
   }
@@ -821,7 +845,10 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   VO_TRY(vo_ensure(ctx, ctx->scratch[4], (size_t)cap_kp * sizeof(surv_t)));
   VO_TRY(vo_ensure(ctx, ctx->scratch[5], (size_t)table_len * 8));
   VO_TRY(vo_ensure(ctx, ctx->scratch[6], (size_t)cap_kp * 4));
-  VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, img, (size_t)H * W, hipMemcpyHostToDevice, st));
+  // through the context's pinned staging buffer: a DMA each way instead of the runtime's pageable-memory path
+  VO_TRY(vo_ensure_pinned(ctx, (size_t)H * W));
+  memcpy(ctx->h_pin, img, (size_t)H * W);
+  VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, ctx->h_pin, (size_t)H * W, hipMemcpyHostToDevice, st));
   unsigned* d_cnt = (unsigned*)ctx->scratch[2].p;   // counters of this call, see C_CAND ..
   VO_HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 64, st));
   VO_HIP_TRY(ctx, hipMemsetAsync(ctx->scratch[5].p, 0, (size_t)table_len * 8, st));
@@ -860,7 +887,15 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   auto grid2 = [](int w, int h) { return dim3(vo_cdiv(w, 64), vo_cdiv(h, 4)); };
   auto blur = [&](const float* src, int h, int w, const taps_t& t, float* dst) {
     const size_t lds = (size_t)(BT_H + 2 * t.r) * (2 * BT_W + 2 * t.r) * 4;
-    hipLaunchKernelGGL(blur2d_kernel, dim3(vo_cdiv(w, BT_W), vo_cdiv(h, BT_H)), dim3(256), lds, st, src, h, w, t, dst);
+    const dim3 grid(vo_cdiv(w, BT_W), vo_cdiv(h, BT_H));
+    switch (t.r) {   // the radii of cv2.SIFT_create()'s default sigma
+      case 5: hipLaunchKernelGGL(blur2d_kernel<5>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
+      case 6: hipLaunchKernelGGL(blur2d_kernel<6>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
+      case 8: hipLaunchKernelGGL(blur2d_kernel<8>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
+      case 10: hipLaunchKernelGGL(blur2d_kernel<10>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
+      case 13: hipLaunchKernelGGL(blur2d_kernel<13>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
+      default: hipLaunchKernelGGL(blur2d_kernel<0>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
+    }
   };
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_SCALESPACE);
@@ -912,8 +947,9 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   if (cnt[C_OVER]) return vo_set_error(ctx, VO_ECAPACITY, "sift: candidate / keypoint list overflow");
   const unsigned n_all = cnt[C_SEL];      // rows described: all keypoints, or those at or above the cap's response bound
   if (n_all == 0) return VO_OK;
-  std::vector<float> rows((size_t)n_all * 134);
-  VO_HIP_TRY(ctx, hipMemcpyAsync(rows.data(), d_rows, rows.size() * 4, hipMemcpyDeviceToHost, st));
+  VO_TRY(vo_ensure_pinned(ctx, (size_t)n_all * 134 * 4));
+  const float* rows = (const float*)ctx->h_pin;
+  VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, d_rows, (size_t)n_all * 134 * 4, hipMemcpyDeviceToHost, st));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   // order, duplicates, optional cap (KeyPointsFilter::removeDuplicatedSorted / retainBest)
   std::vector<unsigned> order(n_all);
