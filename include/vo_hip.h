@@ -225,7 +225,9 @@ int vo_knn2_dev(vo_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt,
 /* ---- Shi-Tomasi corners -----------------------------------------------------------
  * [ref: src/vo/features/klt.py:98]  cv2.goodFeaturesToTrack(img, mask, maxCorners,
  * qualityLevel, minDistance, blockSize).  xy: max_corners*2 float32 (or H*W/4*2 when
- * max_corners <= 0); n: corners found.  vo_min_eigen_map exposes the H*W float32 map. */
+ * max_corners <= 0); n: corners found.  vo_min_eigen_map exposes the H*W float32 map.
+ * All stages run on the device: eigenvalue map, thresholded 3x3 maxima, descending order
+ * (value, then address) and the greedy minimum-distance walk over OpenCV's cell grid.     */
 int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_t* mask,
                      int max_corners, double quality, double min_dist, int block, float* xy,
                      int32_t* n);

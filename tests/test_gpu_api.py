@@ -71,6 +71,20 @@ def test_good_features_match_oracle(ctx, shape, seed):
     assert np.array_equal(gotm, refm) and np.all(gotm[:, 0] < shape[1] // 2)
 
 
+@pytest.mark.parametrize("n,quality,min_dist,block", [(2000, 0.01, 8, 7), (500, 0.01, 7.5, 7), (0, 0.02, 12, 5),
+                                                      (3000, 0.01, 0, 7), (100000, 0.001, 3, 3)])
+def test_good_features_at_configuration_size(ctx, n, quality, min_dist, block):
+    """cv2.goodFeaturesToTrack's ordering and greedy minimum-distance rule run on the device (descending radix sort,
+    one workgroup walking the rule): the same corners in the same order as the oracle's sequential walk, at
+    1376x1241, for the bootstrap's 2000 corners, a fractional distance, no corner limit, no distance, and a list
+    long enough to need many blocks."""
+    img = synthetic_image(1241, 1376, 17, block=9)
+    ref = native.good_features(img, None, n, quality, min_dist, block)
+    got = ctx.good_features(img, None, n, quality, min_dist, block)
+    assert len(ref) > 400
+    assert np.array_equal(got, ref)
+
+
 # ---------------- the reference's tests/test_p3p.py, restated ----------------
 def test_estimate_pose_like_reference_test(ctx):
     from vo.pose_estimation import P3PPoseEstimator

@@ -7,14 +7,20 @@
 // block x block structure tensor of 3x3 Sobel gradients (reflect-101 borders, exact
 // integer sums scaled once), quality threshold against the masked maximum, 3x3 local
 // maxima, descending order, greedy minimum-distance selection.
-// Device: the image-wide work (eigenvalue map, maximum, thresholded local maxima ->
-// compact candidate list).  Host: ordering and the greedy distance filter over the few
-// thousand candidates, with a cell grid as OpenCV does -- it runs only when the tracker
-// (re)detects, klt.py:207-230.
+// Everything on the device: eigenvalue map, maximum, thresholded local maxima -> candidate keys
+// (value | address), descending radix sort (rocPRIM), then the greedy minimum-distance rule itself,
+// walked by one workgroup in blocks of 512 candidates: a candidate is tested against the accepted
+// corners of earlier blocks through a cell grid (cell side = minDistance, as OpenCV keeps it) and
+// against the earlier candidates of its own block by the rule's own recursion -- accepted when every
+// earlier neighbour is rejected, rejected when one is accepted -- which settles in a few sweeps.
 #include <algorithm>
 #include <cmath>
 
+#include <cstring>
+
 #include "vo_internal.h"
+
+#include <rocprim/rocprim.hpp>
 
 #pragma clang fp contract(off)
 
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(GT) void min_eig_kernel(const uint8_t* __restrict__
 __global__ __launch_bounds__(GT) void corner_candidates_kernel(const float* __restrict__ eig, int H, int W,
                                                                const uint8_t* __restrict__ mask,
                                                                const unsigned* __restrict__ max_key, double quality,
-                                                               float* __restrict__ val, int* __restrict__ idx,
+                                                               unsigned long long* __restrict__ keys,
                                                                unsigned* __restrict__ count, unsigned cap) {
   const int x = blockIdx.x * GX + (threadIdx.x & (GX - 1));
   const int y = blockIdx.y * (GT / GX) + threadIdx.x / GX;
@@ -127,10 +133,146 @@ __global__ __launch_bounds__(GT) void corner_candidates_kernel(const float* __re
     }
   if (v != m) return;
   const unsigned pos = atomicAdd(count, 1u);
-  if (pos < cap) {
-    val[pos] = v;
-    idx[pos] = y * W + x;
+  // descending order of the key = descending value, ties: higher address first (positive floats order like their bits)
+  if (pos < cap) keys[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * W + x);
+}
+
+// The greedy rule over the sorted candidates, one workgroup.  Cell grid in global memory: per cell a count and up to
+// GRID_SLOTS accepted corners (x | y << 16); accepted corners are >= minDistance apart, so a cell of that side holds
+// at most four -- more than GRID_SLOTS raises `fault` and the caller falls back to nothing (an error).
+constexpr int GF_T = 512, GF_NB = 24, GRID_SLOTS = 8;
+enum { GF_UNDECIDED = 0, GF_ACCEPTED = 1, GF_REJECTED = 2 };
+
+__global__ __launch_bounds__(GF_T) void greedy_distance_kernel(const unsigned long long* __restrict__ keys, unsigned nc,
+                                                               int W, int cell, int gw, int gh, double md2, int max_corners,
+                                                               unsigned* __restrict__ cell_cnt,
+                                                               unsigned* __restrict__ cell_pts, float* __restrict__ xy,
+                                                               unsigned* __restrict__ ctl /* [2] n_out, [3] fault */) {
+  __shared__ int s_xy[GF_T];
+  __shared__ unsigned char s_state[GF_T];
+  __shared__ unsigned short s_nb[GF_T][GF_NB];
+  __shared__ int s_scan[GF_T];
+  __shared__ int s_open, s_total;
+  const int t = threadIdx.x;
+  int n_acc = 0;
+  const int limit = max_corners > 0 ? max_corners : 0x7fffffff;
+  for (unsigned base = 0; base < nc && n_acc < limit; base += GF_T) {
+    const unsigned k = base + t;
+    const bool valid = k < nc;
+    int x = 0, y = 0, state = GF_REJECTED;
+    if (valid) {
+      const unsigned id = (unsigned)(keys[k] & 0xffffffffull);
+      y = (int)(id / (unsigned)W);
+      x = (int)(id - (unsigned)y * (unsigned)W);
+      state = GF_UNDECIDED;
+      // accepted corners of earlier blocks, through the grid
+      const int cx = x / cell, cy = y / cell;
+      for (int yy = max(0, cy - 1); yy <= min(gh - 1, cy + 1) && state == GF_UNDECIDED; ++yy)
+        for (int xx = max(0, cx - 1); xx <= min(gw - 1, cx + 1) && state == GF_UNDECIDED; ++xx) {
+          // (agent-scope loads: the grid is written by this workgroup's earlier blocks, past the CU's L1)
+          const unsigned c = (unsigned)yy * gw + xx;
+          const unsigned m = min(__hip_atomic_load(&cell_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (unsigned)GRID_SLOTS);
+          for (unsigned j = 0; j < m; ++j) {
+            const unsigned pt = __hip_atomic_load(&cell_pts[c * GRID_SLOTS + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double dx = x - (int)(pt & 0xffffu), dy = y - (int)(pt >> 16);
+            if (dx * dx + dy * dy < md2) state = GF_REJECTED;
+          }
+        }
+    }
+    s_xy[t] = x | (y << 16);
+    s_state[t] = (unsigned char)state;
+    __syncthreads();
+    // earlier candidates of this block within minDistance (rejected ones can be left out: they decide nothing)
+    // (only corners in the 3x3 cells around the candidate count, as in the grid walk above and in OpenCV)
+    const int mcx = x / cell, mcy = y / cell;
+    int nnb = 0;
+    if (state == GF_UNDECIDED) {
+      for (int q = 0; q < t; ++q) {
+        if (s_state[q] == GF_REJECTED) continue;
+        const int pq = s_xy[q];
+        const int qx = pq & 0xffff, qy = pq >> 16;
+        const double dx = x - qx, dy = y - qy;
+        if (dx * dx + dy * dy < md2 && abs(qx / cell - mcx) <= 1 && abs(qy / cell - mcy) <= 1) {
+          if (nnb < GF_NB) s_nb[t][nnb] = (unsigned short)q;
+          ++nnb;
+        }
+      }
+    }
+    __syncthreads();
+    for (;;) {
+      if (t == 0) s_open = 0;
+      __syncthreads();
+      int next = state;
+      if (state == GF_UNDECIDED) {
+        bool any_acc = false, any_und = false;
+        if (nnb <= GF_NB) {
+          for (int j = 0; j < nnb; ++j) {
+            const int st = s_state[s_nb[t][j]];
+            any_acc |= st == GF_ACCEPTED;
+            any_und |= st == GF_UNDECIDED;
+          }
+        } else {                                     // (more neighbours than the list holds: scan the block)
+          for (int q = 0; q < t; ++q) {
+            const int st = s_state[q];
+            if (st == GF_REJECTED) continue;
+            const int pq = s_xy[q];
+            const int qx = pq & 0xffff, qy = pq >> 16;
+            const double dx = x - qx, dy = y - qy;
+            if (dx * dx + dy * dy < md2 && abs(qx / cell - mcx) <= 1 && abs(qy / cell - mcy) <= 1) {
+              any_acc |= st == GF_ACCEPTED;
+              any_und |= st == GF_UNDECIDED;
+            }
+          }
+        }
+        if (any_acc) next = GF_REJECTED;
+        else if (!any_und) next = GF_ACCEPTED;
+        else atomicOr(&s_open, 1);
+      }
+      __syncthreads();                               // all reads of this sweep are done
+      state = next;
+      s_state[t] = (unsigned char)state;
+      __syncthreads();
+      if (s_open == 0) break;
+      __syncthreads();
+    }
+    // rank of the accepted among the accepted (priority order), output, grid insertion
+    const int acc = state == GF_ACCEPTED ? 1 : 0;
+    s_scan[t] = acc;
+    __syncthreads();
+    for (int off = 1; off < GF_T; off <<= 1) {
+      const int add = t >= off ? s_scan[t - off] : 0;
+      __syncthreads();
+      s_scan[t] += add;
+      __syncthreads();
+    }
+    if (t == GF_T - 1) s_total = s_scan[t];
+    const int rank = n_acc + s_scan[t] - acc;
+    if (acc && rank < limit) {
+      xy[2 * rank] = (float)x;
+      xy[2 * rank + 1] = (float)y;
+      const unsigned c = (unsigned)(y / cell) * gw + (x / cell);
+      const unsigned slot = atomicAdd(&cell_cnt[c], 1u);
+      if (slot < (unsigned)GRID_SLOTS)
+        __hip_atomic_store(&cell_pts[c * GRID_SLOTS + slot], (unsigned)x | ((unsigned)y << 16), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      else ctl[3] = 1u;
+    }
+    __threadfence();
+    __syncthreads();
+    n_acc = min(n_acc + s_total, limit);
+    __syncthreads();
   }
+  if (t == 0) ctl[2] = (unsigned)n_acc;
+}
+
+// minDistance < 1: the first max_corners of the sorted list
+__global__ __launch_bounds__(256) void take_sorted_kernel(const unsigned long long* __restrict__ keys, unsigned n, int W,
+                                                          float* __restrict__ xy) {
+  const unsigned k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const unsigned id = (unsigned)(keys[k] & 0xffffffffull);
+  xy[2 * k] = (float)(id % (unsigned)W);
+  xy[2 * k + 1] = (float)(id / (unsigned)W);
 }
 
 }  // namespace
@@ -173,17 +315,30 @@ int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_
   hipStream_t st = ctx->stream;
   vo_buf* s = ctx->scratch;
   const unsigned cap = (unsigned)((px + 3) / 4 + 64);             // 3x3 maxima: at most one per 2x2 block
+  VO_REQUIRE(ctx, W < 65536 && H < 65536, "good_features: image side must be below 65536");
+  const int cell = std::max(1, (int)std::lround(min_dist));
+  const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+  const size_t cells = (size_t)gw * gh;
+  const size_t out_cap = max_corners > 0 ? (size_t)max_corners : (size_t)cap;
+  size_t sort_tmp = 0;
+  VO_HIP_TRY(ctx, rocprim::radix_sort_keys_desc(nullptr, sort_tmp, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                (size_t)cap, 0, 64, st));
   VO_TRY(vo_ensure(ctx, ctx->img, px));
   VO_TRY(vo_ensure(ctx, s[0], px * 4));
   VO_TRY(vo_ensure(ctx, s[1], 16));
-  VO_TRY(vo_ensure(ctx, s[2], (size_t)cap * 4));
-  VO_TRY(vo_ensure(ctx, s[3], (size_t)cap * 4));
+  VO_TRY(vo_ensure(ctx, s[2], (size_t)cap * 8));
+  VO_TRY(vo_ensure(ctx, s[3], (size_t)cap * 8));
+  VO_TRY(vo_ensure(ctx, s[4], sort_tmp + 256));
+  VO_TRY(vo_ensure(ctx, s[5], cells * 4));
+  VO_TRY(vo_ensure(ctx, s[6], cells * GRID_SLOTS * 4));
+  VO_TRY(vo_ensure(ctx, s[7], out_cap * 8));
   if (mask) VO_TRY(vo_ensure(ctx, ctx->img2, px));
   VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, img, px, hipMemcpyHostToDevice, st));
   if (mask) VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img2.p, mask, px, hipMemcpyHostToDevice, st));
   VO_HIP_TRY(ctx, hipMemsetAsync(s[1].p, 0, 16, st));
+  VO_HIP_TRY(ctx, hipMemsetAsync(s[5].p, 0, cells * 4, st));
   const uint8_t* d_mask = mask ? (const uint8_t*)ctx->img2.p : nullptr;
-  unsigned* d_ctl = (unsigned*)s[1].p;                            // [0] max key, [1] candidate count
+  unsigned* d_ctl = (unsigned*)s[1].p;                            // [0] max key, [1] candidate count, [2] corners, [3] fault
   const double scale = 1.0 / (4.0 * block * 255.0);
   const int RW = GX + block - 1, RH = GY + block - 1;
   const size_t lds = ((size_t)RW * RH + (size_t)3 * RH * GX) * 4;
@@ -191,57 +346,33 @@ int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_
                      H, W, block, (float)(scale * scale), d_mask, (float*)s[0].p, d_ctl);
   VO_TRY(vo_check_launch(ctx, "min_eig_kernel"));
   hipLaunchKernelGGL(corner_candidates_kernel, dim3(vo_cdiv(W, GX), vo_cdiv(H, GT / GX)), dim3(GT), 0, st,
-                     (const float*)s[0].p, H, W, d_mask, d_ctl, quality, (float*)s[2].p, (int*)s[3].p, d_ctl + 1, cap);
+                     (const float*)s[0].p, H, W, d_mask, d_ctl, quality, (unsigned long long*)s[2].p, d_ctl + 1, cap);
   VO_TRY(vo_check_launch(ctx, "corner_candidates_kernel"));
-  unsigned ctl[2] = {0, 0};
+  unsigned ctl[4] = {0, 0, 0, 0};
   VO_HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, 8, hipMemcpyDeviceToHost, st));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(st));                      // (the sort is sized by the candidate count)
   const unsigned nc = std::min(ctl[1], cap);
   if (nc == 0) return VO_OK;
-  std::vector<float> val(nc);
-  std::vector<int> idx(nc);
-  VO_HIP_TRY(ctx, hipMemcpy(val.data(), s[2].p, (size_t)nc * 4, hipMemcpyDeviceToHost));
-  VO_HIP_TRY(ctx, hipMemcpy(idx.data(), s[3].p, (size_t)nc * 4, hipMemcpyDeviceToHost));
-  std::vector<unsigned> order(nc);
-  for (unsigned i = 0; i < nc; ++i) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) {
-    if (val[a] != val[b]) return val[a] > val[b];
-    return idx[a] > idx[b];                                       // ties: higher address first
-  });
-  // greedy minimum distance with a cell grid (cell side = minDistance)
+  unsigned long long* d_sorted = (unsigned long long*)s[3].p;
+  VO_HIP_TRY(ctx, rocprim::radix_sort_keys_desc(s[4].p, sort_tmp, (unsigned long long*)s[2].p, d_sorted, (size_t)nc, 0, 64, st));
+  float* d_xy = (float*)s[7].p;
   int n = 0;
   if (min_dist >= 1) {
-    const int cell = std::max(1, (int)std::lround(min_dist));
-    const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
-    std::vector<std::vector<int>> grid((size_t)gw * gh);
-    const double md2 = min_dist * min_dist;
-    for (unsigned k = 0; k < nc && (max_corners <= 0 || n < max_corners); ++k) {
-      const int id = idx[order[k]], y = id / W, x = id % W;
-      const int cx = x / cell, cy = y / cell;
-      bool ok = true;
-      for (int yy = std::max(0, cy - 1); ok && yy <= std::min(gh - 1, cy + 1); ++yy)
-        for (int xx = std::max(0, cx - 1); ok && xx <= std::min(gw - 1, cx + 1); ++xx)
-          for (int j : grid[(size_t)yy * gw + xx]) {
-            const double dx = x - xy[2 * j], dy = y - xy[2 * j + 1];
-            if (dx * dx + dy * dy < md2) {
-              ok = false;
-              break;
-            }
-          }
-      if (ok) {
-        grid[(size_t)cy * gw + cx].push_back(n);
-        xy[2 * n] = (float)x;
-        xy[2 * n + 1] = (float)y;
-        ++n;
-      }
-    }
+    hipLaunchKernelGGL(greedy_distance_kernel, dim3(1), dim3(GF_T), 0, st, d_sorted, nc, W, cell, gw, gh,
+                       min_dist * min_dist, max_corners, (unsigned*)s[5].p, (unsigned*)s[6].p, d_xy, d_ctl);
+    VO_TRY(vo_check_launch(ctx, "greedy_distance_kernel"));
+    VO_HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, 16, hipMemcpyDeviceToHost, st));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctl[3]) return vo_set_error(ctx, VO_ECAPACITY, "good_features: more than %d corners in one grid cell", GRID_SLOTS);
+    n = (int)ctl[2];
   } else {
-    for (unsigned k = 0; k < nc && (max_corners <= 0 || n < max_corners); ++k) {
-      const int id = idx[order[k]];
-      xy[2 * n] = (float)(id % W);
-      xy[2 * n + 1] = (float)(id / W);
-      ++n;
-    }
+    n = (int)(max_corners > 0 ? std::min<unsigned>(nc, (unsigned)max_corners) : nc);
+    hipLaunchKernelGGL(take_sorted_kernel, dim3(vo_cdiv(n, 256)), dim3(256), 0, st, d_sorted, (unsigned)n, W, d_xy);
+    VO_TRY(vo_check_launch(ctx, "take_sorted_kernel"));
+  }
+  if (n > 0) {
+    VO_HIP_TRY(ctx, hipMemcpyAsync(xy, d_xy, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   }
   *n_out = n;
   return VO_OK;
