@@ -7,8 +7,10 @@
 
 One "step" = one frame of the reference's steady-state loop (src/main.py:248-286, KLT tracker mode with the
 Harris detector) on a 1376x1241 frame that is already resident in HBM, everything on the GPU:
-  pyramid(next) | Harris response + exact greedy NMS (2000 keypoints) on next | re-detect append when fewer than
-  80 % of the tracks survive -> KLT (3 levels, 15x15) of every feature -> Matches regroup -> P3P-RANSAC (1000
+  pyramid(next) | Harris response + exact greedy NMS (2000 keypoints) on next, for a sequence whose track count is
+  within 10 % of the re-detect limit (the reference runs its detector only below the limit, klt.py:207-230;
+  VO_BENCH_DETECT_MARGIN=-1: on every frame) | re-detect append when fewer than 80 % of the tracks survive -> KLT
+  (3 levels, 15x15) of every feature -> Matches regroup -> P3P-RANSAC (1000
   hypotheses solved + scored, reference-exact sampler, sequential accept rule replayed on the device) -> pose
   refinement over the inliers -> State bookkeeping (reset_outliers, bearing-angle candidates) -> DLT of the
   candidates with one start pose per track -> landmark insertion + cheirality check.
@@ -38,10 +40,14 @@ for p in (ROOT, os.path.join(ROOT, "visual-odometry-project_amd")):
 import numpy as np  # noqa: E402
 
 H, W, N_KP, HYP, WIN, MAX_LEVEL = 1241, 1376, 2000, 1000, 15, 2
+CONFIG = os.environ.get("VO_BENCH_CONFIG", "cfg2")
+if CONFIG == "cfg5":     # BASELINE.json configs[4]: the stress shape (secondary line under profiles/, the default stays cfg-2)
+    H, W, N_KP, HYP, MAX_LEVEL = 2160, 3840, 8000, 4000, 3
 N_FRAMES = 8
 REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
 EXCHANGE_EVERY = int(os.environ.get("VO_BENCH_EXCHANGE_EVERY", "16"))   # frames per all-gather of {pose, landmarks} records
 REDETECT_POSE = os.environ.get("VO_BENCH_REDETECT_POSE", "current")   # see vo_pipeline_config.redetect_start_pose
+DETECT_MARGIN = float(os.environ.get("VO_BENCH_DETECT_MARGIN", "0.1"))   # see vo_pipeline_config.detect_margin (< 0: every frame)
 PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 PROFILE_TAG = "r02"
@@ -189,7 +195,7 @@ def oracle_leg(stream, state, gpu_results, gpu_state, frames):
               "note": "refined pose / landmarks vs the CPU oracle of the same loop on the same frames (tolerance of the "
                       "metric: 1e-4 rel.); integer and index results must be identical"}
     base = {"value": frames / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same 1376x1241 stream through the CPU oracle of the loop (tests/pipeline_oracle.py: "
+            "sample": "%d frames of the same stream through the CPU oracle of the loop (tests/pipeline_oracle.py: "
                       "C KLT / P3P, NumPy RANSAC / refinement / DLT / bookkeeping) plus NumPy Harris + the oracle's fast "
                       "exact NMS walk per frame, single thread" % frames}
     return parity, base
@@ -313,7 +319,7 @@ def main():
     ap.add_argument("--exchange", action="store_true",
                     help="run the all-gather of {pose, landmarks} records even on one GPU (always on for --gpus > 1)")
     args = ap.parse_args()
-    if os.environ.get("VO_BENCH_CONFIG", "cfg2") == "cfg3":
+    if CONFIG == "cfg3":
         if args.steps == 2000:
             args.steps, args.warmup = 60, 5
         return cfg3_main(args)
@@ -353,7 +359,8 @@ def main():
     stream = streams[0]
     pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
                             hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
-                            refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, sequences=S)
+                            refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, sequences=S,
+                            detect_margin=DETECT_MARGIN)
     states = [bootstrap_state(st) for st in streams]
     state = states[0]
     for q in range(S):
@@ -513,7 +520,8 @@ def main():
                  "record_to_next_regroup_percentiles_10_50_90_99": [float(v) for v in np.percentile(ts[1:, 1] - ts[:-1, 5], [10, 50, 90, 99])],
                  "unit": "us, medians over the timed steps, from wall_clock64() stamps of each kernel's first work item"}
         out = {
-            "metric": "VO frames/sec at 1376x1241, 2k keypoints; pose err vs reference",
+            "metric": "VO frames/sec at 1376x1241, 2k keypoints; pose err vs reference" if CONFIG != "cfg5" else
+                      "VO frames/sec at 3840x2160, 8k keypoints (stress configuration)",
             "value": round(world * S * args.steps / dt_max, 2),
             "unit": "frames/s",
             "n_gpus": world,
@@ -525,14 +533,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "cfg-2: 1376x1241 KITTI-shaped synthetic stream, per frame: Harris+NMS 2000 kp, re-detect "
-                                   "append, KLT 3-level 15x15 of all tracks, Matches regroup, P3P-RANSAC 1000 hyps + device "
+            "config": {"workload": "%s: %dx%d KITTI-shaped synthetic stream, per frame: Harris+NMS %d kp (see detector), re-detect "
+                                   "append, KLT %d-level 15x15 of all tracks, Matches regroup, P3P-RANSAC %d hyps + device "
                                    "replay of the sequential rule, pose refinement, State bookkeeping, per-track-pose "
-                                   "candidate DLT, cheirality; one independent sequence per GPU",
+                                   "candidate DLT, cheirality; %d independent sequence(s) per GPU"
+                                   % ("cfg-5" if CONFIG == "cfg5" else "cfg-2", W, H, N_KP, MAX_LEVEL + 1, HYP, S),
                        "step_contains": "all of the above, device-resident (Features/State/RANSAC never leave HBM); "
                                         "landmarks are the loop's own triangulations after a host two-view bootstrap",
                        "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP, "sequences_per_gpu": S,
                        "frame_lookahead": 1 if args.lookahead else 0, "redetect_start_pose": REDETECT_POSE,
+                       "detector": ("Harris + NMS on every frame" if DETECT_MARGIN < 0 else
+                                    "Harris + NMS launched every frame, executed for a sequence whose track count is below "
+                                    "%.2f x num_features (re-detect limit 0.80, as klt.py:207-230; a sequence that falls "
+                                    "through the margin in one frame is finished by the host path)" % (0.8 + DETECT_MARGIN)),
                        "rccl_world_size": dist.get_world_size() if exchange else 1,
                        "parallelism": "sequence-sharded x%d%s%s" % (world, ", %d sequences per GPU per launch" % S if S > 1 else "", ", RCCL all-gather of the {pose, landmarks} records of %d frames every %d frames" % (EXCHANGE_EVERY, EXCHANGE_EVERY) if exchange else "")},
             "roofline": roof,

@@ -158,14 +158,19 @@ def test_pipeline_lookahead_and_host_recovery_match_blocking_steps(ctx):
 
     ref, st_ref, g_ref = run(False)
     assert all(r.recovered == 0 for r in ref)
-    for la, kw in ((True, {}), (False, dict(debug_fault_every=3)), (True, dict(debug_fault_every=3))):
+    # detect_margin: < 0 = the detector runs on every frame; tiny = it runs only once the count is AT the re-detect
+    # limit, so the step that crosses the limit finds no keypoints and is finished through the host path
+    for la, kw in ((True, {}), (False, dict(debug_fault_every=3)), (True, dict(debug_fault_every=3)),
+                   (True, dict(detect_margin=-1.0)), (False, dict(detect_margin=1e-6)), (True, dict(detect_margin=1e-6))):
         got, st, g = run(la, **kw)
         for k, (a, b) in enumerate(zip(got, ref)):
             fa, fb = fields(a), fields(b)
             assert fa == fb, (la, kw, "step", k, "recovered", a.recovered,
                               [(i, fa[i], fb[i]) for i in range(len(fa)) if fa[i] != fb[i]][:3])
-        if kw:
+        if "debug_fault_every" in kw:
             assert sum(r.recovered for r in got) == len(pairs) // 3
+        if kw.get("detect_margin", 0) > 0:
+            assert any(r.redetected and r.recovered for r in got), "the skipped-detection path was meant to run"
         assert g == g_ref
         for k in ("keypoints", "state", "candidate_mask", "landmarks", "tracks", "poses", "curr_pose"):
             assert np.array_equal(st[k], st_ref[k], equal_nan=True), k

@@ -69,8 +69,10 @@ __host__ __device__ inline resp_geom response_geometry(int p) {
 template <int P_T>
 __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __restrict__ img, int H, int W,
                                                              int p_arg, double kappa,
-                                                             double* __restrict__ out, size_t img_stride) {
+                                                             double* __restrict__ out, size_t img_stride,
+                                                             const int* __restrict__ go) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (go && !go[blockIdx.z]) return;                 // this sequence's detection is not needed for this frame
   img += (size_t)blockIdx.z * img_stride;            // several sequences per launch: grid.z = sequence
   out += (size_t)blockIdx.z * ((size_t)H * W);
   const int p = P_T > 0 ? P_T : p_arg;
@@ -341,6 +343,7 @@ struct nms_batch {
   size_t alive = 0;     // state map
   size_t hist = 0;      // one histogram
   size_t rank = 0, sel = 0, kp = 0;
+  const int* go = nullptr;   // one word per sequence; 0: the sequence sits this call out (every kernel returns at once)
 };
 
 constexpr int HIST_SHIFT = 47;           // 65536 bins over non-negative doubles
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
                                                             uint4* __restrict__ seg_cnt,
                                                             unsigned* __restrict__ hist, nms_ctl* ctl, nms_batch B) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (B.go && !B.go[blockIdx.z]) return;
   {
     const size_t q = blockIdx.z;
     sc += q * B.sc;
@@ -676,6 +680,7 @@ __global__ __launch_bounds__(NT) void nms_compact_kernel(const unsigned long lon
   const uint4 cnt = seg_cnt[blk];
   const int tid = threadIdx.x;
   for (unsigned i = blk * NT + tid; i < (unsigned)HIST_TOTAL; i += gridDim.x * NT) hist_other[i] = 0;
+  if (B.go && !B.go[blockIdx.y]) return;      // (a sequence that sits the call out still keeps the histogram rotation)
   // the tile's segment entries are requested before the bound is computed (its two dependent
   // histogram reads then overlap these loads instead of preceding one round trip per chunk)
   constexpr int CH = SEG / NT;
@@ -772,6 +777,7 @@ __global__ __launch_bounds__(RT) void nms_round_kernel(const double* __restrict_
                                                        unsigned* __restrict__ idx_c, nms_ctl* ctl, unsigned cap_c,
                                                        int H, int W, int r_arg, int tiles_x, nms_batch B) {
   extern __shared__ __align__(16) unsigned s_dyn[];
+  if (B.go && !B.go[blockIdx.y]) return;
   {
     const size_t q = blockIdx.y;
     sc += q * B.sc;
@@ -1045,6 +1051,7 @@ __global__ __launch_bounds__(NT) void nms_rank_kernel(const unsigned long long* 
                                                       const uint4* __restrict__ seg_cnt,
                                                       const unsigned* __restrict__ seg_cand, unsigned nblk,
                                                       nms_batch B) {
+  if (B.go && !B.go[blockIdx.y]) return;
   {
     const size_t q = blockIdx.y;
     keys_c += q * B.comp;
@@ -1145,6 +1152,7 @@ __global__ __launch_bounds__(SEL_T) void nms_finalize_kernel(unsigned long long*
                                                              unsigned* __restrict__ sel,
                                                              double* __restrict__ kp_xy,
                                                              float* __restrict__ kp_f32, nms_batch B) {
+  if (B.go && !B.go[blockIdx.y]) return;
   {
     const size_t q = blockIdx.y;
     keys_c += q * B.comp;
@@ -1417,7 +1425,7 @@ int vo_harris_response_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int 
 
 // S images (d_img + s * img_stride) -> S score maps (d_scores + s * H * W), one launch (grid.z = sequence)
 int vo_harris_response_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_stride, int S, int H, int W, int patch,
-                                 double kappa, double* d_scores) {
+                                 double kappa, double* d_scores, const int* d_go) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, S >= 1 && S <= 65535, "harris_response: bad sequence count");
   VO_REQUIRE(ctx, d_img && d_scores, "harris_response: null pointer");
@@ -1436,10 +1444,10 @@ int vo_harris_response_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_s
     vo_prof_scope ps(ctx, VO_K_HARRIS_RESPONSE);
     if (patch == 9)
       hipLaunchKernelGGL(harris_response_kernel<9>, grid, dim3(NT), lds, ctx->stream, d_img, H, W, patch, kappa,
-                         d_scores, img_stride);
+                         d_scores, img_stride, d_go);
     else
       hipLaunchKernelGGL(harris_response_kernel<0>, grid, dim3(NT), lds, ctx->stream, d_img, H, W, patch, kappa,
-                         d_scores, img_stride);
+                         d_scores, img_stride, d_go);
   }
   return vo_check_launch(ctx, "harris_response_kernel");
 }
@@ -1455,7 +1463,7 @@ int vo_nms_keypoints_dev(vo_ctx* ctx, const double* d_scores, int H, int W, int 
 // S score maps (d_scores + s * H * W) -> S keypoint lists (d_kp_xy + s * kp_stride doubles; the float copies, when
 // ctx->nms_kp_f32 is set, at the same element stride), every kernel of the chain launched once for all sequences
 int vo_nms_keypoints_batch_dev(vo_ctx* ctx, const double* d_scores, int S, int H, int W, int N, int r, double* d_kp_xy,
-                               size_t kp_stride) {
+                               size_t kp_stride, const int* d_go) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, S >= 1 && S <= 65535, "nms: bad sequence count");
   VO_REQUIRE(ctx, d_scores && d_kp_xy, "nms: null pointer");
@@ -1506,6 +1514,7 @@ int vo_nms_keypoints_batch_dev(vo_ctx* ctx, const double* d_scores, int S, int H
     B.sel = MAX_N;
     B.kp = kp_stride;
   }
+  B.go = d_go;
   nms_ctl* ctl = (nms_ctl*)ctx->nms_ctl.p;   // its counters are reset by the threshold kernel
 
   unsigned long long* keys_l1 = (unsigned long long*)ctx->nms_keys_l1.p;

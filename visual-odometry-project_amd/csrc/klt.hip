@@ -515,6 +515,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
       src.num_features = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(src.num_features) + q * B.ctl);
       src.det_kp += q * B.det;
       if (src.ts) src.ts = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(src.ts) + q * B.ctl);
+      if (src.det_go) src.det_go += q;
     }
   }
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
   if (src.ts && blockIdx.x == 0 && threadIdx.x == 0) *src.ts = wall_clock64();
   if (src.n) {
     n_own = *src.n;
-    const bool redetect = (double)n_own < (double)*src.num_features * src.frac;
+    const bool redetect = (double)n_own < (double)*src.num_features * src.frac && (!src.det_go || *src.det_go != 0);
     N = min(N, n_own + (redetect ? src.n_det : 0));
   }
   if (i >= N) return;                                  // whole wave leaves together
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
       src.num_features = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(src.num_features) + q * B.ctl);
       src.det_kp += q * B.det;
       if (src.ts) src.ts = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(src.ts) + q * B.ctl);
+      if (src.det_go) src.det_go += q;
     }
   }
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   if (src.ts && blockIdx.x == 0 && threadIdx.x == 0) *src.ts = wall_clock64();
   if (src.n) {
     n_own = *src.n;
-    const bool redetect = (double)n_own < (double)*src.num_features * src.frac;
+    const bool redetect = (double)n_own < (double)*src.num_features * src.frac && (!src.det_go || *src.det_go != 0);
     N = min(N, n_own + (redetect ? src.n_det : 0));
   }
   if (i >= N) return;                                  // all lanes of a keypoint leave together

@@ -5,7 +5,11 @@
 // Streams of one step (frame k-1 -> k):
 //   main   : regroup -> hypotheses+counts -> replay+refine+candidates -> landmarks+record
 //   tracker: pyramid(k) -> KLT(k)           needs regroup(k-1) only: runs beside the pose estimation of step k-1
-//   detect : Harris response + NMS on k     (enqueued by a worker thread; consumed by the NEXT step's re-detect)
+//   detect : Harris response + NMS on k     (enqueued by a worker thread; consumed by the NEXT step's re-detect.
+//            The reference runs its detector only when fewer than 80 % of the tracks are left, klt.py:207-230; whether
+//            that will be so for frame k is known one step too late for a launch without a host turn, so the chain is
+//            launched for every frame and each sequence sits it out unless its track count is within `detect_margin`
+//            of the limit.  A sequence that falls through the margin in one frame finds no keypoints: fault, host path.)
 // Nothing on the main stream waits for the host: counts, the generator position, the accepted pose and
 // the inlier mask are words in HBM that the next kernel reads.  The host only enqueues (at most two
 // steps ahead: frame buffers rotate over three slots) and reads each step's result record from mapped
@@ -44,6 +48,8 @@ struct vo_pipeline {
   uint8_t* d_pyr = nullptr;          // [S][3][pyr_bytes]      (frame count mod 3)
   double* d_kp = nullptr;            // [S][3][N * 2]          detector output per frame slot
   double* d_scores[2] = {nullptr, nullptr};   // [S][px] each, alternating between consecutive detections
+  int* d_det_go = nullptr;           // [3][S]: 1 = the detector ran for that sequence on the frame in keypoint slot s
+  double detect_limit = 0.0;         // detect when n < detect_limit * num_features (< 0: always)
   hipEvent_t evPyr[3] = {nullptr, nullptr, nullptr}, evDet[3] = {nullptr, nullptr, nullptr};
   int slot = 0, det_flip = 0, prev_frame = -1;
   // Features double buffer: a step reads F[cur] (frame k-1) and writes F[1 - cur] (frame k)
@@ -121,6 +127,15 @@ __global__ __launch_bounds__(256) void export_state_kernel(pose17 head, const do
   if (i < 17) rec[i] = head.v[i];
   const int m = min(n, cap) * 3;
   if (i < m) rec[17 + i] = land[i];
+}
+
+// does sequence q need the detector on the frame being submitted?  (the count is the one of the frame before, or
+// already this frame's when the step's regroup has run: either is within one frame of the count that decides)
+__global__ __launch_bounds__(64) void detect_decide_kernel(const vo_seq_ctl* __restrict__ ctl, int S, double limit, int force,
+                                                           int* __restrict__ go) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= S) return;
+  go[q] = (force || limit < 0.0 || (double)ctl[q].n2 < (double)ctl[q].num_features * limit) ? 1 : 0;
 }
 
 template <typename T>
@@ -224,7 +239,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   (void)hipStreamSynchronize(p->ctx->stream);
   for (vo_ctx* q : {p->det, p->trk})
     if (q) (void)hipStreamSynchronize(q->stream);
-  void* dev[] = {p->d_img, p->d_pyr, p->d_kp, p->d_scores[0], p->d_scores[1], p->feat_mem, p->d_ctl, p->d_next, p->d_err,
+  void* dev[] = {p->d_det_go, p->d_img, p->d_pyr, p->d_kp, p->d_scores[0], p->d_scores[1], p->feat_mem, p->d_ctl, p->d_next, p->d_err,
                  p->d_status, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_samples, p->d_masks, p->d_best_mask, p->d_table,
                  p->d_raws, p->d_newkp, p->d_pairs};
   for (void* q : dev)
@@ -269,6 +284,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   const int S = p->S;
   if (p->cfg.bearing_threshold == 0.0) p->cfg.bearing_threshold = 0.0075;    // state.py:8
   if (p->cfg.redetect_fraction == 0.0) p->cfg.redetect_fraction = 0.8;       // klt.py:212
+  if (p->cfg.detect_margin == 0.0) p->cfg.detect_margin = 0.1;
+  p->detect_limit = p->cfg.detect_margin < 0.0 ? -1.0 : p->cfg.redetect_fraction + p->cfg.detect_margin;
   memcpy(p->cam.K, cfg->K, sizeof(p->cam.K));
   {
     bool given = false;
@@ -300,6 +317,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_kp, Sz * 3 * N * 2));
   PA(dev_alloc(ctx, &p->d_scores[0], Sz * px));
   PA(dev_alloc(ctx, &p->d_scores[1], Sz * px));
+  PA(dev_alloc(ctx, &p->d_det_go, 3 * Sz));
   {
     const size_t fb = feat_bytes(cap, S);
     char* mem = nullptr;
@@ -432,16 +450,22 @@ int vo_pipeline_get_rng(vo_pipeline* p, vo_pcg64* rng) { return vo_pipeline_get_
 // ---- launches; (q0, Sn): sequences q0 .. q0 + Sn - 1 (all of them, or one when a step is redone) ----
 
 // Harris + NMS of frame slot `frame` into keypoint slot `s` on the detection stream; evDet[s] when done
-static int enqueue_detection(vo_pipeline* p, int frame, int s) {
+static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force) {
   const vo_pipeline_config& c = p->cfg;
   p->det_flip ^= 1;
   vo_ctx* det = p->det;
   double* scores = p->d_scores[p->det_flip];
   det->nms_kp_f32 = nullptr;
-  int rc = vo_harris_response_batch_dev(det, p->img(0, frame), p->img_stride(), p->S, c.H, c.W, c.harris_patch,
-                                        c.harris_kappa, scores);
+  int* go = p->d_det_go + (size_t)s * p->S;
+  hipLaunchKernelGGL(detect_decide_kernel, dim3(vo_cdiv(p->S, 64)), dim3(64), 0, det->stream, p->d_ctl, p->S, p->detect_limit,
+                     force ? 1 : 0, go);
+  int rc = vo_check_launch(det, "detect_decide_kernel");
   if (rc == VO_OK)
-    rc = vo_nms_keypoints_batch_dev(det, scores, p->S, c.H, c.W, c.n_keypoints, c.nms_radius, p->kp(0, s), p->det_stride());
+    rc = vo_harris_response_batch_dev(det, p->img(0, frame), p->img_stride(), p->S, c.H, c.W, c.harris_patch, c.harris_kappa,
+                                      scores, go);
+  if (rc == VO_OK)
+    rc = vo_nms_keypoints_batch_dev(det, scores, p->S, c.H, c.W, c.n_keypoints, c.nms_radius, p->kp(0, s), p->det_stride(),
+                                    go);
   if (rc == VO_OK && hipEventRecord(p->evDet[s], det->stream) != hipSuccess) rc = VO_EHIP;
   if (rc != VO_OK) return vo_set_error(p->ctx, rc, "detection: %s", vo_last_error(det));
   return VO_OK;
@@ -523,6 +547,7 @@ static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool 
   src.det_kp = p->kp(q0, f.a);
   src.n_det = c.n_keypoints;
   src.ts = &ctl->ts[0];
+  src.det_go = p->d_det_go + (size_t)f.a * p->S + q0;
   vo_klt_batch kb;
   kb.S = Sn;
   kb.pyr = p->pyr_stride();
@@ -559,6 +584,7 @@ static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fi
   ap.frac = c.redetect_fraction;
   ap.pose_mode = c.redetect_start_pose;
   ap.debug_fault_every = debug_fault_every;
+  ap.det_go = p->d_det_go + (size_t)f.a * p->S + q0;
   VO_TRY(vo_state_regroup_klt(ctx, ctl, A, B, p->d_next + q * p->cap * 2, p->d_status + q * p->cap, p->d_err + q * p->cap,
                               (float)c.klt_err_threshold, ap, p->cap, Sn));
   VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], ctx->stream));
@@ -593,7 +619,7 @@ static void worker_main(vo_pipeline* p) {
     }
     idle = 0;
     const vo_pipeline::flight_t j = p->jobs[seen & 3];
-    const int rc = enqueue_detection(p, j.next_idx, j.b);
+    const int rc = enqueue_detection(p, j.next_idx, j.b, false);
     if (rc != VO_OK) p->worker_rc = rc;
     ++seen;
     p->job_done.store(seen, std::memory_order_release);
@@ -697,8 +723,8 @@ static int prime(vo_pipeline* p) {
   vo_ctx* ctx = p->ctx;
   VO_TRY(worker_idle(p));
   sync_prof(p);
-  VO_TRY(enqueue_pyramid(p, p->prev_frame, 0));
-  VO_TRY(enqueue_detection(p, p->prev_frame, 0));
+  VO_TRY(enqueue_pyramid(p, p->prev_frame, p->slot));
+  VO_TRY(enqueue_detection(p, p->prev_frame, p->slot, true));
   VO_HIP_TRY(ctx, hipStreamSynchronize(p->trk->stream));
   VO_HIP_TRY(ctx, hipStreamSynchronize(p->det->stream));
   p->primed = true;
@@ -766,6 +792,14 @@ int vo_pipeline_get_detection(vo_pipeline* p, double* kp_xy) {
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (p->have_state && !p->primed) VO_TRY(prime(p));
   VO_HIP_TRY(ctx, hipEventSynchronize(p->evDet[p->slot]));
+  {
+    int ran = 0;
+    VO_HIP_TRY(ctx, mcpy(ctx->stream, &ran, p->d_det_go + (size_t)p->slot * p->S, 4, hipMemcpyDeviceToHost));
+    if (!ran) {                          // the frame's detection was skipped: made now (all sequences)
+      VO_TRY(enqueue_detection(p, p->prev_frame, p->slot, true));
+      VO_HIP_TRY(ctx, hipStreamSynchronize(p->det->stream));
+    }
+  }
   VO_HIP_TRY(ctx, mcpy(ctx->stream, kp_xy, p->kp(0, p->slot), (size_t)p->cfg.n_keypoints * 16, hipMemcpyDeviceToHost));
   return VO_OK;
 }
@@ -869,6 +903,19 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
                         c.n_keypoints, p->cap);
   const int zero = 0;
   VO_HIP_TRY(ctx, mcpy(st, &ctl->fault, &zero, 4, hipMemcpyHostToDevice));
+  if (h.fault & VO_FAULT_NO_DETECTION) {
+    // the tracks fell through the detection margin within one frame: the detector's keypoints of `prev` are made now
+    vo_ctx* det = p->det;
+    VO_HIP_TRY(ctx, hipStreamSynchronize(det->stream));
+    double* scores = p->d_scores[p->det_flip] + (size_t)q * p->px;
+    det->nms_kp_f32 = nullptr;
+    int rc = vo_harris_response_batch_dev(det, p->img(q, f.prev_idx), 0, 1, c.H, c.W, c.harris_patch, c.harris_kappa, scores);
+    if (rc == VO_OK) rc = vo_nms_keypoints_batch_dev(det, scores, 1, c.H, c.W, c.n_keypoints, c.nms_radius, p->kp(q, f.a), 0);
+    if (rc != VO_OK) return vo_set_error(ctx, rc, "detection: %s", vo_last_error(det));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(det->stream));
+    const int one = 1;
+    VO_HIP_TRY(ctx, mcpy(st, p->d_det_go + (size_t)f.a * p->S + q, &one, 4, hipMemcpyHostToDevice));
+  }
   VO_TRY(enqueue_tracker(p, f, false, q, 1));
   VO_TRY(enqueue_chain(p, f, true, 0, q, 1, 0u));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
   // `length < self._num_features * 0.8` (klt.py:208-212)
   const bool redetect = !fault && (double)n < (double)ctl->num_features * ap.frac;
   if (redetect && n + ap.n_det > cap) fault |= VO_FAULT_CAPACITY;
+  if (redetect && ap.det_go && !ap.det_go[blockIdx.y]) fault |= VO_FAULT_NO_DETECTION;
   if (fault) {
     if (blockIdx.x == 0 && tid == 0) {
       ctl->fault = fault;

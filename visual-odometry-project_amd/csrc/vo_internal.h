@@ -133,6 +133,7 @@ struct vo_klt_source {
   const double* det_kp = nullptr;
   int n_det = 0;
   unsigned long long* ts = nullptr;   // (optional) receives wall_clock64() when the kernel's first work item starts
+  const int* det_go = nullptr;        // (optional, one int per sequence) 0: det_kp was not produced, nothing is appended
 };
 // several sequences per launch (grid.y = sequence): element strides from one sequence's block to the next
 struct vo_klt_batch {
@@ -152,7 +153,8 @@ int vo_pyramid_build_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_str
                                uint8_t* d_pyr, size_t pyr_stride);
 // Several sequences per launch (harris.hip): S images at d_img + s * img_stride -> S score maps at d_scores + s * H * W;
 // S score maps -> S keypoint lists at d_kp_xy + s * kp_stride (doubles).  S = 1 is what the C ABI's _dev forms call.
+// d_go (optional, S ints on the device): sequences whose word is 0 are skipped by every kernel of the chain
 int vo_harris_response_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_stride, int S, int H, int W, int patch,
-                                 double kappa, double* d_scores);
+                                 double kappa, double* d_scores, const int* d_go = nullptr);
 int vo_nms_keypoints_batch_dev(vo_ctx* ctx, const double* d_scores, int S, int H, int W, int N, int r, double* d_kp_xy,
-                               size_t kp_stride);
+                               size_t kp_stride, const int* d_go = nullptr);

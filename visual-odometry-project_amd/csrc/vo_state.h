@@ -42,7 +42,8 @@ enum {
   VO_FAULT_RISKY_DRAW = 2,      // a bounded draw inside the consumed prefix could have been rejected by NumPy
   VO_FAULT_UNFINISHED = 4,      // the sequential rule is not done after `hyp` samples
   VO_FAULT_CAPACITY = 8,        // appending the detector's keypoints would exceed the feature capacity
-  VO_FAULT_FORCED = 16          // test hook (vo_pipeline_config.debug_fault_every)
+  VO_FAULT_FORCED = 16,         // test hook (vo_pipeline_config.debug_fault_every)
+  VO_FAULT_NO_DETECTION = 32    // the tracks fell below the re-detect limit on a frame whose detection was skipped
 };
 
 struct vo_seq_ctl {
@@ -87,6 +88,7 @@ struct vo_append {
   double frac;
   int pose_mode;            // vo_pipeline_config.redetect_start_pose
   int debug_fault_every;
+  const int* det_go;        // per sequence: 1 = the detector ran on the frame det_kp belongs to (NULL: it always does)
 };
 
 struct vo_replay_args {

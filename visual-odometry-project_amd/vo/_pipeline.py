@@ -28,7 +28,8 @@ class Pipeline:
                  klt_win=15, klt_max_level=2, klt_max_iter=10, klt_eps=0.03, klt_min_eig=1e-4,
                  klt_err_threshold=100.0, hyp=1000, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99,
                  max_iterations=1000, seed=2023, refine_iters=0, feature_cap=0, bearing_threshold=0.0075,
-                 redetect_fraction=0.8, debug_fault_every=0, redetect_start_pose="identity", sequences=1):
+                 redetect_fraction=0.8, debug_fault_every=0, redetect_start_pose="identity", sequences=1,
+                 detect_margin=0.1):
         from vo import _native
         self.ctx = ctx
         self.cfg = _native.PipelineConfig()
@@ -47,6 +48,7 @@ class Pipeline:
         c.debug_fault_every = int(debug_fault_every)
         c.redetect_start_pose = {"identity": 0, "current": 1}[redetect_start_pose]
         c.sequences = int(sequences)
+        c.detect_margin = float(detect_margin)       # < 0: the detector runs on every frame
         self.sequences = int(sequences)
         K = np.asarray(K, np.float64).reshape(3, 3)
         self.K = K
