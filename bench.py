@@ -550,18 +550,25 @@ def main():
                        "parallelism": "sequence-sharded x%d%s%s" % (world, ", %d sequences per GPU per launch" % S if S > 1 else "", ", RCCL all-gather of the {pose, landmarks} records of %d frames every %d frames" % (EXCHANGE_EVERY, EXCHANGE_EVERY) if exchange else "")},
             "roofline": roof,
             # the image-wide (streaming) kernels against the same HBM peak, from the untimed all-kernel event pass
+            # (the detector's kernels only when they run on every frame: a launch that a sequence sits out returns at once
+            #  and would flatter the average; VO_BENCH_DETECT_MARGIN=-1 gives their figures, profiles/ holds that line)
             "roofline_streaming": {k: {"avg_launch_us": round(us(k), 2),
                                        "algorithmic_bytes_per_launch": abytes(k),
                                        "achieved": round(abytes(k) / (us(k) * 1e-6) / 1e9, 1),
                                        "frac": round(abytes(k) / (us(k) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-                                   for k in ("harris_response", "nms_candidates", "pyr_down") if k in per_kernel},
+                                   for k in (("harris_response", "nms_candidates", "pyr_down") if DETECT_MARGIN < 0 else ("pyr_down",))
+                                   if k in per_kernel},
             "per_kernel_us": {k: round(us(k), 2) for k in sorted(per_kernel)},
+            "per_kernel_note": "HIP-event averages over 16 untimed steps with every kernel bracketed (streams overlap: a kernel's "
+                               "time includes what it waits for the others)" + ("" if DETECT_MARGIN < 0 else
+                               "; harris_response / nms_* average over launches most sequences sit out"),
             "chain_us": chain,
             "loop": {"features_in_median": n_in, "tracked_median": n_trk, "landmarks_p3p_median": n_tri,
                      "inliers_median": float(np.median([r.n_inliers for r in every])),
                      "candidates_median": float(np.median([r.n_candidates for r in every])),
                      "ransac_iters_median": float(np.median([r.ransac_iterations for r in every])),
                      "redetect_fraction_of_steps": float(np.mean([r.redetected for r in every])),
+                     "detector_executed_fraction_of_steps": float(np.mean([r.detector_ran for r in every])),
                      "steps_finished_by_host_path": int(sum(r.recovered for r in every)),
                      "refine_steps_median": float(np.median([r.refine_iterations for r in every])),
                      "bootstrap_landmarks": n_boot},

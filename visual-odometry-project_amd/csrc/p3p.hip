@@ -417,8 +417,10 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
 //   the population is read from memory once per workgroup (Hyp / HG times in all, not Hyp times: the one-workgroup-
 //   per-hypothesis kernel streams ~70 MB through L2 at cfg-2 and slows down 3x when the tracker and the detector
 //   run beside it), inlier bits leave as one ballot word per wave, counts as popcounts.
-constexpr int HG = 8;      // hypotheses per workgroup
+// HG hypotheses per workgroup: 8 for one sequence (125 workgroups at 1000 hypotheses: latency), 16 when a launch holds
+// several sequences (wave 0's 64 lanes all solve, half as many workgroups share the solve's latency: throughput).
 constexpr int HP = 7;      // correspondences per thread and tile (256 * 7 = 1792 = 28 mask words)
+template <int HG>
 __global__ __launch_bounds__(256) void p3p_hyp_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
                                                       const unsigned* __restrict__ raws,
                                                       const unsigned long long* __restrict__ d_rawpos, unsigned raw_mask,
@@ -588,9 +590,16 @@ int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x
   VO_REQUIRE(ctx, K[0] != 0.0 && K[4] != 0.0, "p3p_hypotheses_ring: singular intrinsics");
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
-    hipLaunchKernelGGL(p3p_hyp_kernel, dim3(vo_cdiv(Hyp, HG), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
-                       (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], thr_sq, d_R,
-                       d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts, B);
+    if (S >= 8)
+      hipLaunchKernelGGL(p3p_hyp_kernel<16>, dim3(vo_cdiv(Hyp, 16), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
+                         (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], thr_sq, d_R,
+                         d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts,
+                         B);
+    else
+      hipLaunchKernelGGL(p3p_hyp_kernel<8>, dim3(vo_cdiv(Hyp, 8), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
+                         (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], thr_sq, d_R,
+                         d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts,
+                         B);
   }
   return vo_check_launch(ctx, "p3p_hyp_kernel");
 }

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
   if (blockIdx.x == 0 && tid == 0) {
     ctl->n_in = n_in;
     ctl->redetected = redetect ? 1 : 0;
+    ctl->det_ran = ap.det_go ? ap.det_go[blockIdx.y] : 1;
     ctl->n2 = T0 + T1 + T2;
     ctl->n_tri = T0;
     ctl->n_mat = T1;
@@ -492,6 +493,8 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
     res->refine_cost = use_refined > 0 ? ctl->refined[13] : 0.0;
     res->n_features_in = ctl->n_in;
     res->redetected = ctl->redetected;
+    res->detector_ran = ctl->det_ran;
+    res->reserved = 0;
     res->n_triangulated = ctl->n_tri;
     res->n_candidates = n_cand;
     res->n_dropped = n_dropped;

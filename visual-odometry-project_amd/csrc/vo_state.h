@@ -52,6 +52,7 @@ struct vo_seq_ctl {
   int32_t num_features;    // KLTTracker._num_features
   int32_t n_in;            // features handed to the tracker (after a possible re-detect)
   int32_t redetected;
+  int32_t det_ran;         // the detector ran on this step's `prev` frame (its keypoints exist whether or not they were needed)
   int32_t n2, n_tri, n_mat, n_new;   // new frame: total, and the sizes of its first three groups
   int32_t n_p3p;           // population the hypothesis kernels see: n_tri, or 0 when the step must not run
   int32_t fault;           // sticky: every later kernel of this and the following steps leaves the state alone

@@ -79,7 +79,8 @@ class StepResult(C.Structure):
                 ("R_refined", C.c_double * 9), ("t_refined", C.c_double * 3), ("refine_cost", C.c_double),
                 ("n_features_in", C.c_int32), ("redetected", C.c_int32), ("n_triangulated", C.c_int32),
                 ("n_candidates", C.c_int32), ("n_dropped", C.c_int32), ("n_landmarks", C.c_int32),
-                ("fault", C.c_int32), ("recovered", C.c_int32), ("raw_pos", C.c_uint64), ("T_wc", C.c_double * 12),
+                ("fault", C.c_int32), ("recovered", C.c_int32), ("detector_ran", C.c_int32), ("reserved", C.c_int32),
+                ("raw_pos", C.c_uint64), ("T_wc", C.c_double * 12),
                 ("ts", C.c_uint64 * 8), ("seq_head", C.c_uint32), ("seq_tail", C.c_uint32)]
 
     def pose_world_cam(self):
