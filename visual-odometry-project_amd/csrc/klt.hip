@@ -500,12 +500,12 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
                                                        float* __restrict__ err, int lds_per_wave) {
   extern __shared__ __align__(16) unsigned char smem_all[];
   const int i = blockIdx.x * KLT_WAVES + (threadIdx.x >> 6);
+  // (the kernel argument P is left untouched: written to, it would be copied to scratch -- one copy per lane -- for the
+  //  run-time level index; measured as 14 MB of scratch traffic per launch)
+  size_t pyr_off = 0;
   if (blockIdx.y != 0) {                               // several sequences per launch: grid.y = sequence
     const size_t q = blockIdx.y;
-    for (int l = 0; l < P.n_levels; ++l) {
-      P.prev[l] += q * B.pyr;
-      P.next[l] += q * B.pyr;
-    }
+    pyr_off = q * B.pyr;
     prev_xy += q * B.xy;
     next_xy += q * B.xy;
     status += q * B.out;
@@ -547,8 +547,8 @@ __global__ __launch_bounds__(64 * KLT_WAVES) void klt_track_kernel(pyr_t P, cons
   float nx = 0.f, ny = 0.f;
 
   for (int level = P.n_levels - 1; level >= 0; --level) {
-    const uint8_t* I = P.prev[level];
-    const uint8_t* J = P.next[level];
+    const uint8_t* I = P.prev[level] + pyr_off;
+    const uint8_t* J = P.next[level] + pyr_off;
     const int H = P.H[level], W = P.W[level], pitch = P.pitch[level];
     const float sc = (float)(1. / (double)(1 << level));
     float px = p0x * sc, py = p0y * sc;
@@ -846,12 +846,12 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   __shared__ __align__(16) uint8_t smem[KPW * G::SLICE + 16];
   const int lane = threadIdx.x;
   const int i = blockIdx.x * KPW + lane / LPK;
+  // (the kernel argument P is left untouched: written to, it would be copied to scratch -- one copy per lane -- for the
+  //  run-time level index; measured as 14 MB of scratch traffic per launch)
+  size_t pyr_off = 0;
   if (blockIdx.y != 0) {                               // several sequences per launch: grid.y = sequence
     const size_t q = blockIdx.y;
-    for (int l = 0; l < P.n_levels; ++l) {
-      P.prev[l] += q * B.pyr;
-      P.next[l] += q * B.pyr;
-    }
+    pyr_off = q * B.pyr;
     prev_xy += q * B.xy;
     next_xy += q * B.xy;
     status += q * B.out;
@@ -896,12 +896,12 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
     int ipx = (int)floorf(px), ipy = (int)floorf(py);
     ipx = min(max(ipx, -win), P.W[level] - 1);       // (a level whose block would leave the border is skipped below)
     ipy = min(max(ipy, -win), P.H[level] - 1);
-    stage_load<n3, n3, LPK>(P.prev[level], P.pitch[level], ipx - 1, ipy - 1, r, tplI);
+    stage_load<n3, n3, LPK>(P.prev[level] + pyr_off, P.pitch[level], ipx - 1, ipy - 1, r, tplI);
   };
   request_template(P.n_levels - 1);
 
   for (int level = P.n_levels - 1; level >= 0; --level) {
-    const uint8_t* J = P.next[level];
+    const uint8_t* J = P.next[level] + pyr_off;
     const int H = P.H[level], W = P.W[level], pitch = P.pitch[level];
     const float sc = (float)(1. / (double)(1 << level));
     const staged_block<n3, n3, LPK> curI = tplI;
