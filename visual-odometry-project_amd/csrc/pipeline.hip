@@ -3,7 +3,7 @@
 // State / RANSAC bookkeeping living in HBM (state.hip).  See include/vo_hip.h for the stage list.
 //
 // Streams of one step (frame k-1 -> k):
-//   main   : regroup -> hypotheses+counts -> replay+refine+candidates -> landmarks+record
+//   main   : regroup -> hypotheses+counts -> replay+refine+candidates+landmarks+record
 //   tracker: pyramid(k) -> KLT(k)           needs regroup(k-1) only: runs beside the pose estimation of step k-1
 //   detect : Harris response + NMS on k     (enqueued by a worker thread; consumed by the NEXT step's re-detect.
 //            The reference runs its detector only when fewer than 80 % of the tracks are left, klt.py:207-230; whether
@@ -525,6 +525,10 @@ static vo_pose_job make_pose_job(vo_pipeline* p, const vo_feat& B, int do_replay
   j.cam = p->cam;
   j.bearing_thr = c.bearing_threshold;
   j.max_iter = c.refine_iters;
+  j.tail = 0;
+  j.res = nullptr;
+  j.seq_word = nullptr;
+  j.seq = 0u;
   return j;
 }
 
@@ -599,9 +603,13 @@ static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fi
                                     p->ring_len - 1, c.hyp, c.p3p_thr_sq, p->d_R + q * c.hyp * 9, p->d_t + q * c.hyp * 3,
                                     p->d_valid + q * c.hyp, p->d_counts + q * c.hyp, p->d_masks + q * c.hyp * p->words,
                                     (uint32_t*)&ctl->solve_flag, (uint64_t*)&ctl->ts[2], &hb));
-  VO_TRY(vo_frame_pose(ctx, make_pose_job(p, p->F[1 - f.fcur], 1, q0), Sn));
-  VO_TRY(vo_state_landmarks(ctx, ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + (size_t)f.rslot * p->S + q,
-                            p->m_seq + (size_t)f.rslot * p->S + q, seq, Sn));
+  // pose, candidates, candidate triangulation, landmark update and the record in one launch (frame_pose_kernel's tail)
+  vo_pose_job job = make_pose_job(p, p->F[1 - f.fcur], 1, q0);
+  job.tail = 1;
+  job.res = p->m_res + (size_t)f.rslot * p->S + q;
+  job.seq_word = p->m_seq + (size_t)f.rslot * p->S + q;
+  job.seq = seq;
+  VO_TRY(vo_frame_pose(ctx, job, Sn));
   return VO_OK;
 }
 
@@ -993,9 +1001,14 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   VO_HIP_TRY(ctx, mcpy(st, ctl, &h, sizeof(h), hipMemcpyHostToDevice));
   const unsigned seq = ++p->seq;           // the fault record carried the step's number: the new record gets its own
   p->slot_seq[(size_t)f.rslot * p->S + q] = seq;
-  VO_TRY(vo_frame_pose(ctx, make_pose_job(p, p->F[1 - f.fcur], 0, q), 1));
-  VO_TRY(vo_state_landmarks(ctx, ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, p->m_res + (size_t)f.rslot * p->S + q,
-                            p->m_seq + (size_t)f.rslot * p->S + q, seq, 1));
+  {
+    vo_pose_job job = make_pose_job(p, p->F[1 - f.fcur], 0, q);
+    job.tail = 1;
+    job.res = p->m_res + (size_t)f.rslot * p->S + q;
+    job.seq_word = p->m_seq + (size_t)f.rslot * p->S + q;
+    job.seq = seq;
+    VO_TRY(vo_frame_pose(ctx, job, 1));
+  }
   VO_TRY(wait_record(p, f.rslot, q, seq, 0, out));
   out->recovered = 1;
   ++p->n_recovered;

@@ -13,6 +13,7 @@
 // halving butterfly (32 shuffles for all 28 sums), wave 0 adds the eight wave totals, solves the
 // 6x6 system with one lane per row and applies the update; all fp64, two barriers per iteration.
 #include "state_device.h"
+#include "dlt_device.h"
 
 #pragma clang fp contract(off)
 
@@ -320,13 +321,20 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
 //   1. wave 0 replays the sequential RANSAC rule over the scored hypotheses (ransac.py:90-121, state_device.h)
 //      while the other waves already fetch the population's coordinates;
 //   2. all waves refine the accepted pose over its inliers (p3p.py:188-213), as refine_pose_kernel does;
-//   3. all threads walk the new frame's features: pose, outliers, bearing-angle candidates (main.py:261-268).
+//   3. all threads walk the new frame's features: pose, outliers, bearing-angle candidates (main.py:261-268);
+//   4. (job.tail) main.py:279-286 as state_landmarks_kernel does it -- the candidates, compacted into a list, are
+//      triangulated one per work item with their track's own start pose (triangulation.py:38-86), inserted as landmarks
+//      (state.py:69-88), all landmarks checked for cheirality when there was a candidate (state.py:90-107) -- and the
+//      step's result record: two launches and a kernel boundary (5-7 us on the dependent chain) less per step.
+constexpr int TAIL_LIST = 4096;   // candidates the LDS list holds (more: every work item walks its own features)
 __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   using namespace vo_state_dev;
   __shared__ double s_table[RP_TABLE_LDS];
   __shared__ double s_w[RF_T / 64][RF_S];
   __shared__ double s_pose[12], s_try[12];
   __shared__ int s_state, s_cand[RF_T / 64];
+  __shared__ int s_list[TAIL_LIST];
+  __shared__ int s_nc, s_tail[2];
   if (blockIdx.x != 0) {               // several sequences per launch: one workgroup per sequence
     const size_t q = blockIdx.x;
     job.ctl += q;
@@ -337,10 +345,20 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
     job.rp.masks += q * (size_t)job.rp.hyp * job.rp.words;
     job.rp.best_mask += q * (size_t)job.rp.words;
     job.B = vo_feat_seq(job.B, q);
+    if (job.res) {
+      job.res += q;
+      job.seq_word += q;
+    }
   }
   vo_seq_ctl* ctl = job.ctl;
   if (threadIdx.x == 0) ctl->ts[3] = wall_clock64();
-  if (ctl->fault) return;
+  if (ctl->fault) {
+    if (job.tail && job.res && threadIdx.x == 0) {
+      ctl->ts[4] = wall_clock64();
+      write_fault_record(ctl, ctl->fault, job.res, job.seq_word, job.seq);
+    }
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const double* X = job.B.land;
   const double* x = job.B.kp64;
@@ -356,7 +374,13 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   __syncthreads();
   if (job.do_replay && wv == 0) replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table);
   __syncthreads();
-  if (ctl->fault) return;                       // (raised by the replay: the host finishes this step)
+  if (ctl->fault) {                             // (raised by the replay: the host finishes this step)
+    if (job.tail && job.res && tid == 0) {
+      ctl->ts[4] = wall_clock64();
+      write_fault_record(ctl, ctl->fault, job.res, job.seq_word, job.seq);
+    }
+    return;
+  }
   const int N = min(ctl->n_p3p, cap);
   const unsigned long long* mask_bits = job.rp.best_mask;
 #pragma unroll
@@ -391,16 +415,28 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   }
   rigid_inverse_3x4(Tcw, Twc);
   const int n2 = ctl->n2, n_tri = ctl->n_tri;
+  if (tid == 0) {
+    s_nc = 0;
+    s_tail[0] = s_tail[1] = 0;
+  }
+  __syncthreads();
   int count = 0;
-  for (int i = tid; i < n2; i += RF_T) count += candidate_feature(job.B, i, n_tri, mask_bits, job.cam, Twc, job.bearing_thr);
+  for (int i = tid; i < n2; i += RF_T) {
+    const int c = candidate_feature(job.B, i, n_tri, mask_bits, job.cam, Twc, job.bearing_thr);
+    count += c;
+    if (c && job.tail) {
+      const int slot = atomicAdd(&s_nc, 1);
+      if (slot < TAIL_LIST) s_list[slot] = i;
+    }
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off);
   if (lane == 0) s_cand[wv] = count;
   __syncthreads();
+  int n_cand = 0;
+  for (int w = 0; w < RF_T / 64; ++w) n_cand += s_cand[w];
   if (tid == 0) {
-    int total = 0;
-    for (int w = 0; w < RF_T / 64; ++w) total += s_cand[w];
-    ctl->n_cand = total;
+    ctl->n_cand = n_cand;
     ctl->n = n2;                                 // the new frame is the current one from here on
   }
   if (tid < 12) {
@@ -412,6 +448,99 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
     }
     commit_pose(ctl, tid, ncw, nwc);
   }
+  if (!job.tail) return;
+  // ---- 4. triangulate_candidates -> update_with_world_landmarks -> _check_landmarks, then the record ----
+  __syncthreads();                               // (poses committed, candidate flags and restarted tracks in place)
+  unsigned long long ts4 = 0ull;
+  if (tid == 0) {
+    ts4 = wall_clock64();
+    ctl->ts[4] = ts4;
+  }
+  vo_feat B = job.B;
+  {
+    double Tp[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Tp[k] = ctl->T_cw_prev[k];
+    int dropped = 0, land = 0;
+    // _check_landmarks for one feature whose landmark is X (state.py:90-107): behind either camera -> the track restarts here
+    auto check = [&](int i, int st, double X0, double X1, double X2) {
+      if (n_cand > 0) {
+        const double zc = Tcw[8] * X0 + Tcw[9] * X1 + Tcw[10] * X2 + Tcw[11];
+        const double zp = Tp[8] * X0 + Tp[9] * X1 + Tp[10] * X2 + Tp[11];
+        if (zc < 0.0 || zp < 0.0) {                            // (NaN landmarks compare false)
+          const double nan = dnan();
+          B.land[3 * i] = B.land[3 * i + 1] = B.land[3 * i + 2] = nan;
+          B.state[i] = 0;
+          st = 0;
+          B.track[2 * i] = B.kp64[2 * i];
+          B.track[2 * i + 1] = B.kp64[2 * i + 1];
+#pragma unroll
+          for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + i] = Twc[k];
+          ++dropped;
+        }
+      }
+      land += st == 2 ? 1 : 0;
+    };
+    // features that are no candidates: nothing to wait for -- four per work item and pass, their loads in flight together
+    for (int base = tid; base < n2; base += 4 * RF_T) {
+      int st[4];
+      double X[4][3];
+      bool go[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * RF_T, ic = min(i, n2 - 1);
+        go[u] = i < n2 && !B.cand[ic];
+        st[u] = B.state[ic];
+        X[u][0] = B.land[3 * ic];
+        X[u][1] = B.land[3 * ic + 1];
+        X[u][2] = B.land[3 * ic + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (go[u]) check(base + u * RF_T, st[u], X[u][0], X[u][1], X[u][2]);
+    }
+    // the candidates: triangulated with their track's own start pose, inserted, checked by the same work item
+    double C2[12];
+    k_times(job.cam.K, Tcw, C2);                 // proj2 = K inv(current_pose)[:3] (triangulation.py:53-57)
+    auto triangulate = [&](int i) {
+      double Ts[12], Ti[12], C1[12], X[3];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) Ts[q] = B.pose[(size_t)q * B.pitch + i];
+      rigid_inverse_3x4(Ts, Ti);
+      k_times(job.cam.K, Ti, C1);                // proj1 = K inv(pose_start)[:3]
+      vo_dlt::triangulate_point(C1, B.track[2 * i], B.track[2 * i + 1], C2, B.kp64[2 * i], B.kp64[2 * i + 1], X);
+      B.land[3 * i] = X[0];
+      B.land[3 * i + 1] = X[1];
+      B.land[3 * i + 2] = X[2];
+      B.state[i] = 2;
+      check(i, 2, X[0], X[1], X[2]);
+    };
+    if (n_cand <= TAIL_LIST) {
+      for (int k = tid; k < n_cand; k += RF_T) triangulate(s_list[k]);
+    } else {
+      for (int i = tid; i < n2; i += RF_T)
+        if (B.cand[i]) triangulate(i);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      dropped += __shfl_xor(dropped, off);
+      land += __shfl_xor(land, off);
+    }
+    if (lane == 0) {
+      if (dropped) atomicAdd(&s_tail[0], dropped);
+      if (land) atomicAdd(&s_tail[1], land);
+    }
+  }
+  __syncthreads();
+  const int n_dropped = s_tail[0], n_land = s_tail[1];
+  if (tid == 0) {
+    ctl->n_dropped = n_dropped;
+    ctl->n_land = n_land;
+    ctl->step += 1;
+  }
+  if (!job.res) return;
+  ts4 = __shfl(ts4, 0);                          // (only wave 0's first lane writes the record's scalar fields)
+  write_step_record(ctl, tid, job.max_iter > 0 ? 1 : 0, n2, n_cand, n_dropped, n_land, ts4, job.res, job.seq_word, job.seq);
 }
 
 }  // namespace

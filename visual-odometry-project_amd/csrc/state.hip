@@ -392,17 +392,7 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
   if (blockIdx.x == 0 && tid == 0) ctl->ts[4] = wall_clock64();
   const int fault = ctl->fault;
   if (fault) {
-    if (res && blockIdx.x == 0 && tid == 0) {
-      res->seq_head = seq;
-      res->fault = fault;
-      res->n_features_in = ctl->n_in;
-      res->n_tracked = ctl->n2;
-      res->n_triangulated = ctl->n_tri;
-      res->raw_pos = ctl->raw_pos;
-      res->seq_tail = seq;
-      __threadfence_system();
-      *seq_word = seq;
-    }
+    if (res && blockIdx.x == 0 && tid == 0) write_fault_record(ctl, fault, res, seq_word, seq);
     return;
   }
   const int n2 = ctl->n2, n_cand = ctl->n_cand;
@@ -472,48 +462,7 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
   const int n_dropped = atomicAdd(&ctl->n_dropped, 0), n_land = atomicAdd(&ctl->n_land, 0);
   if (tid == 0) ctl->step += 1;
   if (!res) return;
-  if (tid < 9) {
-    res->R[tid] = ctl->best_pose[tid];
-    res->R_refined[tid] = use_refined > 0 ? ctl->refined[tid] : ctl->best_pose[tid];
-  }
-  if (tid < 3) {
-    res->t[tid] = ctl->best_pose[9 + tid];
-    res->t_refined[tid] = use_refined > 0 ? ctl->refined[9 + tid] : ctl->best_pose[9 + tid];
-  }
-  if (tid < 12) res->T_wc[tid] = ctl->T_wc[tid];
-  if (tid == 0) {
-    res->seq_head = seq;
-    res->n_tracked = n2;
-    res->n_inliers = ctl->best_count;
-    res->best_index = ctl->best_idx;
-    res->hyp_valid = ctl->hyp_valid;
-    res->ransac_iterations = ctl->n_done;
-    res->draws_consumed = ctl->consumed;
-    res->refine_iterations = use_refined > 0 ? (int)ctl->refined[12] : -1;
-    res->refine_cost = use_refined > 0 ? ctl->refined[13] : 0.0;
-    res->n_features_in = ctl->n_in;
-    res->redetected = ctl->redetected;
-    res->detector_ran = ctl->det_ran;
-    res->reserved = 0;
-    res->n_triangulated = ctl->n_tri;
-    res->n_candidates = n_cand;
-    res->n_dropped = n_dropped;
-    res->n_landmarks = n_land;
-    res->fault = 0;
-    res->recovered = 0;
-    res->raw_pos = ctl->raw_pos;
-    res->ts[0] = ctl->ts[6];
-    for (int k = 1; k < 4; ++k) res->ts[k] = ctl->ts[k];
-    res->ts[4] = atomicAdd(&ctl->ts[4], 0ull);
-    res->ts[5] = wall_clock64();
-  }
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0) {
-    res->seq_tail = seq;
-    __threadfence_system();
-    *seq_word = seq;
-  }
+  write_step_record(ctl, tid, use_refined, n2, n_cand, n_dropped, n_land, atomicAdd(&ctl->ts[4], 0ull), res, seq_word, seq);
 }
 
 }  // namespace

@@ -216,4 +216,68 @@ __device__ __forceinline__ void commit_pose(vo_seq_ctl* __restrict__ ctl, int ti
   ctl->T_wc[tid] = nwc;
 }
 
+// The record of a step that raised a fault: what the host needs to redo it.  One work item.
+__device__ __forceinline__ void write_fault_record(const vo_seq_ctl* __restrict__ ctl, int fault, vo_step_result* __restrict__ res,
+                                                   unsigned* __restrict__ seq_word, unsigned seq) {
+  res->seq_head = seq;
+  res->fault = fault;
+  res->n_features_in = ctl->n_in;
+  res->n_tracked = ctl->n2;
+  res->n_triangulated = ctl->n_tri;
+  res->raw_pos = ctl->raw_pos;
+  res->seq_tail = seq;
+  __threadfence_system();
+  *seq_word = seq;
+}
+
+// The record of a finished step, by the workgroup that closes it (every count is final, the workgroup is in step).
+// ts4: the device clock at the start of the landmark stage.
+__device__ __forceinline__ void write_step_record(vo_seq_ctl* __restrict__ ctl, int tid, int use_refined, int n2, int n_cand,
+                                                  int n_dropped, int n_land, unsigned long long ts4,
+                                                  vo_step_result* __restrict__ res, unsigned* __restrict__ seq_word,
+                                                  unsigned seq) {
+  if (tid < 9) {
+    res->R[tid] = ctl->best_pose[tid];
+    res->R_refined[tid] = use_refined > 0 ? ctl->refined[tid] : ctl->best_pose[tid];
+  }
+  if (tid < 3) {
+    res->t[tid] = ctl->best_pose[9 + tid];
+    res->t_refined[tid] = use_refined > 0 ? ctl->refined[9 + tid] : ctl->best_pose[9 + tid];
+  }
+  if (tid < 12) res->T_wc[tid] = ctl->T_wc[tid];
+  if (tid == 0) {
+    res->seq_head = seq;
+    res->n_tracked = n2;
+    res->n_inliers = ctl->best_count;
+    res->best_index = ctl->best_idx;
+    res->hyp_valid = ctl->hyp_valid;
+    res->ransac_iterations = ctl->n_done;
+    res->draws_consumed = ctl->consumed;
+    res->refine_iterations = use_refined > 0 ? (int)ctl->refined[12] : -1;
+    res->refine_cost = use_refined > 0 ? ctl->refined[13] : 0.0;
+    res->n_features_in = ctl->n_in;
+    res->redetected = ctl->redetected;
+    res->detector_ran = ctl->det_ran;
+    res->reserved = 0;
+    res->n_triangulated = ctl->n_tri;
+    res->n_candidates = n_cand;
+    res->n_dropped = n_dropped;
+    res->n_landmarks = n_land;
+    res->fault = 0;
+    res->recovered = 0;
+    res->raw_pos = ctl->raw_pos;
+    res->ts[0] = ctl->ts[6];
+    for (int k = 1; k < 4; ++k) res->ts[k] = ctl->ts[k];
+    res->ts[4] = ts4;
+    res->ts[5] = wall_clock64();
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    res->seq_tail = seq;
+    __threadfence_system();
+    *seq_word = seq;
+  }
+}
+
 }  // namespace vo_state_dev

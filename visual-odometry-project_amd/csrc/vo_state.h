@@ -115,6 +115,13 @@ struct vo_pose_job {
   vo_cam cam;
   double bearing_thr;
   int max_iter;         // Gauss-Newton steps allowed; 0 = refinement off
+  // tail != 0: the same workgroup goes on with what state_landmarks_kernel does (candidate triangulation, landmark
+  // insertion, cheirality check) and writes the step's result record -- one launch and one kernel boundary less on the
+  // dependent chain of a step
+  int tail;
+  vo_step_result* res;  // mapped host memory (sequence q: res + q), may be NULL
+  unsigned* seq_word;
+  unsigned seq;
 };
 int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job, int S = 1);   // S > 1: sequence q uses block q of every array
 
