@@ -283,8 +283,12 @@ def cfg3_main(args):
                         "achieved": None if not ss_us else round(ss_bytes / (ss_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": None if not ss_us else round(ss_bytes / (ss_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic": None},
-           "matcher": {"kernel": "match_knn2 (packed-byte dot products, exact)", "avg_launch_us": None if m_us is None else round(m_us, 1),
-                       "flops": flops, "achieved_tflops": None if not m_us else round(flops / (m_us * 1e-6) / 1e12, 2)},
+           # dense i8 MFMA peak: twice the bf16 rate (MI355X_MICROARCH.md, matrix cores) = 2 x 2.5 POP/s
+           "matcher": {"bound": "mfma", "kernel": "match_knn2 (v_mfma_i32_32x32x32_i8 on bytes offset by 128, exact integer distances)",
+                       "avg_launch_us": None if m_us is None else round(m_us, 1), "ops": flops,
+                       "achieved": None if not m_us else round(flops / (m_us * 1e-6) / 1e12, 2), "peak": 5000.0, "unit": "TOP/s",
+                       "frac": None if not m_us else round(flops / (m_us * 1e-6) / 1e12 / 5000.0, 5),
+                       "note": "2000 x 2000 x 128: 1 GOP, a launch of ~500 workgroups -- latency-bound, not MFMA-bound"},
            "per_kernel_us": {k: round(v, 1) for k, v in sorted(per.items())}}
     print(json.dumps(out), flush=True)
     ctx.close()

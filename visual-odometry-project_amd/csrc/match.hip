@@ -6,8 +6,9 @@
 //   and the train index has not been used yet (queries in order).
 // Both descriptor kinds are integer-valued in 0..255, so the squared distance
 //   |a|^2 + |b|^2 - 2 a.b
-// is an exact integer: descriptors are packed to bytes and a.b runs on the packed
-// 4-way byte dot product (v_dot4_u32_u8), 4 multiply-adds per lane per instruction.
+// is an exact integer: descriptors are packed to bytes and a.b runs on the matrix cores
+// (v_mfma_i32_32x32x32_i8, knn2_mfma_kernel: unsigned bytes through the -128 offset identity, exact in int32;
+// descriptor lengths 128 and 361) or on the packed 4-way byte dot product (v_dot4_u32_u8, any other length).
 // Any other input takes the float path (float64 accumulation in index order).  Either
 // way the result equals the oracle's definition (oracle/csrc/match.c) bit for bit.
 // The first-come uniqueness filter is a sequential pass over nq results (host side).
@@ -27,12 +28,10 @@ struct top2 {
 };
 
 __device__ __forceinline__ void top2_insert(unsigned long long& k0, unsigned long long& k1, unsigned long long k) {
-  if (k < k0) {
-    k1 = k0;
-    k0 = k;
-  } else if (k < k1) {
-    k1 = k;
-  }
+  // (selects only: written with branches the compiler kept the pair in scratch memory inside the MFMA kernel's loop)
+  const unsigned long long lo = k < k0 ? k : k0, hi = k < k0 ? k0 : k;
+  k0 = lo;
+  k1 = hi < k1 ? hi : k1;
 }
 
 // descriptors as bytes, rows padded to Dp = multiple of 4
@@ -100,6 +99,142 @@ __global__ __launch_bounds__(MT) void knn2_u8_kernel(const uint8_t* __restrict__
       d2[2 * qi] = a0 == ~0ull ? 0.0 : (double)(unsigned)(a0 >> 32);
       d2[2 * qi + 1] = a1 == ~0ull ? 0.0 : (double)(unsigned)(a1 >> 32);
     }
+  }
+}
+
+// ---- the same on the matrix cores ----
+// A wave owns a 32 (train rows) x 32 (queries) tile of a . b per step: v_mfma_i32_32x32x32_i8 takes signed bytes, so
+// every byte is flipped to x - 128 (x ^ 0x80) and
+//     a . b = sum (a' + 128)(b' + 128) = dot' + 128 (sum a + sum b) - 16384 Dp          (sums over the padded length Dp)
+//     |a - b|^2 = (|a|^2 - 256 sum a + 32768 Dp) + (|b|^2 - 256 sum b) - 2 dot'
+// with every term an exact integer below 2^31.  The queries are the B operand (kept in registers for the whole
+// train set), the train rows the A operand (16 bytes per lane and instruction, next tile's loads issued before this
+// tile's arithmetic): the result tile has its query on the lane (column = lane & 31) and 16 train rows in the lane's
+// registers, so the running top-2 of a query is lane-local; the 8 partial lists of a query (2 lane halves x 4 waves)
+// meet in LDS at the end.  The train set is split over gridDim.y workgroups per block of 32 queries (63 workgroups of
+// one wave per SIMD each would wait out every load: 93 us at 2000 x 2000 against 63 us for the byte-dot kernel); each
+// leaves its top-2 in global memory and the one that arrives last merges them.  Whatever order the instruction assigns the 32 k-positions of a step to (lane half,
+// element), A and B use the same one: the sum over k does not depend on it.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int KB>   // Dp = 32 * KB bytes per row
+__global__ __launch_bounds__(256) void knn2_mfma_kernel(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t,
+                                                        int nt, unsigned long long* __restrict__ part,
+                                                        unsigned* __restrict__ arrived, int* __restrict__ best,
+                                                        double* __restrict__ d2) {
+  constexpr int Dp = 32 * KB;
+  __shared__ unsigned s_t[4][32];                      // per wave: the tile's train terms
+  __shared__ unsigned long long s_k[32][8][2];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * 32;
+  // the wave's queries: B fragments + the query term of column r
+  v4i bq[KB];
+  unsigned qterm;
+  {
+    const int qi = min(q0 + r, nq - 1);
+    unsigned n2 = 0, sm = 0;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const v4i w = *reinterpret_cast<const v4i*>(q + (size_t)qi * Dp + kb * 32 + 16 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        n2 = __builtin_amdgcn_udot4((unsigned)w[e], (unsigned)w[e], n2, false);
+        sm = __builtin_amdgcn_udot4((unsigned)w[e], 0x01010101u, sm, false);
+      }
+      bq[kb] = w ^ (int)0x80808080;
+    }
+    n2 += __shfl_xor(n2, 32);
+    sm += __shfl_xor(sm, 32);
+    qterm = n2 - 256u * sm + 32768u * (unsigned)Dp;
+  }
+  unsigned long long k0 = ~0ull, k1 = ~0ull;
+  const int ntiles_all = (nt + 31) / 32;
+  const int tile_lo = (int)((long long)ntiles_all * blockIdx.y / gridDim.y);
+  const int ntiles = (int)((long long)ntiles_all * (blockIdx.y + 1) / gridDim.y);     // this workgroup: tiles tile_lo .. ntiles - 1
+  v4i a_next[KB];
+  auto load_tile = [&](int tile) {
+    const int row = min(tile * 32 + r, nt - 1);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) a_next[kb] = *reinterpret_cast<const v4i*>(t + (size_t)row * Dp + kb * 32 + 16 * h);
+  };
+  if (tile_lo + wv < ntiles) load_tile(tile_lo + wv);
+  for (int tile = tile_lo + wv; tile < ntiles; tile += 4) {
+    v4i a[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) a[kb] = a_next[kb];
+    if (tile + 4 < ntiles) load_tile(tile + 4);
+    unsigned n2 = 0, sm = 0;
+    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        n2 = __builtin_amdgcn_udot4((unsigned)a[kb][e], (unsigned)a[kb][e], n2, false);
+        sm = __builtin_amdgcn_udot4((unsigned)a[kb][e], 0x01010101u, sm, false);
+      }
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kb] ^ (int)0x80808080, bq[kb], acc, 0, 0, 0);
+    }
+    n2 += __shfl_xor(n2, 32);
+    sm += __shfl_xor(sm, 32);
+    // (a wave's LDS operations execute in order: the previous tile's reads are done)
+    if (h == 0) s_t[wv][r] = n2 - 256u * sm;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int m = (g & 3) + 8 * (g >> 2) + 4 * h;             // row of register g (C/D layout of the 32x32 shapes)
+      const int j = tile * 32 + m;
+      const unsigned dist = qterm + s_t[wv][m] - 2u * (unsigned)acc[g];
+      if (j < nt) top2_insert(k0, k1, ((unsigned long long)dist << 32) | (unsigned)j);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  s_k[r][wv * 2 + h][0] = k0;
+  s_k[r][wv * 2 + h][1] = k1;
+  __syncthreads();
+  unsigned long long a0 = ~0ull, a1 = ~0ull;
+  if (tid < 32) {
+    for (int i = 0; i < 8; ++i) {
+      top2_insert(a0, a1, s_k[tid][i][0]);
+      top2_insert(a0, a1, s_k[tid][i][1]);
+    }
+  }
+  if (gridDim.y > 1) {
+    // this workgroup's share of the train set is done: leave it, and merge everybody's if this is the last to arrive
+    unsigned long long* mine = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64;
+    if (tid < 32) {
+      mine[2 * tid] = a0;
+      mine[2 * tid + 1] = a1;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned n = atomicAdd(&arrived[blockIdx.x], 1u);
+      s_last = n == gridDim.y - 1 ? 1 : 0;
+      if (s_last) arrived[blockIdx.x] = 0u;               // ready for the next call
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid < 32) {
+      a0 = a1 = ~0ull;
+      const unsigned long long* all = part + (size_t)blockIdx.x * gridDim.y * 64;
+      for (unsigned sidx = 0; sidx < gridDim.y; ++sidx) {
+        top2_insert(a0, a1, __hip_atomic_load(&all[sidx * 64 + 2 * tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        top2_insert(a0, a1, __hip_atomic_load(&all[sidx * 64 + 2 * tid + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+    }
+  }
+  if (tid < 32 && q0 + tid < nq) {
+    const int qi = q0 + tid;
+    best[2 * qi] = a0 == ~0ull ? -1 : (int)(a0 & 0xffffffffu);
+    best[2 * qi + 1] = a1 == ~0ull ? -1 : (int)(a1 & 0xffffffffu);
+    d2[2 * qi] = a0 == ~0ull ? 0.0 : (double)(unsigned)(a0 >> 32);
+    d2[2 * qi + 1] = a1 == ~0ull ? 0.0 : (double)(unsigned)(a1 >> 32);
   }
 }
 
@@ -193,7 +328,8 @@ int vo_match_knn2_ratio(vo_ctx* ctx, const float* q, int nq, const float* t, int
   VO_TRY(vo_ensure(ctx, s[2], (size_t)nq * 8));
   VO_TRY(vo_ensure(ctx, s[3], (size_t)nq * 16));
   if (all_bytes(q, (size_t)nq * D) && all_bytes(t, (size_t)nt * D) && (size_t)D * 255 * 255 < (1ull << 31)) {
-    const int Dp = (D + 3) & ~3;
+    const bool mfma = D == 128 || D == 361;               // the reference's two descriptor lengths (sift.py, harris.py)
+    const int Dp = mfma ? (D + 31) & ~31 : (D + 3) & ~3;
     std::vector<uint8_t> qb((size_t)nq * Dp, 0), tb((size_t)nt * Dp, 0);
     for (int i = 0; i < nq; ++i)
       for (int k = 0; k < D; ++k) qb[(size_t)i * Dp + k] = (uint8_t)q[(size_t)i * D + k];
@@ -204,12 +340,32 @@ int vo_match_knn2_ratio(vo_ctx* ctx, const float* q, int nq, const float* t, int
     VO_HIP_TRY(ctx, hipMemcpyAsync(s[0].p, qb.data(), qb.size(), hipMemcpyHostToDevice, st));
     VO_HIP_TRY(ctx, hipMemcpyAsync(s[1].p, tb.data(), tb.size(), hipMemcpyHostToDevice, st));
     const size_t lds = (size_t)QB * (Dp / 4) * 4 + (size_t)QB * MT * 2 * 8;
+    // MFMA form: enough workgroups to fill the chip -- the train set is split while a share keeps >= 4 tiles of 32
+    const int qblocks = vo_cdiv(nq, 32), ttiles = vo_cdiv(nt, 32);
+    int splits = 1;
+    while (qblocks * splits < 512 && ttiles / (splits * 2) >= 4) splits *= 2;
+    if (mfma) {
+      VO_TRY(vo_ensure(ctx, s[4], (size_t)qblocks * splits * 64 * 8));
+      if (ctx->match_arrived.cap < (size_t)qblocks * 4) {     // arrival counters: zero once, the kernel leaves them at zero
+        VO_TRY(vo_ensure(ctx, ctx->match_arrived, (size_t)qblocks * 4));
+        VO_HIP_TRY(ctx, hipMemsetAsync(ctx->match_arrived.p, 0, ctx->match_arrived.cap, st));
+      }
+    }
     {
       vo_prof_scope ps(ctx, VO_K_MATCH);
-      hipLaunchKernelGGL(knn2_u8_kernel, dim3(vo_cdiv(nq, QB)), dim3(MT), lds, st, (const uint8_t*)s[0].p, nq,
-                         (const uint8_t*)s[1].p, nt, Dp, (int*)s[2].p, (double*)s[3].p);
+      if (Dp == 128)
+        hipLaunchKernelGGL(knn2_mfma_kernel<4>, dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)s[0].p, nq,
+                           (const uint8_t*)s[1].p, nt, (unsigned long long*)s[4].p, (unsigned*)ctx->match_arrived.p,
+                           (int*)s[2].p, (double*)s[3].p);
+      else if (mfma)
+        hipLaunchKernelGGL(knn2_mfma_kernel<12>, dim3(qblocks, splits), dim3(256), 0, st, (const uint8_t*)s[0].p, nq,
+                           (const uint8_t*)s[1].p, nt, (unsigned long long*)s[4].p, (unsigned*)ctx->match_arrived.p,
+                           (int*)s[2].p, (double*)s[3].p);
+      else
+        hipLaunchKernelGGL(knn2_u8_kernel, dim3(vo_cdiv(nq, QB)), dim3(MT), lds, st, (const uint8_t*)s[0].p, nq,
+                           (const uint8_t*)s[1].p, nt, Dp, (int*)s[2].p, (double*)s[3].p);
     }
-    VO_TRY(vo_check_launch(ctx, "knn2_u8_kernel"));
+    VO_TRY(vo_check_launch(ctx, "knn2 kernel"));
     VO_HIP_TRY(ctx, hipStreamSynchronize(st));   // host staging vectors go out of scope below
   } else {
     VO_TRY(vo_ensure(ctx, s[0], (size_t)nq * D * 4));

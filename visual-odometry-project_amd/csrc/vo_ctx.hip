@@ -86,7 +86,8 @@ void vo_destroy(vo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   vo_buf* all[] = {&c->img, &c->img2, &c->scores, &c->kp, &c->desc, &c->nms_keys_l1, &c->nms_idx_l1,
                    &c->nms_keys_a1, &c->nms_idx_a1, &c->nms_keys_c, &c->nms_idx_c, &c->nms_hist,
-                   &c->nms_ctl, &c->nms_sel, &c->nms_cand, &c->nms_alive, &c->nms_segcnt, &c->nms_rank, &c->sift_arena};
+                   &c->nms_ctl, &c->nms_sel, &c->nms_cand, &c->nms_alive, &c->nms_segcnt, &c->nms_rank, &c->sift_arena,
+                   &c->match_arrived};
   for (vo_buf* b : all) free_buf(*b);
   for (vo_buf& b : c->scratch) free_buf(b);
   if (c->h_pin) (void)hipHostFree(c->h_pin);

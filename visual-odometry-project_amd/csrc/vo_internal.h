@@ -53,6 +53,7 @@ struct vo_ctx {
   int nms_S = 0;                 // sequences per launch of the last NMS call (the histograms' layout depends on it)
   float* nms_kp_f32 = nullptr;   // optional: the NMS also writes its keypoints as float pairs here (device)
   vo_buf scratch[16];
+  vo_buf match_arrived;          // knn2_mfma_kernel's per-query-block arrival counters (zero between calls)
   vo_buf sift_arena;
   // pinned host staging
   void* h_pin = nullptr;
