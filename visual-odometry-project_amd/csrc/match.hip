@@ -11,7 +11,9 @@
 // descriptor lengths 128 and 361) or on the packed 4-way byte dot product (v_dot4_u32_u8, any other length).
 // Any other input takes the float path (float64 accumulation in index order).  Either
 // way the result equals the oracle's definition (oracle/csrc/match.c) bit for bit.
-// The first-come uniqueness filter is a sequential pass over nq results (host side).
+// Packing to bytes (with the check that every value is a whole number in 0..255), the ratio test and the
+// first-come uniqueness filter run on the device too: a train index goes to the first query, in query order,
+// that passes the ratio test with it -- the smallest such query index (atomicMin), then an ordered compaction.
 #include <cmath>
 
 #include "vo_internal.h"
@@ -287,12 +289,66 @@ __global__ __launch_bounds__(MT) void knn2_f32_kernel(const float* __restrict__ 
   }
 }
 
-bool all_bytes(const float* v, size_t n) {
-  for (size_t i = 0; i < n; ++i) {
-    const float f = v[i];
-    if (!(f >= 0.f && f <= 255.f) || f != (float)(int)f) return false;
+// float descriptors -> bytes, rows padded with zeros to Dp; *not_bytes is raised when a value is not a whole number
+// in 0..255 (the byte kernels' result is then discarded and the float kernel runs)
+__global__ __launch_bounds__(256) void pack_bytes_kernel(const float* __restrict__ in, int n, int D, int Dp,
+                                                         uint8_t* __restrict__ out, unsigned* __restrict__ not_bytes) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n * Dp) return;
+  const int row = (int)(i / Dp), k = (int)(i - (size_t)row * Dp);
+  uint8_t b = 0;
+  if (k < D) {
+    const float f = in[(size_t)row * D + k];
+    if (!(f >= 0.f && f <= 255.f) || f != (float)(int)f) atomicOr(not_bytes, 1u);
+    else b = (uint8_t)f;
   }
-  return true;
+  out[i] = b;
+}
+
+// ratio test (harris.py:250-258, sift.py:45-52): m.distance < ratio * n.distance on float32 distances, then the
+// train index goes to the first query that asks for it.  One workgroup; pairs come out in query order.
+constexpr int RU_T = 1024;
+__global__ __launch_bounds__(RU_T) void ratio_unique_kernel(const int* __restrict__ best, const double* __restrict__ d2, int nq,
+                                                            double ratio, int* __restrict__ owner /* nt, preset to INT_MAX */,
+                                                            int* __restrict__ pairs, int* __restrict__ n_pairs) {
+  __shared__ int s_scan[RU_T];
+  __shared__ int s_base;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nq; i += RU_T) {
+    const int b0 = best[2 * i], b1 = best[2 * i + 1];
+    if (b0 < 0 || b1 < 0) continue;
+    const float m = sqrtf((float)d2[2 * i]), sd = sqrtf((float)d2[2 * i + 1]);
+    if ((double)m < ratio * (double)sd) atomicMin(&owner[b0], i);
+  }
+  if (tid == 0) s_base = 0;
+  __threadfence();
+  __syncthreads();
+  for (int base = 0; base < nq; base += RU_T) {
+    const int i = base + tid;
+    int keep = 0, b0 = -1;
+    if (i < nq) {
+      b0 = best[2 * i];
+      const int b1 = best[2 * i + 1];
+      if (b0 >= 0 && b1 >= 0) keep = __hip_atomic_load(&owner[b0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i ? 1 : 0;
+    }
+    s_scan[tid] = keep;
+    __syncthreads();
+    for (int off = 1; off < RU_T; off <<= 1) {
+      const int add = tid >= off ? s_scan[tid - off] : 0;
+      __syncthreads();
+      s_scan[tid] += add;
+      __syncthreads();
+    }
+    const int pos = s_base + s_scan[tid] - keep;
+    if (keep) {
+      pairs[2 * pos] = i;
+      pairs[2 * pos + 1] = b0;
+    }
+    __syncthreads();
+    if (tid == RU_T - 1) s_base += s_scan[tid];
+    __syncthreads();
+  }
+  if (tid == 0) *n_pairs = s_base;
 }
 
 }  // namespace
@@ -323,22 +379,42 @@ int vo_match_knn2_ratio(vo_ctx* ctx, const float* q, int nq, const float* t, int
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   vo_buf* s = ctx->scratch;
-  std::vector<int32_t> best((size_t)nq * 2);
-  std::vector<double> d2((size_t)nq * 2);
+  const size_t qbytes = (size_t)nq * D * 4, tbytes = (size_t)nt * D * 4;
+  const bool bytes_fit = (size_t)D * 255 * 255 < (1ull << 31);
+  const bool mfma = D == 128 || D == 361;               // the reference's two descriptor lengths (sift.py, harris.py)
+  const int Dp = mfma ? (D + 31) & ~31 : (D + 3) & ~3;
+  VO_TRY(vo_ensure(ctx, s[0], (size_t)nq * Dp));
+  VO_TRY(vo_ensure(ctx, s[1], (size_t)nt * Dp));
   VO_TRY(vo_ensure(ctx, s[2], (size_t)nq * 8));
   VO_TRY(vo_ensure(ctx, s[3], (size_t)nq * 16));
-  if (all_bytes(q, (size_t)nq * D) && all_bytes(t, (size_t)nt * D) && (size_t)D * 255 * 255 < (1ull << 31)) {
-    const bool mfma = D == 128 || D == 361;               // the reference's two descriptor lengths (sift.py, harris.py)
-    const int Dp = mfma ? (D + 31) & ~31 : (D + 3) & ~3;
-    std::vector<uint8_t> qb((size_t)nq * Dp, 0), tb((size_t)nt * Dp, 0);
-    for (int i = 0; i < nq; ++i)
-      for (int k = 0; k < D; ++k) qb[(size_t)i * Dp + k] = (uint8_t)q[(size_t)i * D + k];
-    for (int i = 0; i < nt; ++i)
-      for (int k = 0; k < D; ++k) tb[(size_t)i * Dp + k] = (uint8_t)t[(size_t)i * D + k];
-    VO_TRY(vo_ensure(ctx, s[0], qb.size()));
-    VO_TRY(vo_ensure(ctx, s[1], tb.size()));
-    VO_HIP_TRY(ctx, hipMemcpyAsync(s[0].p, qb.data(), qb.size(), hipMemcpyHostToDevice, st));
-    VO_HIP_TRY(ctx, hipMemcpyAsync(s[1].p, tb.data(), tb.size(), hipMemcpyHostToDevice, st));
+  VO_TRY(vo_ensure(ctx, s[5], qbytes));
+  VO_TRY(vo_ensure(ctx, s[6], tbytes));
+  VO_TRY(vo_ensure(ctx, s[7], (size_t)nt * 4));           // owner of every train index
+  VO_TRY(vo_ensure(ctx, s[8], (size_t)nq * 8 + 16));      // pairs, then [n_pairs, not_bytes]
+  // descriptors go up as they are (through the pinned staging buffer); packing happens on the device
+  VO_TRY(vo_ensure_pinned(ctx, qbytes + tbytes));
+  memcpy(ctx->h_pin, q, qbytes);
+  memcpy((char*)ctx->h_pin + qbytes, t, tbytes);
+  VO_HIP_TRY(ctx, hipMemcpyAsync(s[5].p, ctx->h_pin, qbytes, hipMemcpyHostToDevice, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(s[6].p, (char*)ctx->h_pin + qbytes, tbytes, hipMemcpyHostToDevice, st));
+  int* d_pairs = (int*)s[8].p;
+  int* d_n = d_pairs + (size_t)nq * 2;
+  unsigned* d_flag = (unsigned*)(d_n + 1);
+  VO_HIP_TRY(ctx, hipMemsetAsync(d_n, 0, 8, st));
+  auto filter = [&]() -> int {
+    VO_HIP_TRY(ctx, hipMemsetAsync(s[7].p, 0x7f, (size_t)nt * 4, st));     // 0x7f7f7f7f: above every query index
+    hipLaunchKernelGGL(ratio_unique_kernel, dim3(1), dim3(RU_T), 0, st, (const int*)s[2].p, (const double*)s[3].p, nq, ratio,
+                       (int*)s[7].p, d_pairs, d_n);
+    return vo_check_launch(ctx, "ratio_unique_kernel");
+  };
+  int host[2] = {0, 0};
+  bool float_path = !bytes_fit;
+  if (bytes_fit) {
+    hipLaunchKernelGGL(pack_bytes_kernel, dim3((unsigned)(((size_t)nq * Dp + 255) / 256)), dim3(256), 0, st,
+                       (const float*)s[5].p, nq, D, Dp, (uint8_t*)s[0].p, d_flag);
+    hipLaunchKernelGGL(pack_bytes_kernel, dim3((unsigned)(((size_t)nt * Dp + 255) / 256)), dim3(256), 0, st,
+                       (const float*)s[6].p, nt, D, Dp, (uint8_t*)s[1].p, d_flag);
+    VO_TRY(vo_check_launch(ctx, "pack_bytes_kernel"));
     const size_t lds = (size_t)QB * (Dp / 4) * 4 + (size_t)QB * MT * 2 * 8;
     // MFMA form: enough workgroups to fill the chip -- the train set is split while a share keeps >= 4 tiles of 32
     const int qblocks = vo_cdiv(nq, 32), ttiles = vo_cdiv(nt, 32);
@@ -366,30 +442,21 @@ int vo_match_knn2_ratio(vo_ctx* ctx, const float* q, int nq, const float* t, int
                            (const uint8_t*)s[1].p, nt, Dp, (int*)s[2].p, (double*)s[3].p);
     }
     VO_TRY(vo_check_launch(ctx, "knn2 kernel"));
-    VO_HIP_TRY(ctx, hipStreamSynchronize(st));   // host staging vectors go out of scope below
-  } else {
-    VO_TRY(vo_ensure(ctx, s[0], (size_t)nq * D * 4));
-    VO_TRY(vo_ensure(ctx, s[1], (size_t)nt * D * 4));
-    VO_HIP_TRY(ctx, hipMemcpyAsync(s[0].p, q, (size_t)nq * D * 4, hipMemcpyHostToDevice, st));
-    VO_HIP_TRY(ctx, hipMemcpyAsync(s[1].p, t, (size_t)nt * D * 4, hipMemcpyHostToDevice, st));
-    VO_TRY(vo_knn2_dev(ctx, (const float*)s[0].p, nq, (const float*)s[1].p, nt, D, (int32_t*)s[2].p, (double*)s[3].p));
+    VO_TRY(filter());
+    VO_HIP_TRY(ctx, hipMemcpyAsync(host, d_n, 8, hipMemcpyDeviceToHost, st));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+    float_path = host[1] != 0;                             // some value was no byte: the result above does not count
   }
-  VO_HIP_TRY(ctx, hipMemcpyAsync(best.data(), s[2].p, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
-  VO_HIP_TRY(ctx, hipMemcpyAsync(d2.data(), s[3].p, (size_t)nq * 16, hipMemcpyDeviceToHost, st));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
-  // ratio test + first-come uniqueness, queries in order (harris.py:250-258, sift.py:45-52)
-  std::vector<uint8_t> used((size_t)nt, 0);
-  int n = 0;
-  for (int i = 0; i < nq; ++i) {
-    const int b0 = best[2 * i], b1 = best[2 * i + 1];
-    if (b0 < 0 || b1 < 0) continue;
-    const float m = sqrtf((float)d2[2 * i]), sd = sqrtf((float)d2[2 * i + 1]);
-    if ((double)m < ratio * (double)sd && !used[b0]) {
-      pairs[2 * n] = i;
-      pairs[2 * n + 1] = b0;
-      used[b0] = 1;
-      ++n;
-    }
+  if (float_path) {
+    VO_TRY(vo_knn2_dev(ctx, (const float*)s[5].p, nq, (const float*)s[6].p, nt, D, (int32_t*)s[2].p, (double*)s[3].p));
+    VO_TRY(filter());
+    VO_HIP_TRY(ctx, hipMemcpyAsync(host, d_n, 4, hipMemcpyDeviceToHost, st));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
+  const int n = host[0];
+  if (n > 0) {
+    VO_HIP_TRY(ctx, hipMemcpyAsync(pairs, d_pairs, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   }
   *n_pairs = n;
   return VO_OK;
