@@ -278,7 +278,7 @@ def cfg3_main(args):
                                   "brute-force L2 2-NN + 0.8 ratio + uniqueness against the previous frame, host entry "
                                   "points (PCIe-inclusive: 1.7 MB up, ~1 MB of keypoints / descriptors down per frame)",
                       "keypoints": n_desc, "matches_median": int(np.median([c[1] for c in counts]))},
-           "roofline": {"bound": "hbm", "kernel": "sift_scale_space (all blur / DoG / decimate launches of a frame)",
+           "roofline": {"bound": "hbm", "kernel": "sift_scale_space (upsample, fused row+column blurs, decimations; the octaves' last two layers and extrema searches on a second stream, inside the same bracket)",
                         "avg_launch_us": None if ss_us is None else round(ss_us, 1), "algorithmic_bytes_per_launch": int(ss_bytes),
                         "achieved": None if not ss_us else round(ss_bytes / (ss_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": None if not ss_us else round(ss_bytes / (ss_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),

@@ -885,34 +885,51 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
     }
   }
   auto grid2 = [](int w, int h) { return dim3(vo_cdiv(w, 64), vo_cdiv(h, 4)); };
-  auto blur = [&](const float* src, int h, int w, const taps_t& t, float* dst) {
+  auto blur = [&](hipStream_t on, const float* src, int h, int w, const taps_t& t, float* dst) {
     const size_t lds = (size_t)(BT_H + 2 * t.r) * (2 * BT_W + 2 * t.r) * 4;
     const dim3 grid(vo_cdiv(w, BT_W), vo_cdiv(h, BT_H));
     switch (t.r) {   // the radii of cv2.SIFT_create()'s default sigma
-      case 5: hipLaunchKernelGGL(blur2d_kernel<5>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
-      case 6: hipLaunchKernelGGL(blur2d_kernel<6>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
-      case 8: hipLaunchKernelGGL(blur2d_kernel<8>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
-      case 10: hipLaunchKernelGGL(blur2d_kernel<10>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
-      case 13: hipLaunchKernelGGL(blur2d_kernel<13>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
-      default: hipLaunchKernelGGL(blur2d_kernel<0>, grid, dim3(256), lds, st, src, h, w, t, dst); break;
+      case 5: hipLaunchKernelGGL(blur2d_kernel<5>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
+      case 6: hipLaunchKernelGGL(blur2d_kernel<6>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
+      case 8: hipLaunchKernelGGL(blur2d_kernel<8>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
+      case 10: hipLaunchKernelGGL(blur2d_kernel<10>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
+      case 13: hipLaunchKernelGGL(blur2d_kernel<13>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
+      default: hipLaunchKernelGGL(blur2d_kernel<0>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
     }
   };
+  // Octave o + 1 starts from layer NOL of octave o: the chain  base -> g1..g3 -> decimate -> g1..g3 -> ...  is the
+  // critical path (the small octaves are a launch latency each); the last two layers of every octave and its extrema
+  // search run beside it on a second stream.
+  if (!ctx->aux_stream) VO_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  while ((int)ctx->aux_events.size() < MAX_OCT + 1) {
+    hipEvent_t e;
+    VO_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->aux_events.push_back(e);
+  }
+  hipStream_t sb = ctx->aux_stream;
+  const float threshold = std::floor(0.5f * contrast_thr / NOL * 255.f);
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_SCALESPACE);
     // base image: doubled, blurred to sigma
     float* up = const_cast<float*>(oct[0].g[1]);   // scratch until g[1] is produced
     hipLaunchKernelGGL(upsample2_kernel, grid2(W0, H0), dim3(256), 0, st, (const uint8_t*)ctx->img.p, H, W, up);
-    blur(up, H0, W0, taps[0], const_cast<float*>(oct[0].g[0]));
+    blur(st, up, H0, W0, taps[0], const_cast<float*>(oct[0].g[0]));
     for (int o = 0; o < n_oct; ++o) {
       const int w = oct[o].W, h = oct[o].H;
       if (o > 0)
         hipLaunchKernelGGL(decimate_kernel, grid2(w, h), dim3(256), 0, st, oct[o - 1].g[NOL], oct[o - 1].W, h, w,
                            const_cast<float*>(oct[o].g[0]));
-      for (int i = 1; i < NG; ++i) blur(oct[o].g[i - 1], h, w, taps[i], const_cast<float*>(oct[o].g[i]));
+      for (int i = 1; i <= NOL; ++i) blur(st, oct[o].g[i - 1], h, w, taps[i], const_cast<float*>(oct[o].g[i]));
+      VO_HIP_TRY(ctx, hipEventRecord(ctx->aux_events[o], st));
+      VO_HIP_TRY(ctx, hipStreamWaitEvent(sb, ctx->aux_events[o], 0));
+      for (int i = NOL + 1; i < NG; ++i) blur(sb, oct[o].g[i - 1], h, w, taps[i], const_cast<float*>(oct[o].g[i]));
+      hipLaunchKernelGGL(extrema_kernel, grid2(w, h), dim3(256), 0, sb, oct[o], threshold, (int4*)ctx->scratch[0].p,
+                         d_cnt + C_CAND, cap_cand);
     }
+    VO_HIP_TRY(ctx, hipEventRecord(ctx->aux_events[MAX_OCT], sb));
+    VO_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->aux_events[MAX_OCT], 0));
   }
   VO_TRY(vo_check_launch(ctx, "sift scale space"));
-  const float threshold = std::floor(0.5f * contrast_thr / NOL * 255.f);
   skp_t* d_kps = (skp_t*)ctx->scratch[1].p;
   surv_t* d_surv = (surv_t*)ctx->scratch[4].p;
   unsigned* d_sel = (unsigned*)ctx->scratch[6].p;
@@ -922,9 +939,6 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   for (int o = 0; o < n_oct; ++o) OS.o[o] = oct[o];
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_DETECT);
-    for (int o = 0; o < n_oct; ++o)
-      hipLaunchKernelGGL(extrema_kernel, grid2(oct[o].W, oct[o].H), dim3(256), 0, st, oct[o], threshold,
-                         (int4*)ctx->scratch[0].p, d_cnt + C_CAND, cap_cand);
     // counts stay on the device: fixed grids, every kernel strides over what the one before it produced
     hipLaunchKernelGGL(refine_kernel, dim3(1024), dim3(256), 0, st, OS, (const int4*)ctx->scratch[0].p, d_cnt + C_CAND,
                        cap_cand, contrast_thr, edge_thr, sigma, (unsigned long long*)ctx->scratch[5].p, table_len - 1,

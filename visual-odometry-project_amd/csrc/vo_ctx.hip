@@ -96,6 +96,8 @@ void vo_destroy(vo_ctx* c) {
     (void)hipEventDestroy(p.b);
   }
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->aux_events) (void)hipEventDestroy(e);
+  if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

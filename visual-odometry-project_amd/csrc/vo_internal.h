@@ -54,6 +54,8 @@ struct vo_ctx {
   float* nms_kp_f32 = nullptr;   // optional: the NMS also writes its keypoints as float pairs here (device)
   vo_buf scratch[16];
   vo_buf match_arrived;          // knn2_mfma_kernel's per-query-block arrival counters (zero between calls)
+  hipStream_t aux_stream = nullptr;            // vo_sift: the octaves' last two layers and extrema run beside the next octave
+  std::vector<hipEvent_t> aux_events;
   vo_buf sift_arena;
   // pinned host staging
   void* h_pin = nullptr;
