@@ -69,21 +69,25 @@ def algorithmic_bytes(kernel_name, n_in, n_tracked, n_tri):
         "pyr_down": 2 * px + px // 4 + px // 16,              # frame read, bordered copy of level 0, levels 1 and 2 written
         "klt_track": n_in * levels * ((WIN + 3) ** 2 + (WIN + 1) ** 2) + n_in * (8 + 8 + 1 + 4),
         "state_regroup": n_in * (8 + 1 + 4 + 1) + n_tracked * 2 * feat,
-        "p3p_solve": HYP * (28 + 4 * 40 + 96 + 1),
+        "p3p_solve": HYP * (28 + 4 * 40 + 96 + 1) + n_tri * 40 + HYP * (4 + ((n_tri + 63) // 64) * 8),   # solve + score in one launch
         "p3p_score": n_tri * 40 + HYP * (96 + 1 + 4 + ((n_tri + 63) // 64) * 8),
         "ransac_replay": HYP * 5 + 96 + ((n_tri + 63) // 64) * 16,
         "refine_pose": n_tri * 40 + ((n_tri + 63) // 64) * 8 + 96 + 120,
         "state_candidates": n_tracked * (16 + 1 + 16 + 96 + 1) + ((n_tri + 63) // 64) * 8,
         "state_landmarks": n_tracked * (1 + 1 + 24 + 16 + 96 + 24),
     }
+    # the frame loop's pose kernel (kernel id "refine_pose"): replay + refinement + candidates + landmark stage in one launch
+    table["refine_pose"] = table["ransac_replay"] + table["refine_pose"] + table["state_candidates"] + table["state_landmarks"]
     return table.get(kernel_name)
 
 
+KERNEL_LABEL = {"refine_pose": "frame_pose (RANSAC replay + pose refinement + State bookkeeping + candidate DLT + record, one workgroup)",
+                "p3p_solve": "p3p_hyp (P3P solve + inlier counts of all hypotheses)"}
 ROCPROF_NAMES = {"klt_track": "klt_track16_kernel<15, 16>", "nms_round": "nms_round_kernel<5, true>",
                  "nms_candidates": "nms_candidates_kernel<5>", "harris_response": "harris_response_kernel<9>",
-                 "p3p_solve": "p3p_solve_kernel<true>", "p3p_score": "p3p_score_kernel", "nms_compact": "nms_compact_kernel",
-                 "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel", "refine_pose": "refine_pose_kernel",
-                 "pyr_down": "pyramid3_tiled_kernel", "state_regroup": "state_regroup_klt_kernel",
+                 "p3p_solve": "p3p_hyp_kernel<8>", "p3p_score": "p3p_score_kernel", "nms_compact": "nms_compact_kernel",
+                 "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel", "refine_pose": "frame_pose_kernel",
+                 "pyr_down": "pyramid3_tiled_kernel<32, 16>", "state_regroup": "state_regroup_klt_kernel",
                  "ransac_replay": "ransac_replay_kernel", "state_candidates": "state_candidates_kernel",
                  "state_landmarks": "state_landmarks_kernel"}
 
@@ -481,7 +485,7 @@ def main():
             return None if v is None else v * S
 
         ab = abytes(dom_name)
-        roof = {"bound": "hbm", "kernel": dom_name, "avg_launch_us": round(avg_us, 3), "launches": dom_n,
+        roof = {"bound": "hbm", "kernel": KERNEL_LABEL.get(dom_name, dom_name), "avg_launch_us": round(avg_us, 3), "launches": dom_n,
                 "algorithmic_bytes_per_launch": ab, "sequences_per_launch": S, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "traffic": pmc_traffic(dom_name) if S == 1 else None}
         if ab and avg_us > 0:
