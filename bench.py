@@ -509,11 +509,13 @@ def main():
             gt = np.linalg.inv(stream.T_world_cam(0)) @ stream.T_world_cam(b)
             gt_err.append((float(np.linalg.norm(Twc[:3, :3] - gt[:3, :3])), float(np.linalg.norm(scale * Twc[:3, 3] - gt[:3, 3]))))
         # device clock (100 MHz) stamps the kernels of the chain leave in every record: where a step's time goes
-        ts = np.array([[r.ts[k] for k in range(6)] for r in res], dtype=np.float64) * 1e-2          # us
+        ts = np.array([[r.ts[k] for k in range(8)] for r in res], dtype=np.float64) * 1e-2          # us
         chain = {"tracker_start_to_regroup_start": float(np.median(ts[:, 1] - ts[:, 0])),
                  "regroup_to_hypotheses": float(np.median(ts[:, 2] - ts[:, 1])),
                  "hypotheses_to_pose": float(np.median(ts[:, 3] - ts[:, 2])),
                  "pose_to_landmarks": float(np.median(ts[:, 4] - ts[:, 3])),
+                 "pose_kernel_replay_refine_candidates": [float(np.median(ts[:, 6] - ts[:, 3])), float(np.median(ts[:, 7] - ts[:, 6])),
+                                                          float(np.median(ts[:, 4] - ts[:, 7]))],
                  "landmarks_to_record": float(np.median(ts[:, 5] - ts[:, 4])),
                  "record_to_next_regroup": float(np.median(ts[1:, 1] - ts[:-1, 5])),
                  "regroup_to_next_tracker_start": float(np.median(ts[1:, 0] - ts[:-1, 1])),
@@ -522,7 +524,7 @@ def main():
                  "step_period_percentiles_10_50_90_99": [float(v) for v in np.percentile(np.diff(ts[:, 1]), [10, 50, 90, 99])],
                  "slow_steps": [{"i": int(i), "period": float(v), "redetected": [int(res[i].redetected), int(res[i + 1].redetected)],
                                  "n_in": [int(res[i].n_features_in), int(res[i + 1].n_features_in)],
-                                 "stages_i": [float(x) for x in np.diff(ts[i])], "stages_i1": [float(x) for x in np.diff(ts[i + 1])],
+                                 "stages_i": [float(x) for x in np.diff(ts[i, :6])], "stages_i1": [float(x) for x in np.diff(ts[i + 1, :6])],
                                  "rec_to_regroup": float(ts[i + 1, 1] - ts[i, 5])}
                                 for i, v in enumerate(np.diff(ts[:, 1])) if v > 400.0][:10],
                  "record_to_next_regroup_percentiles_10_50_90_99": [float(v) for v in np.percentile(ts[1:, 1] - ts[:-1, 5], [10, 50, 90, 99])],

@@ -356,7 +356,8 @@ typedef struct vo_step_result {
   uint64_t raw_pos;             /* generator outputs consumed so far (32-bit words)   */
   double T_wc[12];              /* camera -> world pose after the step, rows 0..2 (State.curr_pose) */
   uint64_t ts[8];               /* device clock (100 MHz ticks) at the start of: tracker, regroup, hypotheses, pose,
-                                   landmarks kernels, and at the end of the step (the record's last write)      */
+                                   landmark stage, at the end of the step (the record's last write); [6], [7]:
+                                   inside the pose kernel, RANSAC replay done / refinement done               */
   uint32_t seq_head, seq_tail;  /* internal: the record is complete when both equal the step's sequence number */
 } vo_step_result;
 int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out);

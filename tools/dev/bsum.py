@@ -12,5 +12,5 @@ for f in sys.argv[1:]:
     print("  kernels", d["per_kernel_us"])
     print("  streaming", {k: (v["avg_launch_us"], v["frac"]) for k, v in d["roofline_streaming"].items()})
     c = d["chain_us"]
-    print("  chain", {k: round(c[k], 1) for k in c if isinstance(c[k], float)})
+    print("  chain", {k: round(c[k], 1) for k in c if isinstance(c[k], float)}, c.get("pose_kernel_replay_refine_candidates"))
     print("  loop", d["loop"])

@@ -351,7 +351,9 @@ int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_
   unsigned ctl[4] = {0, 0, 0, 0};
   VO_HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, 8, hipMemcpyDeviceToHost, st));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));                      // (the sort is sized by the candidate count)
-  const unsigned nc = std::min(ctl[1], cap);
+  if (ctl[1] > cap)      // (ties count as maxima: plateaus can exceed one maximum per 2x2 block)
+    return vo_set_error(ctx, VO_ECAPACITY, "good_features: %u local maxima exceed the candidate capacity %u", ctl[1], cap);
+  const unsigned nc = ctl[1];
   if (nc == 0) return VO_OK;
   unsigned long long* d_sorted = (unsigned long long*)s[3].p;
   VO_HIP_TRY(ctx, rocprim::radix_sort_keys_desc(s[4].p, sort_tmp, (unsigned long long*)s[2].p, d_sorted, (size_t)nc, 0, 64, st));

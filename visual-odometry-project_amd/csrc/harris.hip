@@ -1435,7 +1435,7 @@ int vo_harris_response_batch_dev(vo_ctx* ctx, const uint8_t* d_img, size_t img_s
   dim3 grid(vo_cdiv(W, RX), vo_cdiv(H, RY), S);
   size_t lds = response_lds_bytes(patch);
   {
-    static bool lds_opt_in = false;   // dynamic LDS above 64 KiB must be requested per kernel
+    bool& lds_opt_in = ctx->lds_opt_in[0];   // dynamic LDS above 64 KiB must be requested per kernel (and device)
     if (!lds_opt_in) {
       VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&harris_response_kernel<0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)response_lds_bytes(31)));
@@ -1532,7 +1532,7 @@ int vo_nms_keypoints_batch_dev(vo_ctx* ctx, const double* d_scores, int S, int H
   unsigned* rank = (unsigned*)ctx->nms_rank.p;
   hipStream_t st = ctx->stream;
   {
-    static bool lds_opt_in = false;   // dynamic LDS above 64 KiB must be requested per kernel
+    bool& lds_opt_in = ctx->lds_opt_in[1];   // dynamic LDS above 64 KiB must be requested per kernel (and device)
     if (!lds_opt_in) {
       const int max_dyn = (int)candidates_lds_bytes(12);   // largest radius accepted above
       VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_candidates_kernel<5>),

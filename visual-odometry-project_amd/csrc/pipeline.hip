@@ -529,6 +529,8 @@ static vo_pose_job make_pose_job(vo_pipeline* p, const vo_feat& B, int do_replay
   j.res = nullptr;
   j.seq_word = nullptr;
   j.seq = 0u;
+  static const int stamps = getenv("VO_POSE_STAMPS") ? 1 : 0;
+  j.stamps = stamps;
   return j;
 }
 

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   __syncthreads();
   if (job.do_replay && wv == 0) replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table);
   __syncthreads();
+  if (tid == 0 && job.stamps) ctl->ts[5] = wall_clock64();
   if (ctl->fault) {                             // (raised by the replay: the host finishes this step)
     if (job.tail && job.res && tid == 0) {
       ctl->ts[4] = wall_clock64();
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
     if (lane == 0) {
       ctl->refined[12] = (double)(it < 0 ? 0 : it);
       ctl->refined[13] = cost;
+      if (job.stamps) ctl->ts[7] = wall_clock64();
     }
   }
   // ---- the new pose, both ways (update_with_world_pose, state.py:38-50), then every feature ----

@@ -270,6 +270,8 @@ __device__ __forceinline__ void write_step_record(vo_seq_ctl* __restrict__ ctl, 
     for (int k = 1; k < 4; ++k) res->ts[k] = ctl->ts[k];
     res->ts[4] = ts4;
     res->ts[5] = wall_clock64();
+    res->ts[6] = ctl->ts[5];     // inside the pose kernel: the RANSAC replay is done ...
+    res->ts[7] = ctl->ts[7];     // ... the refinement is done
   }
   __threadfence_system();
   __syncthreads();

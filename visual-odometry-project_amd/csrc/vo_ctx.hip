@@ -13,6 +13,7 @@ int vo_set_error(vo_ctx* ctx, int code, const char* fmt, ...) {
 
 int vo_ensure(vo_ctx* ctx, vo_buf& b, size_t bytes) {
   if (bytes <= b.cap) return VO_OK;
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));     // (a process may hold contexts on several GPUs: allocate on this one's)
   // growing an allocation: the old one may still be in use by queued kernels
   VO_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (b.p) VO_HIP_TRY(ctx, hipFree(b.p));

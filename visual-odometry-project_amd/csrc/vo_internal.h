@@ -54,6 +54,7 @@ struct vo_ctx {
   float* nms_kp_f32 = nullptr;   // optional: the NMS also writes its keypoints as float pairs here (device)
   vo_buf scratch[16];
   vo_buf match_arrived;          // knn2_mfma_kernel's per-query-block arrival counters (zero between calls)
+  bool lds_opt_in[2] = {false, false};         // hipFuncSetAttribute is per device: remembered per context (response, NMS)
   hipStream_t aux_stream = nullptr;            // vo_sift: the octaves' last two layers and extrema run beside the next octave
   std::vector<hipEvent_t> aux_events;
   vo_buf sift_arena;

@@ -122,6 +122,7 @@ struct vo_pose_job {
   vo_step_result* res;  // mapped host memory (sequence q: res + q), may be NULL
   unsigned* seq_word;
   unsigned seq;
+  int stamps;           // debug: device-clock stamps after the replay and after the refinement (record ts[6], ts[7])
 };
 int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job, int S = 1);   // S > 1: sequence q uses block q of every array
 

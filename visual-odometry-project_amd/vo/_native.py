@@ -342,7 +342,7 @@ class Context:
         img = _c(img, np.uint8)
         H, W = img.shape
         m = None if mask is None else _c(mask, np.uint8)
-        cap = max_corners if max_corners > 0 else (H * W) // 4 + 64
+        cap = max_corners if max_corners > 0 else (H * W + 3) // 4 + 64     # (the C side's candidate capacity)
         xy = np.empty((cap, 2), np.float32)
         n = C.c_int32(0)
         self._chk(self._lib.vo_good_features(self._h, _ptr(img), H, W, _ptr(m), int(max_corners), float(quality),
