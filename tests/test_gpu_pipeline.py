@@ -158,10 +158,10 @@ def test_pipeline_lookahead_and_host_recovery_match_blocking_steps(ctx):
 
     ref, st_ref, g_ref = run(False)
     assert all(r.recovered == 0 for r in ref)
-    # detect_margin: < 0 = the detector runs on every frame; tiny = it runs only once the count is AT the re-detect
-    # limit, so the step that crosses the limit finds no keypoints and is finished through the host path
+    # detect_margin < 0: the detector runs on every frame; debug_never_detect: never ahead of time, so the step that
+    # crosses the re-detect limit finds no keypoints and is finished through the host path (which runs the detector)
     for la, kw in ((True, {}), (False, dict(debug_fault_every=3)), (True, dict(debug_fault_every=3)),
-                   (True, dict(detect_margin=-1.0)), (False, dict(detect_margin=1e-6)), (True, dict(detect_margin=1e-6))):
+                   (True, dict(detect_margin=-1.0)), (False, dict(debug_never_detect=1)), (True, dict(debug_never_detect=1))):
         got, st, g = run(la, **kw)
         for k, (a, b) in enumerate(zip(got, ref)):
             fa, fb = fields(a), fields(b)
@@ -169,7 +169,7 @@ def test_pipeline_lookahead_and_host_recovery_match_blocking_steps(ctx):
                               [(i, fa[i], fb[i]) for i in range(len(fa)) if fa[i] != fb[i]][:3])
         if "debug_fault_every" in kw:
             assert sum(r.recovered for r in got) == len(pairs) // 3
-        if kw.get("detect_margin", 0) > 0:
+        if kw.get("debug_never_detect"):
             assert any(r.redetected and r.recovered for r in got), "the skipped-detection path was meant to run"
         assert g == g_ref
         for k in ("keypoints", "state", "candidate_mask", "landmarks", "tracks", "poses", "curr_pose"):

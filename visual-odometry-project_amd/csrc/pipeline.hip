@@ -129,13 +129,18 @@ __global__ __launch_bounds__(256) void export_state_kernel(pose17 head, const do
   if (i < m) rec[17 + i] = land[i];
 }
 
-// does sequence q need the detector on the frame being submitted?  (the count is the one of the frame before, or
-// already this frame's when the step's regroup has run: either is within one frame of the count that decides)
-__global__ __launch_bounds__(64) void detect_decide_kernel(const vo_seq_ctl* __restrict__ ctl, int S, double limit, int force,
-                                                           int* __restrict__ go) {
+// Does sequence q need the detector on the frame being submitted?  The count that decides is known one step later;
+// what is known now is the count of the frame before (or already this frame's, when the step's regroup has run) and
+// how many tracks the last step lost: the detector runs when the count, extrapolated by four such losses, is below
+// (redetect_fraction + detect_margin) * num_features.  (The fields are read while a regroup may be writing them: any
+// mix of old and new values is a usable guess, and a wrong guess is caught by the step that needs the keypoints.)
+__global__ __launch_bounds__(64) void detect_decide_kernel(const vo_seq_ctl* __restrict__ ctl, int S, double limit, int n_det,
+                                                           int force, int* __restrict__ go) {
   const int q = blockIdx.x * 64 + threadIdx.x;
   if (q >= S) return;
-  go[q] = (force || limit < 0.0 || (double)ctl[q].n2 < (double)ctl[q].num_features * limit) ? 1 : 0;
+  const int n2 = ctl[q].n2;
+  const int lost = max(ctl[q].n_in - (ctl[q].redetected ? n_det : 0) - n2, 0);
+  go[q] = (force || limit < 0.0 || (limit > 0.0 && (double)(n2 - 4 * lost) < (double)ctl[q].num_features * limit)) ? 1 : 0;
 }
 
 template <typename T>
@@ -284,8 +289,9 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   const int S = p->S;
   if (p->cfg.bearing_threshold == 0.0) p->cfg.bearing_threshold = 0.0075;    // state.py:8
   if (p->cfg.redetect_fraction == 0.0) p->cfg.redetect_fraction = 0.8;       // klt.py:212
-  if (p->cfg.detect_margin == 0.0) p->cfg.detect_margin = 0.1;
+  if (p->cfg.detect_margin == 0.0) p->cfg.detect_margin = 0.02;
   p->detect_limit = p->cfg.detect_margin < 0.0 ? -1.0 : p->cfg.redetect_fraction + p->cfg.detect_margin;
+  if (p->cfg.debug_never_detect) p->detect_limit = 0.0;     // test hook: only forced detections (state hand-over, host path)
   memcpy(p->cam.K, cfg->K, sizeof(p->cam.K));
   {
     bool given = false;
@@ -458,7 +464,7 @@ static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force) {
   det->nms_kp_f32 = nullptr;
   int* go = p->d_det_go + (size_t)s * p->S;
   hipLaunchKernelGGL(detect_decide_kernel, dim3(vo_cdiv(p->S, 64)), dim3(64), 0, det->stream, p->d_ctl, p->S, p->detect_limit,
-                     force ? 1 : 0, go);
+                     c.n_keypoints, force ? 1 : 0, go);
   int rc = vo_check_launch(det, "detect_decide_kernel");
   if (rc == VO_OK)
     rc = vo_harris_response_batch_dev(det, p->img(0, frame), p->img_stride(), p->S, c.H, c.W, c.harris_patch, c.harris_kappa,
