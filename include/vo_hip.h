@@ -354,7 +354,8 @@ typedef struct vo_step_result {
   int32_t fault;                /* internal: reason the step left the device-only path */
   int32_t recovered;            /* 1: the step was finished through the host path     */
   int32_t detector_ran;         /* 1: the detector was executed on this step's `prev` frame (detect_margin) */
-  int32_t reserved;
+  int32_t reserved;             /* recovered steps: the reason as fault bits (1 few landmarks, 2 a draw NumPy might have
+                                   rejected, 4 rule not done after `hyp` samples, 8 capacity, 16 forced, 32 detector skipped) */
   uint64_t raw_pos;             /* generator outputs consumed so far (32-bit words)   */
   double T_wc[12];              /* camera -> world pose after the step, rows 0..2 (State.curr_pose) */
   uint64_t ts[8];               /* device clock (100 MHz ticks) at the start of: tracker, regroup, hypotheses, pose,

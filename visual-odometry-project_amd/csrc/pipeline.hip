@@ -51,6 +51,9 @@ struct vo_pipeline {
   int* d_det_go = nullptr;           // [3][S]: 1 = the detector ran for that sequence on the frame in keypoint slot s
   double detect_limit = 0.0;         // detect when n < detect_limit * num_features (< 0: always)
   hipEvent_t evPyr[3] = {nullptr, nullptr, nullptr}, evDet[3] = {nullptr, nullptr, nullptr};
+  // frame upload: pinned staging per (sequence, frame slot), allocated on first use; evImg[idx]: slot idx is in HBM
+  std::vector<uint8_t*> h_img;
+  std::vector<hipEvent_t> evImg;
   int slot = 0, det_flip = 0, prev_frame = -1;
   // Features double buffer: a step reads F[cur] (frame k-1) and writes F[1 - cur] (frame k)
   vo_feat F[2];
@@ -252,6 +255,10 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   void* pin[] = {p->h_stage, p->h_res, (void*)p->h_seq};
   for (void* q : pin)
     if (q) (void)hipHostFree(q);
+  for (uint8_t* q : p->h_img)
+    if (q) (void)hipHostFree(q);
+  for (hipEvent_t e : p->evImg)
+    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : {p->evPyr[0], p->evPyr[1], p->evPyr[2], p->evDet[0], p->evDet[1], p->evDet[2], p->evRaw, p->evA, p->evB,
                        p->evKlt[0], p->evKlt[1], p->evRegroup[0], p->evRegroup[1]})
     if (e) (void)hipEventDestroy(e);
@@ -384,6 +391,14 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     vo_pipeline_destroy(p);
     return rc;
   }
+  p->h_img.assign(Sz * cfg->n_frames, nullptr);
+  p->evImg.assign((size_t)cfg->n_frames, nullptr);
+  for (hipEvent_t& e : p->evImg)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
+  if (rc != VO_OK) {
+    vo_pipeline_destroy(p);
+    return rc;
+  }
   p->gen_upto.assign(Sz, 0);
   p->pos_known.assign(Sz, 0);
   p->raw_gen.resize(Sz);
@@ -421,9 +436,22 @@ int vo_pipeline_set_frame_seq(vo_pipeline* p, int seq, int idx, const uint8_t* i
     VO_REQUIRE(ctx, p->flight[k].prev_idx != idx && p->flight[k].next_idx != idx,
                "pipeline_set_frame: slot %d belongs to a step in flight", idx);
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // on the tracker's stream: steps in flight keep running; the caller's buffer is free on return
-  VO_HIP_TRY(ctx, hipMemcpyAsync(p->img(seq, idx), img, p->px, hipMemcpyHostToDevice, p->trk->stream));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(p->trk->stream));
+  // Through a pinned staging buffer of this (sequence, slot), as one DMA queued on the tracker's stream -- in front of
+  // the pyramid that reads the slot; the detector's stream waits for evImg.  The call does not wait for the GPU (the
+  // runtime's pageable-memory path did, and drained the tracker's stream on top: 0.9 ms per frame through the Python
+  // API); the caller's buffer is free on return.
+  uint8_t*& stage = p->h_img[(size_t)seq * p->cfg.n_frames + idx];
+  if (!stage) {
+    hipError_t e = hipHostMalloc((void**)&stage, p->px, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      stage = nullptr;
+      return vo_set_error(ctx, VO_ENOMEM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+  }
+  VO_HIP_TRY(ctx, hipEventSynchronize(p->evImg[idx]));       // (the slot's previous upload has left the staging buffer)
+  memcpy(stage, img, p->px);
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->img(seq, idx), stage, p->px, hipMemcpyHostToDevice, p->trk->stream));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evImg[idx], p->trk->stream));
   return VO_OK;
 }
 
@@ -463,6 +491,8 @@ static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force) {
   double* scores = p->d_scores[p->det_flip];
   det->nms_kp_f32 = nullptr;
   int* go = p->d_det_go + (size_t)s * p->S;
+  if (hipStreamWaitEvent(det->stream, p->evImg[frame], 0) != hipSuccess)     // the frame's upload (tracker's stream)
+    return vo_set_error(p->ctx, VO_EHIP, "detection: hipStreamWaitEvent failed");
   hipLaunchKernelGGL(detect_decide_kernel, dim3(vo_cdiv(p->S, 64)), dim3(64), 0, det->stream, p->d_ctl, p->S, p->detect_limit,
                      c.n_keypoints, force ? 1 : 0, go);
   int rc = vo_check_launch(det, "detect_decide_kernel");
@@ -914,6 +944,7 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   vo_seq_ctl* ctl = p->d_ctl + q;
   vo_seq_ctl h;
   VO_HIP_TRY(ctx, mcpy(st, &h, ctl, sizeof(h), hipMemcpyDeviceToHost));
+  const int fault_reason = h.fault;
   if (h.fault & VO_FAULT_CAPACITY)
     return vo_set_error(ctx, VO_ECAPACITY, "pipeline: %d features + %d new keypoints exceed the capacity %d", h.n,
                         c.n_keypoints, p->cap);
@@ -1019,6 +1050,7 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   }
   VO_TRY(wait_record(p, f.rslot, q, seq, 0, out));
   out->recovered = 1;
+  out->reserved = fault_reason;          // (why the step left the device-only path: VO_FAULT_* bits)
   ++p->n_recovered;
   return VO_OK;
 }

@@ -103,7 +103,8 @@ def _gray(image):
 
 def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int = 2000, klt_win: int = 17,
                   klt_max_level: int = 2, hyp: int = 1000, context=None, verbose: bool = False,
-                  redetect_start_pose: str = "current"):
+                  redetect_start_pose: str = "current", bootstrap_win: int = None, bootstrap_max_level: int = None,
+                  bootstrap_threshold: float = 0.25):
     """Same loop, same bootstrap, but the steady state runs as the device-resident pipeline (vo_pipeline_*):
     after the host bootstrap the Features / State arrays are handed to the GPU once, every later frame costs one
     image upload and one call, and nothing but the pose record comes back.  KLT tracker mode with the Harris
@@ -121,10 +122,14 @@ def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int =
         # the bootstrap tracks Shi-Tomasi corners (the reference's find_corners, klt.py:98), as many as the
         # pipeline's detector keeps per frame
         KLTTracker._feature_params = dict(saved[0], maxCorners=n_keypoints)
-        KLTTracker._lk_params = dict(saved[1], winSize=(klt_win, klt_win), maxLevel=klt_max_level)
+        # (bootstrap_*: the two bootstrap frames are further apart than consecutive ones; on large frames the loop's own
+        #  window and the reference's 0.25 px epipolar threshold can settle on a wrong model, bench.py: bootstrap_state)
+        bw = bootstrap_win or klt_win
+        KLTTracker._lk_params = dict(saved[1], winSize=(bw, bw),
+                                     maxLevel=klt_max_level if bootstrap_max_level is None else bootstrap_max_level)
 
     try:
-        state, tracker, _, _ = bootstrap(sequence, "klt", tracker_setup=setup)
+        state, tracker, _, _ = bootstrap(sequence, "klt", tracker_setup=setup, ransac_threshold=bootstrap_threshold)
     finally:
         KLTTracker._feature_params, KLTTracker._lk_params = saved
     frame = state.curr_frame
