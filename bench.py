@@ -370,7 +370,7 @@ def main():
     pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
                             hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
                             refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, sequences=S,
-                            detect_margin=DETECT_MARGIN)
+                            detect_margin=DETECT_MARGIN, debug_never_detect=int(os.environ.get("VO_BENCH_NEVER_DETECT", "0")))
     states = [bootstrap_state(st) for st in streams]
     state = states[0]
     for q in range(S):
