@@ -17,7 +17,7 @@ for name in ("collect", "set_frame", "submit"):
     setattr(_pipeline.Pipeline, name, wrap)
 ctx = _native.Context(0)
 seq = Sequence("synthetic", n_frames=40, height=1241, width=1376, channels=1)
-r = driver.run_on_device(seq, n_keypoints=2000, klt_win=15, klt_max_level=2, hyp=1000, context=ctx,
+r = driver.run_on_device(seq, n_keypoints=2000, klt_win=15, klt_max_level=2, hyp=int(os.environ.get('HYP', '1000')), context=ctx,
                          bootstrap_win=21, bootstrap_max_level=3, bootstrap_threshold=1.0)
 import collections
 print("recovery reasons", collections.Counter(x.reserved for x in r.get("results", [])))

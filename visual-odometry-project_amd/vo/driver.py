@@ -102,14 +102,15 @@ def _gray(image):
 
 
 def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int = 2000, klt_win: int = 17,
-                  klt_max_level: int = 2, hyp: int = 1000, context=None, verbose: bool = False,
+                  klt_max_level: int = 2, hyp: int = 4000, context=None, verbose: bool = False,
                   redetect_start_pose: str = "current", bootstrap_win: int = None, bootstrap_max_level: int = None,
                   bootstrap_threshold: float = 0.25):
     """Same loop, same bootstrap, but the steady state runs as the device-resident pipeline (vo_pipeline_*):
     after the host bootstrap the Features / State arrays are handed to the GPU once, every later frame costs one
     image upload and one call, and nothing but the pose record comes back.  KLT tracker mode with the Harris
     detector (BASELINE.json configs[1]); P3P-RANSAC as main.py:194-201 configures it (1.25 px, confidence 0.9999)
-    with `hyp` hypotheses solved and scored per frame.  redetect_start_pose: "identity" is the reference's
+    with `hyp` hypotheses solved and scored per launch (a frame whose sequential rule needs more -- main.py allows
+    10000 iterations -- is finished by the host path; with 4000 none of the synthetic stream's frames is).  redetect_start_pose: "identity" is the reference's
     update_features (klt.py:148-153: re-detected keypoints start their track at np.eye(4), so away from the origin
     they triangulate against a wrong baseline and can take the estimate with them); "current" starts them at the
     pose of the frame they were found on."""
