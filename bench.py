@@ -599,6 +599,35 @@ def main():
             out["cpu_baseline"] = base
         if world == 1 and not args.no_api:
             out["api"] = api_leg(ctx)
+        if world == 1 and DETECT_MARGIN >= 0 and not args.no_api:
+            # the same loop with the detector executed on EVERY frame (what rounds 1 and early 2 timed), in the same line
+            pipe.close()
+            pipe2 = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
+                                     hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
+                                     refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, sequences=S, detect_margin=-1.0)
+            for q in range(S):
+                for i in range(N_FRAMES):
+                    pipe2.set_frame(i, streams[q].image(i), seq=q)
+                pipe2.set_state(2, states[q].curr_frame.features, states[q].curr_pose, states[q].prev_pose, num_features=N_KP,
+                                seq=q)
+            order2 = walk(2, N_FRAMES, 1400)
+
+            def run2(p0, n):
+                pipe2.submit(order2[p0], order2[p0 + 1])
+                for k in range(n):
+                    if k + 1 < n:
+                        pipe2.submit(order2[p0 + k + 1], order2[p0 + k + 2])
+                    pipe2.collect_all()
+
+            run2(0, 200)
+            ctx.sync()
+            t2 = time.perf_counter()
+            run2(200, 1000)
+            ctx.sync()
+            out["detector_every_frame"] = {"frames_per_s": round(S * 1000 / (time.perf_counter() - t2), 1), "steps": 1000,
+                                           "note": "same pipeline, same stream, detect_margin < 0: Harris + NMS executed on every "
+                                                   "frame of every sequence instead of within the margin of the re-detect limit"}
+            pipe2.close()
         print(json.dumps(out), flush=True)
     pipe.close()
     ctx.close()
