@@ -47,7 +47,10 @@ constexpr int RY = 32;   // response tile height (four strips of eight rows)
 //   A  image tile + halo -> LDS bytes          (all global loads issued before the first use)
 //   B  Sobel pair, four pixels per work item   (word reads, one 16-byte store)
 //   C  horizontal box sums of Ix^2, Iy^2, IxIy (one lane per column)
-//   D  vertical box sums as running sums down a strip of eight rows, then the fp64 formula
+//   D  vertical box sums as running sums down a strip of rows, then the fp64 formula
+//   (compile-time patch: C and D run twice, over the upper and the lower 16 output rows, so that the three planes
+//    of horizontal sums hold 24 rows instead of 40: 33 KB of LDS per workgroup instead of 45, four workgroups per CU
+//    instead of three -- the kernel is occupancy-bound on its write-out)
 // P_T > 0: patch size known at compile time; P_T == 0: runtime patch size, plain loops.
 struct resp_geom {
   int pr, GW, GWp, GH, IWp, IH;
@@ -80,9 +83,10 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
   const int pr = g.pr, GWp = g.GWp, GH = g.GH, IWp = g.IWp, IH = g.IH;
   uint8_t* s_img = smem;
   int* s_g = reinterpret_cast<int*>(smem + ((IWp * IH + 15) & ~15));   // packed (Ix | Iy << 16), GH x GWp
-  int* s_hxx = s_g + GWp * GH;                                         // GH x RX each
-  int* s_hyy = s_hxx + GH * RX;
-  int* s_hxy = s_hyy + GH * RX;
+  const int HR = P_T > 0 ? RY / 2 + P_T - 1 : GH;                       // rows of horizontal sums held at a time
+  int* s_hxx = s_g + GWp * GH;                                         // HR x RX each
+  int* s_hyy = s_hxx + HR * RX;
+  int* s_hxy = s_hyy + HR * RX;
 
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * RX, y0 = blockIdx.y * RY;
@@ -174,8 +178,10 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
     // in the middle are shared, each output adds one more pair and one single tap.
     constexpr int NW = P_T > 0 ? (P_T + 1) / 2 : 2;   // words (pairs of columns) a work item reads per plane
     const int wpr = GWp >> 1;                   // words per gradient row
-    for (int i = tid; i < GH * (RX / 2); i += NT) {
-      const int ly = i / (RX / 2), q = i - ly * (RX / 2);
+    for (int half = 0; half < 2; ++half) {
+    for (int i = tid; i < HR * (RX / 2); i += NT) {
+      const int lr = i / (RX / 2), q = i - lr * (RX / 2);
+      const int ly = half * (RY / 2) + lr;                     // gradient row of this row of sums
       const unsigned* px = reinterpret_cast<const unsigned*>(s_ix) + ly * wpr + q;
       const unsigned* py = reinterpret_cast<const unsigned*>(s_iy) + ly * wpr + q;
       unsigned wx[NW], wy[NW];
@@ -207,12 +213,57 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
       bxx = __builtin_amdgcn_sdot2(x0h, x0h, bxx, false);
       byy = __builtin_amdgcn_sdot2(y0h, y0h, byy, false);
       bxy = __builtin_amdgcn_sdot2(x0h, y0h, bxy, false);
-      const int o = ly * RX + 2 * q;
+      const int o = lr * RX + 2 * q;
       *reinterpret_cast<int2*>(s_hxx + o) = make_int2(axx, bxx);
       *reinterpret_cast<int2*>(s_hyy + o) = make_int2(ayy, byy);
       *reinterpret_cast<int2*>(s_hxy + o) = make_int2(axy, bxy);
     }
     __syncthreads();
+    // D (packed), this half: vertical sums as running sums down a strip of four rows, then the fp64 formula
+    {
+      const int lx = tid & (RX - 1);
+      const int border = pr + 1;
+      const int gx = x0 + lx;
+      const int ys = (tid / RX) * 4;               // strip of four output rows of this half
+      int vxx[4 + P_T - 1], vyy[4 + P_T - 1], vxy[4 + P_T - 1];
+#pragma unroll
+      for (int k = 0; k < 4 + P_T - 1; ++k) {
+        const int j = (ys + k) * RX + lx;
+        vxx[k] = s_hxx[j];
+        vyy[k] = s_hyy[j];
+        vxy[k] = s_hxy[j];
+      }
+      int sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+      for (int k = 0; k < P_T; ++k) {
+        sxx += vxx[k];
+        syy += vyy[k];
+        sxy += vxy[k];
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int gy = y0 + half * (RY / 2) + ys + o;
+        if (gy < H && gx < W) {
+          double r = 0.0;
+          if (gy >= border && gy < H - border && gx >= border && gx < W - border) {
+            const double dxx = (double)sxx, dyy = (double)syy, dxy = (double)sxy;
+            const double trace = dxx + dyy;
+            const double det = dxx * dyy - dxy * dxy;
+            r = det - kappa * (trace * trace);
+            if (r < 0) r = 0;
+          }
+          out[(size_t)gy * W + gx] = r;
+        }
+        if (o < 3) {
+          sxx += vxx[o + P_T] - vxx[o];
+          syy += vyy[o + P_T] - vyy[o];
+          sxy += vxy[o + P_T] - vxy[o];
+        }
+      }
+    }
+    __syncthreads();                               // (the sums' planes are free for the other half)
+    }
+    return;
   } else {
     // B: Sobel as a TRUE convolution (kernel flipped): left minus right, top minus bottom
     for (int i = tid; i < GH * groups; i += NT) {
@@ -258,48 +309,11 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
     __syncthreads();
   }
 
-  // D: vertical sums + response
+  // D (run-time patch size): vertical sums + response
   const int lx = tid & (RX - 1);
   const int border = pr + 1;
   const int gx = x0 + lx;
-  if (P_T > 0) {
-    const int ys = (tid / RX) * 8;                 // strip of eight output rows
-    int vxx[8 + P_T - 1], vyy[8 + P_T - 1], vxy[8 + P_T - 1];
-#pragma unroll
-    for (int k = 0; k < 8 + P_T - 1; ++k) {
-      const int j = (ys + k) * RX + lx;
-      vxx[k] = s_hxx[j];
-      vyy[k] = s_hyy[j];
-      vxy[k] = s_hxy[j];
-    }
-    int sxx = 0, syy = 0, sxy = 0;
-#pragma unroll
-    for (int k = 0; k < P_T; ++k) {
-      sxx += vxx[k];
-      syy += vyy[k];
-      sxy += vxy[k];
-    }
-#pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      const int gy = y0 + ys + o;
-      if (gy < H && gx < W) {
-        double r = 0.0;
-        if (gy >= border && gy < H - border && gx >= border && gx < W - border) {
-          const double dxx = (double)sxx, dyy = (double)syy, dxy = (double)sxy;
-          const double trace = dxx + dyy;
-          const double det = dxx * dyy - dxy * dxy;
-          r = det - kappa * (trace * trace);
-          if (r < 0) r = 0;
-        }
-        out[(size_t)gy * W + gx] = r;
-      }
-      if (o < 7) {
-        sxx += vxx[o + P_T] - vxx[o];
-        syy += vyy[o + P_T] - vyy[o];
-        sxy += vxy[o + P_T] - vxy[o];
-      }
-    }
-  } else {
+  {
     for (int ly = tid / RX; ly < RY; ly += NT / RX) {
       const int gy = y0 + ly;
       if (gy >= H || gx >= W) continue;
@@ -1397,7 +1411,8 @@ __global__ __launch_bounds__(NT) void patch_desc_kernel(const uint8_t* __restric
 
 size_t response_lds_bytes(int p) {
   const resp_geom g = response_geometry(p);
-  return (size_t)((g.IWp * g.IH + 15) & ~15) + (size_t)g.GWp * g.GH * 4 + (size_t)3 * g.GH * RX * 4;
+  const int HR = p == 9 ? RY / 2 + p - 1 : g.GH;     // (the compile-time patch holds half the rows of sums at a time)
+  return (size_t)((g.IWp * g.IH + 15) & ~15) + (size_t)g.GWp * g.GH * 4 + (size_t)3 * HR * RX * 4;
 }
 
 size_t candidates_lds_bytes(int r) {
