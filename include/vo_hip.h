@@ -281,7 +281,8 @@ int vo_ransac_replay(vo_ransac_state* st, const uint8_t* valid, const int32_t* c
  * position in the generator's output stream [ref: src/vo/algorithms/ransac.py:42-56], and
  * KLTTracker._num_features.  The pipeline takes IMAGES ONLY; one step = one frame:
  *   side streams: pyramid(next); Harris response + greedy NMS on next (the detector whose
- *                 keypoints the next step appends when too few tracks survive)
+ *                 keypoints the next step appends when too few tracks survive; launched for
+ *                 every frame, executed per sequence within detect_margin of that limit)
  *   re-detect     [ref: src/vo/features/klt.py:207-230, 117-189]  length < 0.8 * _num_features:
  *                 the detector's keypoints of `prev` are appended as unmatched features
  *   KLT           [ref: klt.py:233-249]  every feature prev -> next, keep status & err < thr
