@@ -105,9 +105,24 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ s
   float* s_mid = blur_smem + RH * PI;      // RH x BT_W
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
-  for (int ky = ty; ky < RH; ky += 4) {
-    const float* row = src + (size_t)refl(y0 - r + ky, H) * W;
-    for (int kx = tx; kx < PI; kx += 64) s_in[ky * PI + kx] = row[refl(x0 - r + kx, W)];
+  // the tile with its halo: eight loads per work item in flight at a time (one load per trip leaves every trip waiting
+  // for its own round trip: ~20 of them, 8-10 us of a launch that the small octaves are nothing else but)
+  {
+    const int total = RH * PI;
+    for (int base = 0; base < total; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(base + u * 256 + (int)threadIdx.x, total - 1);
+        const int ky = i / PI, kx = i - ky * PI;
+        v[u] = src[(size_t)refl(y0 - r + ky, H) * W + refl(x0 - r + kx, W)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 256 + (int)threadIdx.x;
+        if (i < total) s_in[i] = v[u];
+      }
+    }
   }
   __syncthreads();
   for (int ky = ty; ky < RH; ky += 4) {
@@ -899,14 +914,14 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   };
   // Octave o + 1 starts from layer NOL of octave o: the chain  base -> g1..g3 -> decimate -> g1..g3 -> ...  is the
   // critical path (the small octaves are a launch latency each); the last two layers of every octave and its extrema
-  // search run beside it on a second stream.
+  // search run beside it: octave 0's (two thirds of that work) on one stream, the smaller octaves' on another.
   if (!ctx->aux_stream) VO_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-  while ((int)ctx->aux_events.size() < MAX_OCT + 1) {
+  if (!ctx->aux_stream2) VO_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream2, hipStreamNonBlocking));
+  while ((int)ctx->aux_events.size() < MAX_OCT + 2) {
     hipEvent_t e;
     VO_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->aux_events.push_back(e);
   }
-  hipStream_t sb = ctx->aux_stream;
   const float threshold = std::floor(0.5f * contrast_thr / NOL * 255.f);
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_SCALESPACE);
@@ -920,14 +935,17 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
         hipLaunchKernelGGL(decimate_kernel, grid2(w, h), dim3(256), 0, st, oct[o - 1].g[NOL], oct[o - 1].W, h, w,
                            const_cast<float*>(oct[o].g[0]));
       for (int i = 1; i <= NOL; ++i) blur(st, oct[o].g[i - 1], h, w, taps[i], const_cast<float*>(oct[o].g[i]));
+      hipStream_t sb = o == 0 ? ctx->aux_stream : ctx->aux_stream2;
       VO_HIP_TRY(ctx, hipEventRecord(ctx->aux_events[o], st));
       VO_HIP_TRY(ctx, hipStreamWaitEvent(sb, ctx->aux_events[o], 0));
       for (int i = NOL + 1; i < NG; ++i) blur(sb, oct[o].g[i - 1], h, w, taps[i], const_cast<float*>(oct[o].g[i]));
       hipLaunchKernelGGL(extrema_kernel, grid2(w, h), dim3(256), 0, sb, oct[o], threshold, (int4*)ctx->scratch[0].p,
                          d_cnt + C_CAND, cap_cand);
     }
-    VO_HIP_TRY(ctx, hipEventRecord(ctx->aux_events[MAX_OCT], sb));
+    VO_HIP_TRY(ctx, hipEventRecord(ctx->aux_events[MAX_OCT], ctx->aux_stream));
+    VO_HIP_TRY(ctx, hipEventRecord(ctx->aux_events[MAX_OCT + 1], ctx->aux_stream2));
     VO_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->aux_events[MAX_OCT], 0));
+    VO_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->aux_events[MAX_OCT + 1], 0));
   }
   VO_TRY(vo_check_launch(ctx, "sift scale space"));
   skp_t* d_kps = (skp_t*)ctx->scratch[1].p;

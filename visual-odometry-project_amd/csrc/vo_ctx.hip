@@ -99,6 +99,7 @@ void vo_destroy(vo_ctx* c) {
   for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->aux_events) (void)hipEventDestroy(e);
   if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+  if (c->aux_stream2) (void)hipStreamDestroy(c->aux_stream2);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

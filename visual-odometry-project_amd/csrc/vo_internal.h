@@ -56,6 +56,7 @@ struct vo_ctx {
   vo_buf match_arrived;          // knn2_mfma_kernel's per-query-block arrival counters (zero between calls)
   bool lds_opt_in[2] = {false, false};         // hipFuncSetAttribute is per device: remembered per context (response, NMS)
   hipStream_t aux_stream = nullptr;            // vo_sift: the octaves' last two layers and extrema run beside the next octave
+  hipStream_t aux_stream2 = nullptr;           //          (octave 0 on the first, the smaller octaves on the second)
   std::vector<hipEvent_t> aux_events;
   vo_buf sift_arena;
   // pinned host staging
