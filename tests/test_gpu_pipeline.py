@@ -166,8 +166,8 @@ def test_pipeline_lookahead_and_host_recovery_match_blocking_steps(ctx):
             fa, fb = fields(a), fields(b)
             assert fa == fb, (la, kw, "step", k, "recovered", a.recovered,
                               [(i, fa[i], fb[i]) for i in range(len(fa)) if fa[i] != fb[i]][:3])
-        if "debug_fault_every" in kw:
-            assert sum(r.recovered for r in got) == len(pairs) // 3
+        if "debug_fault_every" in kw:      # (steps 2, 5, 8, 11 are forced; another one may take the path by itself)
+            assert all(got[k].recovered == 1 for k in range(2, len(pairs), 3))
         if kw.get("debug_never_detect"):
             assert any(r.redetected and r.recovered for r in got), "the skipped-detection path was meant to run"
         assert g == g_ref
