@@ -239,6 +239,14 @@ def test_several_sequences_per_launch_equal_single_sequence_pipelines(ctx, looka
     pipe.close()
 
 
+@pytest.mark.parametrize("seed", [7, 1])
+def test_random_sequences_faults_and_detector_margins(ctx, seed):
+    """tests/pipeline_fuzz.py: sequence counts, scenes, starting track counts, forced faults and detector margins drawn
+    at random (seed 7 holds the case that found a bug: a forced fault hiding a re-detect whose detection was skipped)."""
+    from pipeline_fuzz import run_trials
+    assert run_trials(ctx, seed, 10) == 0
+
+
 def test_pipeline_at_configuration_size(ctx):
     """BASELINE.json configs[1] as a pipeline: 1376x1241, 2000 keypoints, 3-level 15x15 KLT, 1000 hypotheses,
     look-ahead AND device refinement, against the oracle loop on the same frames."""

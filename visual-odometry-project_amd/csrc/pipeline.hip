@@ -950,23 +950,33 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
                         c.n_keypoints, p->cap);
   const int zero = 0;
   VO_HIP_TRY(ctx, mcpy(st, &ctl->fault, &zero, 4, hipMemcpyHostToDevice));
-  if (h.fault & VO_FAULT_NO_DETECTION) {
-    // the tracks fell through the detection margin within one frame: the detector's keypoints of `prev` are made now
-    vo_ctx* det = p->det;
-    VO_HIP_TRY(ctx, hipStreamSynchronize(det->stream));
-    double* scores = p->d_scores[p->det_flip] + (size_t)q * p->px;
-    det->nms_kp_f32 = nullptr;
-    int rc = vo_harris_response_batch_dev(det, p->img(q, f.prev_idx), 0, 1, c.H, c.W, c.harris_patch, c.harris_kappa, scores);
-    if (rc == VO_OK) rc = vo_nms_keypoints_batch_dev(det, scores, 1, c.H, c.W, c.n_keypoints, c.nms_radius, p->kp(q, f.a), 0);
-    if (rc != VO_OK) return vo_set_error(ctx, rc, "detection: %s", vo_last_error(det));
-    VO_HIP_TRY(ctx, hipStreamSynchronize(det->stream));
-    const int one = 1;
-    VO_HIP_TRY(ctx, mcpy(st, p->d_det_go + (size_t)f.a * p->S + q, &one, 4, hipMemcpyHostToDevice));
+  // tracker and regroup of this sequence alone, without the forced fault.  A regroup that needs the detector's keypoints
+  // of `prev` and finds that the detection was skipped (the tracks fell through the margin within one frame -- the
+  // fault this step came with, or one that another fault had hidden) says so: the keypoints are made now, once more.
+  for (int attempt = 0;; ++attempt) {
+    if (h.fault & VO_FAULT_NO_DETECTION) {
+      vo_ctx* det = p->det;
+      VO_HIP_TRY(ctx, hipStreamSynchronize(det->stream));
+      double* scores = p->d_scores[p->det_flip] + (size_t)q * p->px;
+      det->nms_kp_f32 = nullptr;
+      int rc = vo_harris_response_batch_dev(det, p->img(q, f.prev_idx), 0, 1, c.H, c.W, c.harris_patch, c.harris_kappa, scores);
+      if (rc == VO_OK) rc = vo_nms_keypoints_batch_dev(det, scores, 1, c.H, c.W, c.n_keypoints, c.nms_radius, p->kp(q, f.a), 0);
+      if (rc != VO_OK) return vo_set_error(ctx, rc, "detection: %s", vo_last_error(det));
+      VO_HIP_TRY(ctx, hipStreamSynchronize(det->stream));
+      const int one = 1;
+      VO_HIP_TRY(ctx, mcpy(st, p->d_det_go + (size_t)f.a * p->S + q, &one, 4, hipMemcpyHostToDevice));
+    }
+    VO_TRY(enqueue_tracker(p, f, false, q, 1));
+    VO_TRY(enqueue_chain(p, f, true, 0, q, 1, 0u));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+    VO_HIP_TRY(ctx, mcpy(st, &h, ctl, sizeof(h), hipMemcpyDeviceToHost));
+    if (!(h.fault & VO_FAULT_NO_DETECTION) || attempt > 0) break;
+    VO_HIP_TRY(ctx, mcpy(st, &ctl->fault, &zero, 4, hipMemcpyHostToDevice));
   }
-  VO_TRY(enqueue_tracker(p, f, false, q, 1));
-  VO_TRY(enqueue_chain(p, f, true, 0, q, 1, 0u));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
-  VO_HIP_TRY(ctx, mcpy(st, &h, ctl, sizeof(h), hipMemcpyDeviceToHost));
+  if (h.fault & VO_FAULT_CAPACITY)
+    return vo_set_error(ctx, VO_ECAPACITY, "pipeline: %d features + %d new keypoints exceed the capacity %d", h.n,
+                        c.n_keypoints, p->cap);
+  if (h.fault & VO_FAULT_NO_DETECTION) return vo_set_error(ctx, VO_EHIP, "pipeline: the detector's keypoints are missing");
   const int n = h.n_tri;
   if (n < 4) return vo_set_error(ctx, VO_ETRACKING, "pipeline: only %d triangulated tracks survive, no pose", n);
   if (h.fault) VO_HIP_TRY(ctx, mcpy(st, &ctl->fault, &zero, 4, hipMemcpyHostToDevice));   // (few landmarks)
