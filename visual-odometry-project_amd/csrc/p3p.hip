@@ -203,6 +203,44 @@ __device__ __forceinline__ double reproj_sq(const double* R, const double* t, do
   return nrm * nrm;
 }
 
+// The same up to the sum of squares s (the error is fl(fl(sqrt(s))^2)).  fl(fl(sqrt(.))^2) is monotone in s
+// (sqrt is correctly rounded on both sides, rounding is monotone), so  error < thr  <=>  s <= sum_sq_limit(thr):
+// the scoring loops compare s and skip the square root and the square of every evaluation, same decisions.
+__device__ __forceinline__ double reproj_sum_sq(const double* R, const double* t, double fx, double fy, double cx,
+                                                double cy, double X, double Y, double Z, double u0, double v0) {
+  const double xc = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+  const double yc = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+  const double zc = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+  const double iz = (zc != 0.0) ? 1.0 / zc : 1.0;
+  const double xn = xc * iz, yn = yc * iz;
+  const double u = xn * fx + cx;
+  const double v = yn * fy + cy;
+  const double dx = u0 - u, dy = v0 - v;
+  return dx * dx + dy * dy;
+}
+
+// largest s >= 0 with fl(fl(sqrt(s))^2) < thr (bisection over the bit patterns of the non-negative doubles, which
+// order like the numbers); -1 when there is none.  The host's sqrt and product are the device's: both IEEE.
+static double sum_sq_limit(double thr) {
+  auto err_of = [](double s_) {
+    volatile double r = std::sqrt(s_);
+    volatile double e = r * r;
+    return (double)e;
+  };
+  if (!(thr > 0.0) || !(err_of(0.0) < thr)) return -1.0;
+  unsigned long long lo = 0ull, hi = 0x7ff0000000000000ull;   // err_of(lo) < thr, err_of(hi = inf) >= thr
+  while (hi - lo > 1ull) {
+    const unsigned long long mid = lo + (hi - lo) / 2;
+    double m;
+    memcpy(&m, &mid, 8);
+    if (err_of(m) < thr) lo = mid;
+    else hi = mid;
+  }
+  double r;
+  memcpy(&r, &lo, 8);
+  return r;
+}
+
 // NumPy's bounded draw on one 32-bit output of the generator (Lemire, ransac_host.hip):
 // `risky` is raised when the draw could have been rejected, i.e. when the sequential
 // generator might have consumed one more output than this position-based view assumes.
@@ -425,7 +463,7 @@ __global__ __launch_bounds__(256) void p3p_hyp_kernel(const double* __restrict__
                                                       const unsigned* __restrict__ raws,
                                                       const unsigned long long* __restrict__ d_rawpos, unsigned raw_mask,
                                                       const int* __restrict__ d_n, unsigned* __restrict__ flag, int Hyp,
-                                                      double fx, double fy, double cx, double cy, double thr,
+                                                      double fx, double fy, double cx, double cy, double lim,
                                                       double* __restrict__ Rout, double* __restrict__ tout,
                                                       uint8_t* __restrict__ valid, int* __restrict__ counts,
                                                       unsigned long long* __restrict__ masks, int words,
@@ -462,7 +500,9 @@ __global__ __launch_bounds__(256) void p3p_hyp_kernel(const double* __restrict__
       pv[k] = xi[2 * i + 1];
     }
   };
-  if (wv == 0) {
+  // the solving wave changes with the workgroup: a workgroup's wave k runs on SIMD k, and with every solver on
+  // SIMD 0 the solves of the workgroups sharing a CU would queue there while the other three SIMDs wait
+  if (wv == ((blockIdx.x + blockIdx.y) & 3)) {
     if (lane < 4 * HG)
       p3p_solve_quad<true>(h0 * 4 + lane, Xw, xi, nullptr, raws, d_rawpos, raw_mask, d_n, flag, Hyp, fx, fy, cx, cy, Rout,
                            tout, valid);
@@ -492,11 +532,11 @@ __global__ __launch_bounds__(256) void p3p_hyp_kernel(const double* __restrict__
       for (int k = 0; k < HP; ++k) {
         const int i = tile * (256 * HP) + k * 256 + tid;
         bool in = false;
-        if (ok && i < N) in = reproj_sq(R, t, fx, fy, cx, cy, pX[k], pY[k], pZ[k], pu[k], pv[k]) < thr;
+        if (ok && i < N) in = reproj_sum_sq(R, t, fx, fy, cx, cy, pX[k], pY[k], pZ[k], pu[k], pv[k]) <= lim;
         const unsigned long long m = __ballot(in);
-        const int w = i >> 6;                  // (uniform in the wave)
-        if (lane == 0 && w < words_n) {
-          if (masks) masks[(size_t)h * words + w] = m;
+        const int w = __builtin_amdgcn_readfirstlane(i >> 6);   // (uniform in the wave: the counts stay in scalar registers)
+        if (w < words_n) {
+          if (lane == 0 && masks) masks[(size_t)h * words + w] = m;
           cnt[g] += __popcll(m);
         }
       }
@@ -588,16 +628,17 @@ int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x
              "p3p_hypotheses_ring: null pointer");
   VO_REQUIRE(ctx, n_cap >= 4 && Hyp >= 1, "p3p_hypotheses_ring: need n_cap >= 4 and Hyp >= 1");
   VO_REQUIRE(ctx, K[0] != 0.0 && K[4] != 0.0, "p3p_hypotheses_ring: singular intrinsics");
+  const double lim = sum_sq_limit(thr_sq);   // (lim: see reproj_sum_sq)
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
     if (S >= 8)
       hipLaunchKernelGGL(p3p_hyp_kernel<16>, dim3(vo_cdiv(Hyp, 16), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
-                         (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], thr_sq, d_R,
+                         (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], lim, d_R,
                          d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts,
                          B);
     else
       hipLaunchKernelGGL(p3p_hyp_kernel<8>, dim3(vo_cdiv(Hyp, 8), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
-                         (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], thr_sq, d_R,
+                         (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], lim, d_R,
                          d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts,
                          B);
   }

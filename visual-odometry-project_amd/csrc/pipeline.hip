@@ -317,7 +317,10 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   // A fifth stream shares a queue: with two detection streams the second sat on the tracker's queue and delayed
   // it every other frame (rocprofv3 trace, same queue id; 8.2k vs 5.1k frames/s run to run).  Hence the next
   // frame's pyramid on the tracker's stream, one detection stream, no hipMemcpy in here.
-  if (vo_create(ctx->device, nullptr, &p->det) != VO_OK || vo_create(ctx->device, nullptr, &p->trk) != VO_OK)
+  // (VO_ONE_STREAM=1, measurements only: every kernel on the caller's stream, so that a kernel trace shows each
+  // kernel's duration without the others running beside it)
+  void* side = getenv("VO_ONE_STREAM") ? (void*)ctx->stream : nullptr;
+  if (vo_create(ctx->device, side, &p->det) != VO_OK || vo_create(ctx->device, side, &p->trk) != VO_OK)
     rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
   const int N = cfg->n_keypoints, Hyp = cfg->hyp;
   const size_t px = (size_t)cfg->H * cfg->W, Sz = (size_t)S;
