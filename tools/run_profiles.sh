@@ -5,7 +5,7 @@
 # 2./3. one PMC pass each for FETCH_SIZE and WRITE_SIZE (never combined with a trace), with the detector on every
 #    frame so that every kernel's figures are per executed launch; 4. kernel-trace statistics of that mode and of the
 #    16-sequence run; 5. the bench lines: headline (with the CPU baseline and API legs), 4 and 16 sequences per GPU,
-#    detector on every frame (1 and 16 sequences), cfg-3, cfg-5.
+#    detector on every frame (1 and 16 sequences), cfg-3, cfg-5.  4b: see below.
 set -eo pipefail
 tag=${1:-r02}
 out=gpurun_out/prof_$tag
@@ -19,6 +19,12 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- $cmd > $out/writ
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_all -- $cmd > $out/stats_all.log 2>&1
 unset VO_BENCH_DETECT_MARGIN
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16 -- $cmd --sequences 16 --steps 100 > $out/stats_s16.log 2>&1
+# 4b. the same 16-sequence run with every pipeline stream = the main stream (VO_ONE_STREAM=1): each kernel's duration
+#     without the others running beside it (what a roofline fraction of a single kernel should be computed from)
+VO_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16_one -- $cmd --sequences 16 --steps 60 --warmup 20 > $out/stats_s16_one.log 2>&1
+VO_ONE_STREAM=1 VO_BENCH_DETECT_MARGIN=-1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16_one_all -- $cmd --sequences 16 --steps 60 --warmup 20 > $out/stats_s16_one_all.log 2>&1
+cp "$(ls $out/stats_s16_one/*/*kernel_stats.csv | head -1)" $out/${tag}_s16_one_stream_kernel_stats.csv
+cp "$(ls $out/stats_s16_one_all/*/*kernel_stats.csv | head -1)" $out/${tag}_s16_one_stream_detect_every_frame_kernel_stats.csv
 python3 tools/summarize_profiles.py $out/stats $out/fetch $out/write $out/$tag
 python3 tools/summarize_profiles.py $out/stats_all $out/fetch $out/write $out/${tag}_detect_every_frame
 python3 tools/summarize_profiles.py $out/stats_s16 $out/fetch $out/write $out/${tag}_s16
