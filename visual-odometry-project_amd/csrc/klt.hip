@@ -270,10 +270,9 @@ __global__ __launch_bounds__(256) void pyramid3_kernel(const uint8_t* __restrict
 
 // seven bytes starting at byte 2 of dword a: two neighbouring 5-tap row sums
 __device__ __forceinline__ void tap_pair(unsigned a, unsigned b, unsigned c, int& ra, int& rb) {
-  const int p0 = (a >> 16) & 255, p1 = a >> 24, p2 = b & 255, p3 = (b >> 8) & 255, p4 = (b >> 16) & 255, p5 = b >> 24,
-            p6 = c & 255;
-  ra = p0 + 4 * p1 + 6 * p2 + 4 * p3 + p4;
-  rb = p2 + 4 * p3 + 6 * p4 + 4 * p5 + p6;
+  // (1, 4, 6, 4) . four bytes is one v_dot4_u32_u8, the fifth tap its addend: five instructions for the pair
+  ra = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 2), 0x04060401u, (b >> 16) & 255u, false);
+  rb = (int)__builtin_amdgcn_udot4(b, 0x04060401u, c & 255u, false);
 }
 
 __device__ __forceinline__ int reflect_once(int c, int n) {
