@@ -195,6 +195,11 @@ int vo_reproj_inliers(vo_ctx* ctx, const double* X, const double* x, int N, cons
 int vo_reproj_inliers_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N,
                           const double* K, const double* d_Rt, double thr_sq,
                           uint8_t* d_mask, double* d_err);
+/* The frame loop's hypothesis kernel takes the decision `error < thr_sq` (ransac.py:104-106) on the sum of squares
+ * s, where error = fl(fl(sqrt(s))^2) is what error_fn computes (p3p.py:81-108: norm, then square):
+ * vo_inlier_sum_sq_limit returns the largest double s whose error is below thr_sq (-1: there is none), and
+ * `s <= limit` is the same decision because rounding and sqrt are monotone.  Host arithmetic only.          */
+double vo_inlier_sum_sq_limit(double thr_sq);
 
 /* ---- pose refinement --------------------------------------------------------------
  * [ref: src/vo/pose_estimation/p3p.py:188-213 _nonlinear_refinement; helpers.py:86-142]
@@ -362,7 +367,10 @@ typedef struct vo_step_result {
   uint64_t ts[8];               /* device clock (100 MHz ticks) at the start of: tracker, regroup, hypotheses, pose,
                                    landmark stage, at the end of the step (the record's last write); [6], [7]:
                                    inside the pose kernel, RANSAC replay done / refinement done               */
-  uint32_t seq_head, seq_tail;  /* internal: the record is complete when both equal the step's sequence number */
+  uint32_t seq_head, seq_tail;  /* internal; the last two words.  In the mapped record: seq_tail = the step's sequence
+                                   number, seq_head = that number XOR every other 32-bit word of the record, so that a
+                                   copy taken while some of its lines were still on their way is recognised; in what
+                                   the collect calls return both equal the number                                  */
 } vo_step_result;
 int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out);
 void vo_pipeline_destroy(vo_pipeline* p);

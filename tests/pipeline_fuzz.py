@@ -58,7 +58,13 @@ def run_trials(ctx, seed, trials, verbose=False):
                 if fields(got[k][q]) != fields(single[q][0][k]):
                     ok = False
                     if verbose:
-                        print("  MISMATCH trial", trial, "seq", q, "step", k)
+                        names = ("n_features_in redetected n_tracked n_triangulated n_inliers ransac_iterations draws_consumed "
+                                 "n_candidates n_dropped n_landmarks R t R_refined t_refined T_wc").split()
+                        fa, fb = fields(got[k][q]), fields(single[q][0][k])
+                        diff = [(n, a, b) for n, a, b in zip(names, fa, fb) if a != b and not isinstance(a, tuple)]
+                        diff += [n for n, a, b in zip(names, fa, fb) if a != b and isinstance(a, tuple)]
+                        print("  MISMATCH trial", trial, "seq", q, "step", k, "recovered", got[k][q].recovered, "reason",
+                              got[k][q].reserved, "detector_ran", got[k][q].detector_ran, single[q][0][k].detector_ran, diff)
                     break
             st = pipe.get_state(seq=q)
             for key in ("keypoints", "state", "candidate_mask", "landmarks", "tracks", "poses", "curr_pose"):

@@ -133,6 +133,29 @@ def test_library_exports_every_declared_symbol():
     assert bound <= names, sorted(bound - names)
 
 
+def test_inlier_limit_on_the_sum_of_squares_is_the_reference_decision():
+    """p3p.py:81-108 / ransac.py:104-106: inlier <=> norm(dx, dy)**2 < thr.  The hypothesis kernel compares the sum of
+    squares with vo_inlier_sum_sq_limit(thr): the limit is the last double that is an inlier, the next one is not, and
+    sums drawn around it decide as the reference does."""
+    from vo import _native
+    lib = ctypes.CDLL(_native.lib_path())
+    lib.vo_inlier_sum_sq_limit.restype = ctypes.c_double
+    lib.vo_inlier_sum_sq_limit.argtypes = [ctypes.c_double]
+    err = lambda s: np.sqrt(np.float64(s)) ** 2
+    rng = np.random.default_rng(11)
+    thrs = [1.0, 1.25 ** 2, 1.5625, 2.0, 1e-12, 1e-300, 5e-324, 1e300, 0.1 ** 2, 3.0, 4.0, 9.0, 2.0 ** -1074, 2.0 ** 1023]
+    thrs += list(np.exp(rng.uniform(-40, 40, size=300))) + list(rng.uniform(0.5, 4.0, size=300))
+    for thr in thrs:
+        lim = lib.vo_inlier_sum_sq_limit(float(thr))
+        assert lim >= 0.0 and err(lim) < thr, (thr, lim)
+        up = np.nextafter(lim, np.inf)
+        assert not (err(up) < thr), (thr, lim)
+        around = np.float64(lim) * (1.0 + rng.integers(-40, 41, size=64) * 2.0 ** -52)
+        assert np.array_equal(err(around) < thr, around <= lim), thr
+    for thr in (0.0, -1.0, float("nan")):
+        assert lib.vo_inlier_sum_sq_limit(thr) == -1.0
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a HIP device the context constructor raises; nothing silently runs on the CPU."""
     from vo import _native

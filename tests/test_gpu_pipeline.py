@@ -80,14 +80,17 @@ def check_step(r, ref, pipe, gen_ref, tol_refined=1e-7):
 
 @pytest.mark.parametrize("H,W,N,hyp,frac,redetect", [(240, 320, 300, 256, 1.0, "identity"),
                                                       (480, 640, 500, 1000, 0.83, "identity"),
-                                                      (480, 640, 500, 1000, 0.83, "current")])
+                                                      (480, 640, 500, 1000, 0.83, "current"),
+                                                      (240, 320, 300, 4, 0.83, "current")])
 def test_pipeline_matches_oracle_loop(ctx, H, W, N, hyp, frac, redetect):
     """Every array the reference carries from frame to frame, after every frame: keypoints, states, candidate
     masks, tracks bit for bit; landmarks and poses to rounding; RANSAC bookkeeping and the generator state
     exact.  frac < 1 starts below 80 % of the detector's count so the re-detect branch (klt.py:207-230) runs:
     with the reference's np.eye(4) start pose for the new keypoints ("identity"; their triangulation then uses a
     wrong baseline and the estimate leaves the ground truth, in the oracle exactly as on the device), and with
-    the pipeline's optional correction ("current")."""
+    the pipeline's optional correction ("current").  hyp = 4: the loop never ends inside one launch of hypotheses, so
+    every step leaves the device-only path from the POSE kernel (after its regroup has run) and is finished by the
+    host's sequential sampler -- around a re-detect too."""
     from vo import synthetic
     F = 6
     stream = synthetic.Stream(F, H, W)
@@ -98,11 +101,12 @@ def test_pipeline_matches_oracle_loop(ctx, H, W, N, hyp, frac, redetect):
     orc.set_state(0, feats, T, T)
     check_state(pipe.get_state(), feats, T)
     order = stream.order(7)
-    redetects = 0
+    redetects = host_path = 0
     for a, b in zip(order[:-1], order[1:]):
         ref = orc.step(b)
         r = pipe.step(a, b)
         redetects += r.redetected
+        host_path += r.recovered
         assert r.n_features_in == ref["n_before"] + (N if r.redetected else 0)
         check_step(r, ref, pipe, orc.rs.rng)
         # against analytic ground truth of the stream
@@ -112,6 +116,8 @@ def test_pipeline_matches_oracle_loop(ctx, H, W, N, hyp, frac, redetect):
             assert np.abs(np.array(r.t_refined) - Tcw[:3, 3]).max() < 0.1
     if frac < 1.0:
         assert redetects >= 1, "the re-detect branch was meant to run"
+    if hyp < 16:
+        assert host_path >= 4, "the host path was meant to finish these steps"
     pipe.close()
 
 
@@ -239,12 +245,14 @@ def test_several_sequences_per_launch_equal_single_sequence_pipelines(ctx, looka
     pipe.close()
 
 
-@pytest.mark.parametrize("seed", [7, 1])
-def test_random_sequences_faults_and_detector_margins(ctx, seed):
+@pytest.mark.parametrize("seed,trials", [(7, 10), (1, 10), (22, 24)])
+def test_random_sequences_faults_and_detector_margins(ctx, seed, trials):
     """tests/pipeline_fuzz.py: sequence counts, scenes, starting track counts, forced faults and detector margins drawn
-    at random (seed 7 holds the case that found a bug: a forced fault hiding a re-detect whose detection was skipped)."""
+    at random (seed 7 holds the case that found a bug: a forced fault hiding a re-detect whose detection was skipped;
+    seed 22 several that found another, now and then: a fault raised by the pose kernel, redone with the tracker
+    reading the new frame's feature count)."""
     from pipeline_fuzz import run_trials
-    assert run_trials(ctx, seed, 10) == 0
+    assert run_trials(ctx, seed, trials) == 0
 
 
 def test_pipeline_at_configuration_size(ctx):

@@ -647,6 +647,8 @@ int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x
 
 extern "C" {
 
+double vo_inlier_sum_sq_limit(double thr_sq) { return sum_sq_limit(thr_sq); }
+
 int vo_p3p_hypotheses_dev(vo_ctx* ctx, const double* d_X, const double* d_x, int N, const double* K,
                           const int32_t* d_samples, int Hyp, double thr_sq, double* d_R, double* d_t,
                           uint8_t* d_valid, int32_t* d_counts, uint64_t* d_masks) {

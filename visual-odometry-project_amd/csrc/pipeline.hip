@@ -914,6 +914,16 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
 // fences at system scope, then the sequence word; the record also carries the number at both ends and the generator
 // position can only grow, so a copy taken while some of the record's lines were still on their way (seen twice in
 // ~40k steps: the sequence word visible, a field behind it not yet) is recognised and taken again.
+// state_device.h: seq_tail = the step's number, seq_head = the number XOR every other dword of the record
+static bool record_fits(vo_step_result* out, unsigned seq) {
+  const unsigned* dw = reinterpret_cast<const unsigned*>(out);
+  unsigned x = 0u;
+  for (size_t k = 0; k + 2 < sizeof(*out) / 4; ++k) x ^= dw[k];
+  if (out->seq_tail != seq || out->seq_head != (seq ^ x)) return false;
+  out->seq_head = seq;           // (what the caller sees: both equal the step's number)
+  return true;
+}
+
 static int wait_record(vo_pipeline* p, int rslot, int q, unsigned seq, uint64_t floor, vo_step_result* out) {
   volatile unsigned* w = p->seq_h(rslot, q);
   const double t0 = now_s();
@@ -922,13 +932,13 @@ static int wait_record(vo_pipeline* p, int rslot, int q, unsigned seq, uint64_t 
     if (*w == seq) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       memcpy(out, (const void*)p->res_h(rslot, q), sizeof(*out));
-      if (out->seq_head == seq && out->seq_tail == seq && out->raw_pos >= floor) return VO_OK;
+      if (record_fits(out, seq) && out->raw_pos >= floor) return VO_OK;
     }
     __builtin_ia32_pause();
     if ((++it & 0xffff) == 0 && now_s() - t0 > 5.0) {
       VO_HIP_TRY(p->ctx, hipStreamSynchronize(p->ctx->stream));
       memcpy(out, (const void*)p->res_h(rslot, q), sizeof(*out));
-      if (*w == seq && out->seq_head == seq && out->seq_tail == seq) return VO_OK;
+      if (*w == seq && record_fits(out, seq)) return VO_OK;
       return vo_set_error(p->ctx, VO_EHIP, "pipeline: the GPU never published the record of step %u (sequence %d)", seq, q);
     }
   }
@@ -953,6 +963,11 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
                         c.n_keypoints, p->cap);
   const int zero = 0;
   VO_HIP_TRY(ctx, mcpy(st, &ctl->fault, &zero, 4, hipMemcpyHostToDevice));
+  // The tracker reads its feature count from n2, which the step's own regroup has replaced by the NEW frame's count
+  // when the fault came from the pose kernel (a possibly rejected draw, an unfinished loop): the tracker below would
+  // redo only the first n2 features, and the rest of d_next would be whatever the next step's tracker left there --
+  // the step's own values unless that one appended a detection (found by tests/pipeline_fuzz.py, now and then).
+  VO_HIP_TRY(ctx, mcpy(st, &ctl->n2, &h.n, 4, hipMemcpyHostToDevice));
   // tracker and regroup of this sequence alone, without the forced fault.  A regroup that needs the detector's keypoints
   // of `prev` and finds that the detection was skipped (the tracks fell through the margin within one frame -- the
   // fault this step came with, or one that another fault had hidden) says so: the keypoints are made now, once more.

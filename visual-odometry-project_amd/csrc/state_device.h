@@ -2,6 +2,7 @@
 // loop's pose kernel, which runs the RANSAC replay in front of the refinement and the candidate selection
 // behind it so that three launches of the dependent chain become one).
 #pragma once
+#include <cstddef>
 #include "vo_state.h"
 
 #pragma clang fp contract(off)
@@ -216,16 +217,40 @@ __device__ __forceinline__ void commit_pose(vo_seq_ctl* __restrict__ ctl, int ti
   ctl->T_wc[tid] = nwc;
 }
 
+// ---- result records in mapped host memory ----
+// The host polls a sequence word and then copies the record.  Stores to host memory are not seen in the order they were
+// made, fences notwithstanding (the record's 64-byte lines travel as separate writes: a record whose last line had
+// arrived and whose first lines had not was seen about once in 10^4 steps, tests/pipeline_fuzz.py), so a record proves
+// itself: all of it is written every time (staged in LDS first), seq_head = the step's number XOR all other dwords,
+// seq_tail = the number.  The host takes a copy whose sum fits (pipeline.hip:wait_record) and copies again otherwise.
+constexpr int REC_DW = (int)(sizeof(vo_step_result) / 4);   // seq_head and seq_tail are the last two dwords
+static_assert(sizeof(vo_step_result) % 4 == 0 && REC_DW <= 128 + 2, "record: two dwords per lane of one wave");
+static_assert(offsetof(vo_step_result, seq_head) == sizeof(vo_step_result) - 8 &&
+              offsetof(vo_step_result, seq_tail) == sizeof(vo_step_result) - 4, "record: the closing words come last");
+
 // The record of a step that raised a fault: what the host needs to redo it.  One work item.
 __device__ __forceinline__ void write_fault_record(const vo_seq_ctl* __restrict__ ctl, int fault, vo_step_result* __restrict__ res,
                                                    unsigned* __restrict__ seq_word, unsigned seq) {
-  res->seq_head = seq;
-  res->fault = fault;
-  res->n_features_in = ctl->n_in;
-  res->n_tracked = ctl->n2;
-  res->n_triangulated = ctl->n_tri;
-  res->raw_pos = ctl->raw_pos;
-  res->seq_tail = seq;
+  // (no local copy of the record: it would live in scratch memory, and a kernel that uses scratch pays for it at every
+  //  launch -- this is the pose kernel of the dependent chain)
+  const unsigned long long rp = ctl->raw_pos;
+  const unsigned f_fault = (unsigned)fault, f_in = (unsigned)ctl->n_in, f_n2 = (unsigned)ctl->n2, f_tri = (unsigned)ctl->n_tri;
+  unsigned x = 0u;
+  unsigned* dst = reinterpret_cast<unsigned*>(res);
+  for (int k = 0; k < REC_DW - 2; ++k) {
+    unsigned v = 0u;
+    if (k == (int)(offsetof(vo_step_result, fault) / 4)) v = f_fault;
+    if (k == (int)(offsetof(vo_step_result, n_features_in) / 4)) v = f_in;
+    if (k == (int)(offsetof(vo_step_result, n_tracked) / 4)) v = f_n2;
+    if (k == (int)(offsetof(vo_step_result, n_triangulated) / 4)) v = f_tri;
+    if (k == (int)(offsetof(vo_step_result, raw_pos) / 4)) v = (unsigned)rp;
+    if (k == (int)(offsetof(vo_step_result, raw_pos) / 4) + 1) v = (unsigned)(rp >> 32);
+    x ^= v;
+    dst[k] = v;
+  }
+  dst[REC_DW - 2] = seq ^ x;
+  __threadfence_system();
+  dst[REC_DW - 1] = seq;
   __threadfence_system();
   *seq_word = seq;
 }
@@ -236,49 +261,60 @@ __device__ __forceinline__ void write_step_record(vo_seq_ctl* __restrict__ ctl, 
                                                   int n_dropped, int n_land, unsigned long long ts4,
                                                   vo_step_result* __restrict__ res, unsigned* __restrict__ seq_word,
                                                   unsigned seq) {
+  __shared__ __align__(8) unsigned s_rec[REC_DW];
+  vo_step_result* r = reinterpret_cast<vo_step_result*>(s_rec);
+  if (tid < REC_DW) s_rec[tid] = 0u;
+  __syncthreads();
   if (tid < 9) {
-    res->R[tid] = ctl->best_pose[tid];
-    res->R_refined[tid] = use_refined > 0 ? ctl->refined[tid] : ctl->best_pose[tid];
+    r->R[tid] = ctl->best_pose[tid];
+    r->R_refined[tid] = use_refined > 0 ? ctl->refined[tid] : ctl->best_pose[tid];
   }
   if (tid < 3) {
-    res->t[tid] = ctl->best_pose[9 + tid];
-    res->t_refined[tid] = use_refined > 0 ? ctl->refined[9 + tid] : ctl->best_pose[9 + tid];
+    r->t[tid] = ctl->best_pose[9 + tid];
+    r->t_refined[tid] = use_refined > 0 ? ctl->refined[9 + tid] : ctl->best_pose[9 + tid];
   }
-  if (tid < 12) res->T_wc[tid] = ctl->T_wc[tid];
-  if (tid == 0) {
-    res->seq_head = seq;
-    res->n_tracked = n2;
-    res->n_inliers = ctl->best_count;
-    res->best_index = ctl->best_idx;
-    res->hyp_valid = ctl->hyp_valid;
-    res->ransac_iterations = ctl->n_done;
-    res->draws_consumed = ctl->consumed;
-    res->refine_iterations = use_refined > 0 ? (int)ctl->refined[12] : -1;
-    res->refine_cost = use_refined > 0 ? ctl->refined[13] : 0.0;
-    res->n_features_in = ctl->n_in;
-    res->redetected = ctl->redetected;
-    res->detector_ran = ctl->det_ran;
-    res->reserved = 0;
-    res->n_triangulated = ctl->n_tri;
-    res->n_candidates = n_cand;
-    res->n_dropped = n_dropped;
-    res->n_landmarks = n_land;
-    res->fault = 0;
-    res->recovered = 0;
-    res->raw_pos = ctl->raw_pos;
-    res->ts[0] = ctl->ts[6];
-    for (int k = 1; k < 4; ++k) res->ts[k] = ctl->ts[k];
-    res->ts[4] = ts4;
-    res->ts[5] = wall_clock64();
-    res->ts[6] = ctl->ts[5];     // inside the pose kernel: the RANSAC replay is done ...
-    res->ts[7] = ctl->ts[7];     // ... the refinement is done
+  if (tid >= 32 && tid < 44) r->T_wc[tid - 32] = ctl->T_wc[tid - 32];
+  if (tid == 63) {
+    r->n_tracked = n2;
+    r->n_inliers = ctl->best_count;
+    r->best_index = ctl->best_idx;
+    r->hyp_valid = ctl->hyp_valid;
+    r->ransac_iterations = ctl->n_done;
+    r->draws_consumed = ctl->consumed;
+    r->refine_iterations = use_refined > 0 ? (int)ctl->refined[12] : -1;
+    r->refine_cost = use_refined > 0 ? ctl->refined[13] : 0.0;
+    r->n_features_in = ctl->n_in;
+    r->redetected = ctl->redetected;
+    r->detector_ran = ctl->det_ran;
+    r->n_triangulated = ctl->n_tri;
+    r->n_candidates = n_cand;
+    r->n_dropped = n_dropped;
+    r->n_landmarks = n_land;
+    r->raw_pos = ctl->raw_pos;
+    r->ts[0] = ctl->ts[6];
+    for (int k = 1; k < 4; ++k) r->ts[k] = ctl->ts[k];
+    r->ts[4] = ts4;
+    r->ts[6] = ctl->ts[5];     // inside the pose kernel: the RANSAC replay is done ...
+    r->ts[7] = ctl->ts[7];     // ... the refinement is done
+    r->ts[5] = wall_clock64();
   }
-  __threadfence_system();
   __syncthreads();
-  if (tid == 0) {
-    res->seq_tail = seq;
+  if (tid < 64) {              // one wave: two dwords per lane, the sum by a butterfly, then the two closing words
+    unsigned* dst = reinterpret_cast<unsigned*>(res);
+    const bool second = tid + 64 < REC_DW - 2;
+    const unsigned v0 = s_rec[tid], v1 = second ? s_rec[tid + 64] : 0u;
+    unsigned x = v0 ^ v1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+    dst[tid] = v0;
+    if (second) dst[tid + 64] = v1;
+    if (tid == 0) dst[REC_DW - 2] = seq ^ x;
     __threadfence_system();
-    *seq_word = seq;
+    if (tid == 0) {
+      dst[REC_DW - 1] = seq;
+      __threadfence_system();
+      *seq_word = seq;
+    }
   }
 }
 
