@@ -4,13 +4,15 @@ time with the detector on every frame.  Returns the number of trials that differ
 import numpy as np
 
 
-def run_trials(ctx, seed, trials, verbose=False):
+def run_trials(ctx, seed, trials, verbose=False, big=False):
     from vo import _native, synthetic
     from test_gpu_pipeline import start_state, fields
     rng = np.random.default_rng(seed)
     bad = 0
     for trial in range(trials):
         H, W, N, hyp, F = 240, 320, 300, 256, 5
+        if big and rng.random() < 0.3:
+            H, W, N, hyp = 480, 640, 500, int(rng.choice([64, 512]))
         S = int(rng.integers(2, 5))
         seeds = rng.integers(2023, 12000, size=S)
         fracs = rng.uniform(0.6, 1.0, size=S)
@@ -75,8 +77,8 @@ def run_trials(ctx, seed, trials, verbose=False):
         if verbose:
             rec = sum(r.recovered for rs in got for r in rs)
             red = sum(r.redetected for rs in got for r in rs)
-            print("trial %d S=%d steps=%d fault_every=%d margin=%g never=%d: %s (host-path steps %d, re-detects %d)" % (
-                trial, S, steps, fault_every, margin, never, "ok" if ok else "FAILED", rec, red), flush=True)
+            print("trial %d %dx%d hyp=%d S=%d steps=%d fault_every=%d margin=%g never=%d: %s (host-path steps %d, re-detects %d)" % (
+                trial, H, W, hyp, S, steps, fault_every, margin, never, "ok" if ok else "FAILED", rec, red), flush=True)
         bad += 0 if ok else 1
         pipe.close()
     return bad
