@@ -631,7 +631,8 @@ int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x
   const double lim = sum_sq_limit(thr_sq);   // (lim: see reproj_sum_sq)
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
-    if (S >= 8)
+    static const int forced = getenv("VO_HYP_GROUP") ? atoi(getenv("VO_HYP_GROUP")) : 0;   // measurements: 8 / 16
+    if (forced == 16 || (forced != 8 && S >= 8))
       hipLaunchKernelGGL(p3p_hyp_kernel<16>, dim3(vo_cdiv(Hyp, 16), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
                          (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], lim, d_R,
                          d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts,
