@@ -12,6 +12,7 @@
 // accumulates their 21 + 6 + 1 terms once per iteration; a wave adds its lanes' terms with a
 // halving butterfly (32 shuffles for all 28 sums), wave 0 adds the eight wave totals, solves the
 // 6x6 system with one lane per row and applies the update; all fp64, two barriers per iteration.
+#include <type_traits>
 #include "state_device.h"
 #include "dlt_device.h"
 
@@ -132,6 +133,14 @@ __device__ __forceinline__ double wave_sums(const double* s, int lane) {
   return v[0] + __shfl_xor(v[0], 1);
 }
 
+// lane K's value in every lane, through a scalar register (K is a compile-time constant: v_readlane_b32, no trip
+// through the LDS crossbar as __shfl makes)
+template <int K>
+__device__ __forceinline__ double lane_value(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), K), hi = __builtin_amdgcn_readlane(__double2hiint(v), K);
+  return __hiloint2double(hi, lo);
+}
+
 // position of (a, b), a <= b, in the row-major upper triangle s[0..20]
 __device__ __forceinline__ int tri_index(int a, int b) { return a * 6 - (a * (a - 1)) / 2 + (b - a); }
 
@@ -145,11 +154,11 @@ __device__ __forceinline__ bool solve6_rows(double tot, int lane, double* d_out)
   for (int j = 0; j < 6; ++j) row[j] = __shfl(tot, tri_index(min(i, j), max(i, j)));
   row[6] = __shfl(tot, 21 + i);
   bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  auto pivot = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
     double pk[7];
 #pragma unroll
-    for (int j = k; j < 7; ++j) pk[j] = __shfl(row[j], k);
+    for (int j = k; j < 7; ++j) pk[j] = lane_value<k>(row[j]);
     ok = ok && pk[k] > 0.0;
     const double f = row[k] / pk[k];
     if (i != k) {
@@ -157,7 +166,13 @@ __device__ __forceinline__ bool solve6_rows(double tot, int lane, double* d_out)
       for (int j = k + 1; j < 7; ++j) row[j] -= f * pk[j];
       row[k] = 0.0;
     }
-  }
+  };
+  pivot(std::integral_constant<int, 0>());
+  pivot(std::integral_constant<int, 1>());
+  pivot(std::integral_constant<int, 2>());
+  pivot(std::integral_constant<int, 3>());
+  pivot(std::integral_constant<int, 4>());
+  pivot(std::integral_constant<int, 5>());
   double diag = row[0];
 #pragma unroll
   for (int j = 1; j < 6; ++j) diag = i == j ? row[j] : diag;
@@ -214,7 +229,7 @@ __device__ __forceinline__ void gauss_newton(const rf_point* cache, const double
 #pragma unroll
       for (int w = 0; w < RF_T / 64; ++w) tot += s_w[w][lane];
     }
-    const double cost_new = __shfl(tot, 27);
+    const double cost_new = lane_value<27>(tot);
     bool stop = false;
     if (it < 0) {
       it = 0;
@@ -234,9 +249,8 @@ __device__ __forceinline__ void gauss_newton(const rf_point* cache, const double
       if (!ok) {
         stop = true;
       } else {
-        double d[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) d[j] = __shfl(di, j);
+        const double d[6] = {lane_value<0>(di), lane_value<1>(di), lane_value<2>(di), lane_value<3>(di), lane_value<4>(di),
+                             lane_value<5>(di)};
         double ca, cb;
         rodrigues_coefficients(d[3] * d[3] + d[4] * d[4] + d[5] * d[5], &ca, &cb);
         const double Wx[9] = {0.0, -d[5], d[4], d[5], 0.0, -d[3], -d[4], d[3], 0.0};
