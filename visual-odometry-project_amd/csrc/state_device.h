@@ -42,6 +42,20 @@ __host__ __device__ inline long long table_lookup(const double* table, int len, 
   return (max_it >= 0 && max_it < k) ? max_it : k;
 }
 
+// The same count by all 64 lanes of a wave together (orat uniform): 64 blocks of 64 thresholds, one probe per lane and
+// level -- two dependent reads instead of twelve on the replay's serial path.  Tables above 4096 entries: bisection.
+__device__ __forceinline__ long long table_lookup_wave(const double* table, int len, long long max_it, double orat, int lane) {
+  if (len > 4096) return table_lookup(table, len, max_it, orat);
+  const int nb = (len + 63) >> 6;
+  const bool whole = lane < nb && table[1 + min(lane * 64 + 63, len - 1)] <= orat;   // every threshold of block `lane`
+  const int full = __popcll(__ballot(whole));                                         // (sorted: a prefix of the blocks)
+  const int idx = full * 64 + lane;
+  const bool one = idx < len && table[1 + idx] <= orat;
+  const int lo = min(full * 64, len) + __popcll(__ballot(one));
+  const long long k = lo == len ? 0x7fffffffffffffffll : (long long)table[0] + lo;
+  return (max_it >= 0 && max_it < k) ? max_it : k;
+}
+
 using replay_args = ::vo_replay_args;
 
 constexpr int RP_TABLE_LDS = 4097;
@@ -124,7 +138,7 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
           double o = 1.0 - (double)best / (double)N;
           o = fmin(fmax(o, 0.01), 0.99);
           orat = o;
-          n_it = table_lookup(tb, a.table_len, a.max_it, o);
+          n_it = table_lookup_wave(tb, a.table_len, a.max_it, o, lane);
         }
         cur = ep + 1;
       }
