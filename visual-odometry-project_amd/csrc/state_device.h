@@ -103,22 +103,16 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
       if (consumed >= 0) continue;                // (the loop has ended; only the statistics go on)
       const int c = v ? cs[q] : -1;
       const unsigned long long rmask = __ballot((vb & 2) != 0);
-      int pm = c;                                   // inclusive prefix maximum
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(pm, off);
-        if (lane >= off) pm = max(pm, o);
-      }
-      int epm = __shfl_up(pm, 1);
-      if (lane == 0) epm = -1;
-      epm = max(epm, best);
-      const unsigned long long imask = __ballot(v && c > epm);
       const long long n_here = n + __popcll(vmask & lt);       // iterations counted before this lane's draw
       int cur = 0;
       for (;;) {
         const unsigned long long ge = cur >= 64 ? 0ull : ~((1ull << cur) - 1ull);
         const unsigned long long smask = __ballot(n_here >= n_it) & ge;   // the `while` test fails before this draw
-        const unsigned long long emask = imask & ge;
+        // The hypotheses that improve on everything before them, one at a time: the first lane from `cur` on whose count
+        // beats the running best is one (every lane before it does not), and it becomes the running best.  (A prefix
+        // maximum over the 64 counts said the same for all lanes at once, at six dependent cross-lane steps per round
+        // whether or not the round held an improvement; most do not.)
+        const unsigned long long emask = __ballot(c > best) & ge;
         const int sp = smask ? __ffsll((long long)smask) - 1 : 64;
         const int ep = emask ? __ffsll((long long)emask) - 1 : 64;
         if (sp <= ep && sp < 64) {
