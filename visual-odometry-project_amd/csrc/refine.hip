@@ -107,16 +107,45 @@ __device__ __forceinline__ void accumulate(const rf_point* cache, const double* 
     add_point(load_point(X, x, N, mask8, mask_bits, i), R, t, fx, fy, cx, cy, s);
 }
 
+// the value of lane (l ^ OFF): a DPP move where one exists (8: row_ror:8, 2 and 1: quad_perm), the LDS crossbar otherwise
+template <int OFF>
+__device__ __forceinline__ double lane_xor(double x) {
+  if constexpr (OFF == 8 || OFF == 2 || OFF == 1) {
+    constexpr int ctrl = OFF == 8 ? 0x128 : (OFF == 2 ? 0x4E : 0xB1);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  } else {
+    return __shfl_xor(x, OFF);
+  }
+}
+
 // One butterfly step of the wave-wide sums: the lane pair (l, l ^ OFF) splits the CNT values it still
 // carries between its two lanes, so the number of values halves while the number of lanes summed doubles.
+// (OFF = 32 and 16: gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper lanes (odd rows) of one register
+//  with the lower lanes (even rows) of another -- exactly this step's "keep one half, send the other", so the two values
+//  are swapped in place and added, no select and no trip through the LDS crossbar; a + b = b + a, same bits.)
 template <int CNT, int OFF>
 __device__ __forceinline__ void fold_step(double* v, int lane) {
+  if constexpr (OFF == 32 || OFF == 16) {
+#pragma unroll
+    for (int k = 0; k < CNT / 2; ++k) {
+      const unsigned alo = (unsigned)__double2loint(v[k]), ahi = (unsigned)__double2hiint(v[k]);
+      const unsigned blo = (unsigned)__double2loint(v[k + CNT / 2]), bhi = (unsigned)__double2hiint(v[k + CNT / 2]);
+      const auto rl = OFF == 32 ? __builtin_amdgcn_permlane32_swap(alo, blo, false, false)
+                                : __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+      const auto rh = OFF == 32 ? __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false)
+                                : __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+      v[k] = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+    }
+    return;
+  }
   const bool hi = (lane & OFF) != 0;
 #pragma unroll
   for (int k = 0; k < CNT / 2; ++k) {
     const double keep = hi ? v[k + CNT / 2] : v[k];
     const double send = hi ? v[k] : v[k + CNT / 2];
-    v[k] = keep + __shfl_xor(send, OFF);
+    v[k] = keep + lane_xor<OFF>(send);
   }
 }
 
@@ -130,7 +159,7 @@ __device__ __forceinline__ double wave_sums(const double* s, int lane) {
   fold_step<8, 8>(v, lane);
   fold_step<4, 4>(v, lane);
   fold_step<2, 2>(v, lane);
-  return v[0] + __shfl_xor(v[0], 1);
+  return v[0] + lane_xor<1>(v[0]);
 }
 
 // lane K's value in every lane, through a scalar register (K is a compile-time constant: v_readlane_b32, no trip
