@@ -162,6 +162,17 @@ __device__ __forceinline__ double wave_sums(const double* s, int lane) {
   return v[0] + lane_xor<1>(v[0]);
 }
 
+// sum of an int over the 64 lanes, in all of them: four DPP adds inside each row of 16, the four row sums through scalar
+// registers (six dependent trips through the LDS crossbar as a __shfl_xor butterfly)
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+
 // lane K's value in every lane, through a scalar register (K is a compile-time constant: v_readlane_b32, no trip
 // through the LDS crossbar as __shfl makes)
 template <int K>
@@ -474,8 +485,7 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
       if (slot < TAIL_LIST) s_list[slot] = i;
     }
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off);
+  count = wave_sum_i32(count);
   if (lane == 0) s_cand[wv] = count;
   __syncthreads();
   int n_cand = 0;
@@ -566,11 +576,8 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
       for (int i = tid; i < n2; i += RF_T)
         if (B.cand[i]) triangulate(i);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      dropped += __shfl_xor(dropped, off);
-      land += __shfl_xor(land, off);
-    }
+    dropped = wave_sum_i32(dropped);
+    land = wave_sum_i32(land);
     if (lane == 0) {
       if (dropped) atomicAdd(&s_tail[0], dropped);
       if (land) atomicAdd(&s_tail[1], land);
