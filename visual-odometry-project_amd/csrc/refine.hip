@@ -418,6 +418,8 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   const double* x = job.B.kp64;
   const int cap = job.B.pitch;
   const bool lds_table = job.do_replay && job.rp.table_len + 1 <= RP_TABLE_LDS;
+  replay_chunk first;                              // (wave 0: the replay's first reads go out before everything else)
+  if (job.do_replay && wv == 0) replay_fetch(job.rp, lane, 0, first);
   if (lds_table)
     for (int k = tid; k < job.rp.table_len + 1; k += RF_T) s_table[k] = job.rp.table[k];
   // coordinates first (the population's size and the inlier mask are known only after the replay)
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   for (int k = 0; k < RF_PT; ++k) cache[k] = load_point(X, x, cap, nullptr, nullptr, k * RF_T + tid);
   if (tid == 0) s_state = 0;
   __syncthreads();
-  if (job.do_replay && wv == 0) replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table);
+  if (job.do_replay && wv == 0) replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table, first, true);
   __syncthreads();
   if (tid == 0 && job.stamps) ctl->ts[5] = wall_clock64();
   if (ctl->fault) {                             // (raised by the replay: the host finishes this step)

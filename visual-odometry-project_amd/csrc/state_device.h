@@ -67,8 +67,23 @@ constexpr int RP_TABLE_LDS = 4097;
 // The flags and counts of 16 rounds are requested together; tb: the threshold table (table_len + 1 doubles, in
 // LDS when the caller staged it there).  Leaves the accepted pose in ctl->best_pose, its mask row in a.best_mask, the loop's bookkeeping in ctl; on a
 // step the device cannot finish alone, ctl->fault.  Must be called by all 64 lanes of the wave.
+// flags and counts of the 1024 hypotheses from sbase on, 16 per lane, all requests in flight together
+struct replay_chunk {
+  int vbs[16], cs[16];
+};
+__device__ __forceinline__ void replay_fetch(const replay_args& a, int lane, int sbase, replay_chunk& ch) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int h = min(sbase + 64 * q + lane, a.hyp - 1);
+    ch.vbs[q] = a.valid[h];
+    ch.cs[q] = a.counts[h];
+  }
+}
+
+// ch: working storage; fetched0: it already holds the chunk of sbase = 0 (the pose kernel requests it in front of its
+// staging of the table and the coordinates, so that the replay does not start with a memory round trip of its own)
 __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const replay_args& a, int lane,
-                                            const double* tb) {
+                                            const double* tb, replay_chunk& ch, bool fetched0) {
   if (lane == 0) {            // counters the bookkeeping kernels of this step add to
     ctl->n_cand = 0;
     ctl->n_dropped = 0;
@@ -84,13 +99,9 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
   bool risky_seen = false;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int sbase = 0; sbase < hyp; sbase += 1024) {
-    int vbs[16], cs[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int h = min(sbase + 64 * q + lane, hyp - 1);
-      vbs[q] = a.valid[h];
-      cs[q] = a.counts[h];
-    }
+    if (!(fetched0 && sbase == 0)) replay_fetch(a, lane, sbase, ch);
+    const int (&vbs)[16] = ch.vbs;
+    const int (&cs)[16] = ch.cs;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int base = sbase + 64 * q;
