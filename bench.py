@@ -5,6 +5,13 @@
   (N > 1: one rank per GPU under torch.distributed.run; started that way by the driver, or by this script
    itself when it is called directly with --gpus N)
 
+The stream is SURVEY.md 8d's: 100 frames of a strictly forward drive (0.8 m per frame, src/main.py:248), all resident
+in HBM, walked 2 -> 99 pass after pass.  At the end of a pass the look-ahead is drained and the state the bootstrap
+handed over for frame 2 is put back on the device (vo_pipeline_rewind: one device-to-device copy, that frame's pyramid
+and detection queued behind it, no host synchronisation; the estimator's RANSAC fields and generator go on) -- the seam
+is inside the timed region.  Tracks leave the field of view as the camera advances, so the re-detect of
+klt.py:207-230 fires at the rate the stream produces and the detector executes when it is needed.
+
 One "step" = one frame of the reference's steady-state loop (src/main.py:248-286, KLT tracker mode with the
 Harris detector) on a 1376x1241 frame that is already resident in HBM, everything on the GPU:
   pyramid(next) | Harris response + exact greedy NMS (2000 keypoints) on next, for a sequence whose track count is
@@ -43,14 +50,18 @@ H, W, N_KP, HYP, WIN, MAX_LEVEL = 1241, 1376, 2000, 1000, 15, 2
 CONFIG = os.environ.get("VO_BENCH_CONFIG", "cfg2")
 if CONFIG == "cfg5":     # BASELINE.json configs[4]: the stress shape (secondary line under profiles/, the default stays cfg-2)
     H, W, N_KP, HYP, MAX_LEVEL = 2160, 3840, 8000, 4000, 3
-N_FRAMES = 8
+N_FRAMES = 30 if CONFIG == "cfg5" else 100    # cfg-2 100 frames, cfg-5 30 frames
+PASS_START = 2           # the bootstrap uses frames 0 and 2 (main.py:204-209); a pass walks PASS_START -> N_FRAMES - 1
+S_LEG = 16               # sequences per GPU of the in-line throughput leg
+CPU_BASELINE_FRAMES = int(os.environ.get("VO_BENCH_CPU_FRAMES", "32"))
+RENDER_WORKERS = int(os.environ.get("VO_BENCH_RENDER_WORKERS", str(max(1, min(12, (os.cpu_count() or 2) - 2)))))
 REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
 EXCHANGE_EVERY = int(os.environ.get("VO_BENCH_EXCHANGE_EVERY", "16"))   # frames per all-gather of {pose, landmarks} records
 REDETECT_POSE = os.environ.get("VO_BENCH_REDETECT_POSE", "current")   # see vo_pipeline_config.redetect_start_pose
 DETECT_MARGIN = float(os.environ.get("VO_BENCH_DETECT_MARGIN", "0.02"))   # see vo_pipeline_config.detect_margin (< 0: every frame)
 PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-PROFILE_TAG = "r02"
+PROFILE_TAG = os.environ.get("VO_BENCH_PROFILE_TAG", "r03")
 
 
 def algorithmic_bytes(kernel_name, n_in, n_tracked, n_tri):
@@ -129,15 +140,34 @@ class ResidentSequence:
         return f
 
 
-def walk(start, n, steps):
-    """Frame indices from `start`, back and forth over 0..n-1 (consecutive frames are always neighbours)."""
-    idx, d, out = start, 1, [start]
-    for _ in range(steps):
-        if idx + d < 0 or idx + d >= n:
-            d = -d
-        idx += d
-        out.append(idx)
-    return out
+class Walker:
+    """Drives one pipeline over the resident stream: frames PASS_START -> n_frames - 1, then the seam (drain, rewind
+    to the checkpoint taken at PASS_START), pass after pass; at most two steps in flight (one frame of look-ahead)."""
+
+    def __init__(self, pipe, n_frames):
+        self.pipe, self.n_frames, self.cur, self.passes = pipe, n_frames, PASS_START, 0
+
+    def run(self, n, lookahead=True, on_step=None):
+        """n steps; on_step(next_frame_index, [StepResult per sequence]) after each collect."""
+        pipe, flight, submitted, done = self.pipe, [], 0, 0
+        depth = 2 if lookahead else 1
+        while done < n:
+            while submitted < n and len(flight) < depth:
+                if self.cur + 1 >= self.n_frames:              # the seam
+                    if flight:
+                        break                                  # (drain first: rewind wants nothing in flight)
+                    pipe.rewind()
+                    self.cur = PASS_START
+                    self.passes += 1
+                pipe.submit(self.cur, self.cur + 1)
+                flight.append(self.cur + 1)
+                self.cur += 1
+                submitted += 1
+            rs = pipe.collect_all()
+            b = flight.pop(0)
+            done += 1
+            if on_step is not None:
+                on_step(b, rs)
 
 
 def bootstrap_state(stream):
@@ -161,24 +191,28 @@ def bootstrap_state(stream):
     return state
 
 
-def oracle_leg(stream, state, gpu_results, gpu_state, frames):
+def oracle_leg(stream, state, gpu_results, gpu_state, state_frames):
     """The CPU oracle of the same loop (tests/pipeline_oracle.py: pinned bookkeeping classes + CPU oracles) on the
-    first `frames` frames: (i) parity of the GPU results against it, (ii) its time = the CPU baseline ("port")."""
+    first len(gpu_results) frames of the pass: (i) parity of the GPU's records against it, and of the GPU's Features
+    arrays after `state_frames` frames, (ii) its time = the CPU baseline ("port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import harris_np
     from pipeline_oracle import OracleLoop
+    frames = len(gpu_results)
     orc = OracleLoop(stream, N_KP, WIN, MAX_LEVEL, refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE)
-    orc.set_state(2, state.curr_frame.features, state.curr_pose, state.prev_pose)
-    order = walk(2, stream.n, frames)
+    orc.set_state(PASS_START, state.curr_frame.features, state.curr_pose, state.prev_pose)
+    order = list(range(PASS_START, PASS_START + frames + 1))
     dR = dt = 0.0
     exact = True
     t0 = time.perf_counter()
     refs = []
     for b in order[1:]:
         refs.append(orc.step(b))
-        # the GPU step also runs the detector on every new frame (the keypoints the next step may append)
-        harris_np.nms_keypoints_fast(harris_np.harris_scores(stream.image(b), 9, 0.09), N_KP, 5)
+        # the reference's tracker runs its detector only when it re-detects (klt.py:207-230); the oracle loop does that
+        # inside step().  (Rounds 1-2 added one NumPy Harris + NMS per frame here, matching a GPU step that detected on
+        # every frame; the GPU loop no longer does.)
     cpu_s = time.perf_counter() - t0
+    n_redetect = int(sum(1 for ref in refs if ref["n_before"] < 0.8 * N_KP))      # klt.py:208-212
     for ref, r in zip(refs, gpu_results):
         Rr, tr = np.array(r.R_refined).reshape(3, 3), np.array(r.t_refined)
         dR = max(dR, float(np.abs(Rr - ref["R_ref"]).max()))
@@ -186,7 +220,7 @@ def oracle_leg(stream, state, gpu_results, gpu_state, frames):
         exact &= (r.n_tracked, r.n_triangulated, r.n_inliers, r.draws_consumed, r.ransac_iterations, r.n_candidates,
                   r.n_landmarks) == (ref["n_tracked"], ref["n_tri"], ref["n_inliers"], ref["draws"], ref["iters"],
                                      ref["n_cand"], ref["n_landmarks"])
-    f = refs[-1]["features"]
+    f = refs[state_frames - 1]["features"]
     exact &= bool(np.array_equal(gpu_state["keypoints"], f.keypoints.astype(np.float64)) and
                   np.array_equal(gpu_state["state"], f.state) and
                   np.array_equal(gpu_state["candidate_mask"], f.candidate_mask) and
@@ -194,14 +228,15 @@ def oracle_leg(stream, state, gpu_results, gpu_state, frames):
     with np.errstate(invalid="ignore"):
         d = np.abs(gpu_state["landmarks"] - f.landmarks)[:, :, 0].max(axis=1)
         lm = float(np.nanmax(d / np.maximum(1.0, np.linalg.norm(f.landmarks[:, :, 0], axis=1)))) if f.length else 0.0
-    parity = {"frames": frames, "max_abs_dR": dR, "max_rel_dt": dt, "max_rel_dlandmark": lm,
+    parity = {"frames": frames, "redetect_frames": n_redetect, "max_abs_dR": dR, "max_rel_dt": dt,
+              "max_rel_dlandmark_after_%d_frames" % state_frames: lm,
               "counts_masks_keypoints_states_tracks_exact": bool(exact),
-              "note": "refined pose / landmarks vs the CPU oracle of the same loop on the same frames (tolerance of the "
-                      "metric: 1e-4 rel.); integer and index results must be identical"}
+              "note": "refined pose of every frame / Features arrays after %d frames vs the CPU oracle of the same loop on the same "
+                      "frames (tolerance of the metric: 1e-4 rel.); integer and index results must be identical" % state_frames}
     base = {"value": frames / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same stream through the CPU oracle of the loop (tests/pipeline_oracle.py: "
-                      "C KLT / P3P, NumPy RANSAC / refinement / DLT / bookkeeping) plus NumPy Harris + the oracle's fast "
-                      "exact NMS walk per frame, single thread" % frames}
+            "sample": "the first %d frames of the same stream through the CPU oracle of the loop (tests/pipeline_oracle.py: "
+                      "C KLT / P3P, NumPy RANSAC / refinement / DLT / bookkeeping; NumPy Harris + the oracle's fast exact NMS walk "
+                      "on the %d frame(s) that re-detect), single thread, %.1f s" % (frames, n_redetect, cpu_s)}
     return parity, base
 
 
@@ -242,8 +277,9 @@ def cfg3_main(args):
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     from vo import _native, synthetic
     ctx = _native.Context(0)
-    stream = synthetic.Stream(N_FRAMES, H, W)
-    order = walk(0, N_FRAMES, args.warmup + args.steps + 8)
+    need = args.warmup + args.steps + 8 + 1
+    stream = synthetic.Stream(N_FRAMES, H, W).prefetch(range(min(need, N_FRAMES)), workers=RENDER_WORKERS)
+    order = [k % N_FRAMES for k in range(need)]          # forward; a run longer than the stream starts over at frame 0
     state = {"desc": ctx.sift(stream.image(order[0]), cap=2000)[1], "pos": 0}
     counts = []
 
@@ -314,6 +350,55 @@ def spawn_ranks(args):
     raise SystemExit(subprocess.run(cmd).returncode)
 
 
+def make_pipeline(ctx, streams, states, S, detect_margin, hyp=None):
+    """A pipeline over the resident streams of S sequences, every frame uploaded, the bootstraps' states handed over
+    for frame PASS_START and checkpointed there (the seam of every later pass)."""
+    from vo import _native
+    pipe = _native.Pipeline(ctx, H, W, N_FRAMES, streams[0].K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
+                            hyp=hyp or HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
+                            refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, sequences=S,
+                            detect_margin=detect_margin, debug_never_detect=int(os.environ.get("VO_BENCH_NEVER_DETECT", "0")))
+    for q in range(S):
+        for i in range(N_FRAMES):
+            pipe.set_frame(i, streams[q].image(i), seq=q)
+        pipe.set_state(PASS_START, states[q].curr_frame.features, states[q].curr_pose, states[q].prev_pose,
+                       num_features=N_KP, seq=q)
+    pipe.checkpoint()
+    return pipe
+
+
+def loop_stats(records):
+    """What the loop did over `records` (StepResults of all sequences of the timed steps)."""
+    return {"features_in_median": int(np.median([r.n_features_in for r in records])),
+            "tracked_median": int(np.median([r.n_tracked for r in records])),
+            "landmarks_p3p_median": int(np.median([r.n_triangulated for r in records])),
+            "inliers_median": float(np.median([r.n_inliers for r in records])),
+            "candidates_median": float(np.median([r.n_candidates for r in records])),
+            "ransac_iters_median": float(np.median([r.ransac_iterations for r in records])),
+            "redetect_fraction_of_steps": float(np.mean([r.redetected for r in records])),
+            "detector_executed_fraction_of_steps": float(np.mean([r.detector_ran for r in records])),
+            "steps_finished_by_host_path": int(sum(r.recovered for r in records)),
+            "refine_steps_median": float(np.median([r.refine_iterations for r in records]))}
+
+
+def timed_leg(ctx, pipe, S, warm, steps):
+    """warm untimed + `steps` timed steps of `pipe` (look-ahead, seams included); the leg's dict."""
+    w = Walker(pipe, N_FRAMES)
+    recs = []
+    w.run(warm)
+    ctx.sync()
+    t0 = time.perf_counter()
+    w.run(steps, on_step=lambda b, rs: recs.extend(rs))
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    st = loop_stats(recs)
+    return {"frames_per_s": round(S * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "sequences_per_gpu": S, "passes_started_in_timed_region": w.passes,
+            "redetect_fraction_of_steps": round(st["redetect_fraction_of_steps"], 4),
+            "detector_executed_fraction_of_steps": round(st["detector_executed_fraction_of_steps"], 4),
+            "steps_finished_by_host_path": st["steps_finished_by_host_path"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,12 +406,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the drop-in API frames/s leg")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the in-line detector-every-frame and 16-sequences legs (profiling runs of the headline alone)")
     ap.add_argument("--no-lookahead", dest="lookahead", action="store_false",
                     help="one blocking vo_pipeline_step per frame instead of submitting frame k+1 before "
                          "collecting frame k (vo_pipeline_submit / _collect)")
     ap.add_argument("--sequences", type=int, default=int(os.environ.get("VO_BENCH_SEQUENCES", "1")),
                     help="independent sequences per GPU advancing through the same launches (vo_pipeline_config.sequences); "
-                         "the headline stays at 1, profiles/ holds the lines for 4 and 16")
+                         "the headline stays at 1, the line carries a 16-sequences leg")
     ap.add_argument("--exchange", action="store_true",
                     help="run the all-gather of {pose, landmarks} records even on one GPU (always on for --gpus > 1)")
     args = ap.parse_args()
@@ -342,6 +429,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    S = max(1, args.sequences)
+    legs = world == 1 and not args.no_legs and CONFIG == "cfg2"
+    # the frames first, in worker processes, before this process touches the GPU: every sequence of every rank is its
+    # own scene (its own texture seed); the 16-sequences leg gets 16 more
+    from vo import synthetic
+    workers = max(1, RENDER_WORKERS // max(1, world))
+    t_r = time.perf_counter()
+    streams = [synthetic.Stream(N_FRAMES, H, W, seed=2023 + rank * S + q) for q in range(S)]
+    leg_streams = [synthetic.Stream(N_FRAMES, H, W, seed=3023 + q) for q in range(S_LEG)] if legs and S != S_LEG else []
+    jobs = [(st.start + i, H, W, st.seed) for st in streams + leg_streams for i in range(N_FRAMES)]
+    for (st, i), im in zip([(st, i) for st in streams + leg_streams for i in range(N_FRAMES)],
+                           synthetic.render_images(jobs, workers)):
+        st._img[i] = im
+    render_s = time.perf_counter() - t_r
+
     import torch
     import torch.distributed as dist
     torch.set_num_threads(4)
@@ -351,11 +453,10 @@ def main():
     exchange = False
     want_exchange = world > 1 or args.exchange
 
-    from vo import _native, sharding, synthetic
+    from vo import _native, sharding
     # torch's own (null-stream) work first, then the pipeline's streams: a stream is attached to one of the four
     # hardware queues when it first runs, and the frame loop's four streams should not share one among themselves
     cap = N_KP
-    S = max(1, args.sequences)
     rec_len = sharding.record_length(cap)
     recs = [torch.zeros(EXCHANGE_EVERY * S * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
     gathered = [torch.zeros(world * EXCHANGE_EVERY * S * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
@@ -365,60 +466,39 @@ def main():
     os.environ["VO_DEVICE"] = str(local)
     ctx = _native.Context(local, stream=comp.cuda_stream)
     _native.set_default_context(ctx)      # the host classes of the bootstrap run on the same context / stream
-    # every sequence of every rank is its own scene (its own texture seed), bootstrapped by itself
-    streams = [synthetic.Stream(N_FRAMES, H, W, seed=2023 + rank * S + q) for q in range(S)]
     stream = streams[0]
-    pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
-                            hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
-                            refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, sequences=S,
-                            detect_margin=DETECT_MARGIN, debug_never_detect=int(os.environ.get("VO_BENCH_NEVER_DETECT", "0")))
     states = [bootstrap_state(st) for st in streams]
     state = states[0]
-    for q in range(S):
-        for i in range(N_FRAMES):
-            pipe.set_frame(i, streams[q].image(i), seq=q)
-        pipe.set_state(2, states[q].curr_frame.features, states[q].curr_pose, states[q].prev_pose, num_features=N_KP, seq=q)
+    pipe = make_pipeline(ctx, streams, states, S, DETECT_MARGIN)
     n_boot = int((state.curr_frame.features.state == 2).sum())
-
-    batch_fill, batch_buf = 0, 0
-
-    order = walk(2, N_FRAMES, args.warmup + args.steps + 96)
-    pos = 0
-    log = []
+    walker = Walker(pipe, N_FRAMES)
+    batch = {"fill": 0, "buf": 0}
 
     def run(n, record=False, lookahead=None):
         # Default: one frame of look-ahead, as a camera stream gives it -- frame k+1 is submitted (all of its GPU
         # work enqueued) before the record of frame k is read.  Every frame is processed in full and the results
         # are those of the blocking call (tests/test_gpu_pipeline.py).  --no-lookahead: one blocking step per frame.
-        nonlocal pos, batch_fill, batch_buf
-        la = args.lookahead if lookahead is None else lookahead
         out = []
-        if la:
-            pipe.submit(order[pos], order[pos + 1])
-        for k in range(n):
-            a, b = order[pos], order[pos + 1]
-            pos += 1
-            if la:
-                if k + 1 < n:
-                    pipe.submit(order[pos], order[pos + 1])
-                rs = pipe.collect_all()
-            else:
-                pipe.submit(a, b)
-                rs = pipe.collect_all()
+        left = [n]
+
+        def on_step(b, rs):
+            left[0] -= 1
             if exchange:
                 # The record of every collected step is queued on the pipeline's stream (no host synchronisation);
                 # every EXCHANGE_EVERY frames the records gathered so far go to all ranks in ONE all-gather on the
                 # side stream (fewer, larger collectives: issuing one costs the host ~45 us, a third of a step).
                 for q in range(S):
-                    pipe.export_state_post(rs[q], cap, recs[batch_buf].data_ptr() + batch_fill * rec_len * 8, seq=q)
-                    batch_fill += 1
-                if batch_fill == EXCHANGE_EVERY * S or k == n - 1:
+                    pipe.export_state_post(rs[q], cap, recs[batch["buf"]].data_ptr() + batch["fill"] * rec_len * 8, seq=q)
+                    batch["fill"] += 1
+                if batch["fill"] == EXCHANGE_EVERY * S or left[0] == 0:
                     pipe.export_state_join(comm.cuda_stream)
-                    sharding.allgather_records(recs[batch_buf], gathered[batch_buf])
-                    batch_buf ^= 1
-                    batch_fill = 0
+                    sharding.allgather_records(recs[batch["buf"]], gathered[batch["buf"]])
+                    batch["buf"] ^= 1
+                    batch["fill"] = 0
             if record:
                 out.append((b, rs))
+
+        walker.run(n, lookahead=args.lookahead if lookahead is None else lookahead, on_step=on_step)
         return out
 
     def fence():
@@ -427,11 +507,12 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
 
-    # ---- untimed: the first frames, blocking, kept for the parity / CPU-baseline leg ----
+    # ---- untimed: the whole first pass, blocking.  Its first frames are kept for the parity / CPU-baseline leg, all of
+    # it for the comparison with the analytic ground truth ----
     ORACLE_FRAMES = 4
     first = run(ORACLE_FRAMES, record=True, lookahead=False)
     first_state = pipe.get_state()
-    early = first + run(12, record=True, lookahead=False)     # ground-truth comparison: the frames right after the bootstrap
+    first_pass = first + run(N_FRAMES - 1 - PASS_START - ORACLE_FRAMES, record=True, lookahead=False)
     ctx.sync()
     # The process group comes up only now: HIP spreads streams over its hardware queues in the order they first run,
     # and the pipeline's main stream should not end up sharing a queue with RCCL's (measured in round 1).
@@ -446,7 +527,7 @@ def main():
     run(args.warmup)
     ctx.prof_enable(-1)
     pipe.prof_reset()
-    prof_steps = run(16, record=True)
+    run(16)
     per_kernel = {}
     for kid in range(_native.K_COUNT):
         ms, n = pipe.prof_read(kid)
@@ -461,6 +542,7 @@ def main():
     pipe.prof_reset()
     ctx.prof_set_sampling(PROF_EVERY)
     ctx.prof_enable(dom_id)
+    passes0 = walker.passes
     fence()
     t0 = time.perf_counter()
     timed = run(args.steps, record=True)
@@ -477,10 +559,9 @@ def main():
 
     if rank == 0:
         every = [r for _, rs in timed for r in rs]           # all sequences' records
-        res = [rs[0] for _, rs in timed]                     # sequence 0: chain stamps, ground truth, oracle
-        n_in = int(np.median([r.n_features_in for r in every]))
-        n_trk = int(np.median([r.n_tracked for r in every]))
-        n_tri = int(np.median([r.n_triangulated for r in every]))
+        res = [rs[0] for _, rs in timed]                     # sequence 0: chain stamps
+        lstats = loop_stats(every)
+        n_in, n_trk, n_tri = lstats["features_in_median"], lstats["tracked_median"], lstats["landmarks_p3p_median"]
         avg_us = dom_ms / max(dom_n, 1) * 1e3
 
         def abytes(k):                                       # one launch processes all S sequences
@@ -502,36 +583,38 @@ def main():
         def us(k):
             return per_kernel[k][0] / per_kernel[k][1] * 1e3
 
-        # pose against the analytic ground truth of the stream: the bootstrap fixes the unit of length (|t| = 1 between
-        # frames 0 and 2, 1.6 m apart), positions compared after that one scale
+        # pose against the analytic ground truth of the stream over the whole first pass: the bootstrap fixes the unit of
+        # length (|t| = 1 between frames 0 and 2, 1.6 m apart), positions compared after that one scale
         scale = 2 * synthetic.STEP_Z / max(np.linalg.norm(state.curr_pose[:3, 3]), 1e-12)
         gt_err = []
-        for b, rs in early:
+        for b, rs in first_pass:
             r = rs[0]
             Twc = r.pose_world_cam()
             gt = np.linalg.inv(stream.T_world_cam(0)) @ stream.T_world_cam(b)
             gt_err.append((float(np.linalg.norm(Twc[:3, :3] - gt[:3, :3])), float(np.linalg.norm(scale * Twc[:3, 3] - gt[:3, 3]))))
         # device clock (100 MHz) stamps the kernels of the chain leave in every record: where a step's time goes
+        # (steps right behind a seam start from a drained pipeline: their period is the seam's, not the chain's)
         ts = np.array([[r.ts[k] for k in range(8)] for r in res], dtype=np.float64) * 1e-2          # us
+        period = np.diff(ts[:, 1])
+        seam = np.array([timed[i + 1][0] == PASS_START + 1 for i in range(len(timed) - 1)], dtype=bool)
+        inpass = period[~seam] if (~seam).any() else period
         chain = {"tracker_start_to_regroup_start": float(np.median(ts[:, 1] - ts[:, 0])),
                  "regroup_to_hypotheses": float(np.median(ts[:, 2] - ts[:, 1])),
                  "hypotheses_to_pose": float(np.median(ts[:, 3] - ts[:, 2])),
                  "pose_to_landmarks": float(np.median(ts[:, 4] - ts[:, 3])),
-                 "pose_kernel_replay_refine_candidates": [float(np.median(ts[:, 6] - ts[:, 3])), float(np.median(ts[:, 7] - ts[:, 6])),
-                                                          float(np.median(ts[:, 4] - ts[:, 7]))],
                  "landmarks_to_record": float(np.median(ts[:, 5] - ts[:, 4])),
-                 "record_to_next_regroup": float(np.median(ts[1:, 1] - ts[:-1, 5])),
-                 "regroup_to_next_tracker_start": float(np.median(ts[1:, 0] - ts[:-1, 1])),
-                 "step_period": float(np.median(np.diff(ts[:, 1]))),
-                 "step_period_mean": float(np.mean(np.diff(ts[:, 1]))),
-                 "step_period_percentiles_10_50_90_99": [float(v) for v in np.percentile(np.diff(ts[:, 1]), [10, 50, 90, 99])],
-                 "slow_steps": [{"i": int(i), "period": float(v), "redetected": [int(res[i].redetected), int(res[i + 1].redetected)],
-                                 "n_in": [int(res[i].n_features_in), int(res[i + 1].n_features_in)],
-                                 "stages_i": [float(x) for x in np.diff(ts[i, :6])], "stages_i1": [float(x) for x in np.diff(ts[i + 1, :6])],
-                                 "rec_to_regroup": float(ts[i + 1, 1] - ts[i, 5])}
-                                for i, v in enumerate(np.diff(ts[:, 1])) if v > 400.0][:10],
-                 "record_to_next_regroup_percentiles_10_50_90_99": [float(v) for v in np.percentile(ts[1:, 1] - ts[:-1, 5], [10, 50, 90, 99])],
+                 "record_to_next_regroup": float(np.median((ts[1:, 1] - ts[:-1, 5])[~seam])) if (~seam).any() else None,
+                 "regroup_to_next_tracker_start": float(np.median((ts[1:, 0] - ts[:-1, 1])[~seam])) if (~seam).any() else None,
+                 "step_period": float(np.median(inpass)),
+                 "step_period_mean": float(np.mean(inpass)),
+                 "step_period_percentiles_10_50_90_99": [float(v) for v in np.percentile(inpass, [10, 50, 90, 99])],
+                 "seam_period": [float(v) for v in period[seam]][:8],
+                 "redetect_step_period_median": (float(np.median([period[i] for i in range(len(period)) if res[i + 1].redetected and not seam[i]]))
+                                                 if any(res[i + 1].redetected and not seam[i] for i in range(len(period))) else None),
                  "unit": "us, medians over the timed steps, from wall_clock64() stamps of each kernel's first work item"}
+        if os.environ.get("VO_POSE_STAMPS"):
+            chain["pose_kernel_replay_refine_candidates"] = [float(np.median(ts[:, 6] - ts[:, 3])), float(np.median(ts[:, 7] - ts[:, 6])),
+                                                             float(np.median(ts[:, 4] - ts[:, 7]))]
         out = {
             "metric": "VO frames/sec at 1376x1241, 2k keypoints; pose err vs reference" if CONFIG != "cfg5" else
                       "VO frames/sec at 3840x2160, 8k keypoints (stress configuration)",
@@ -546,14 +629,20 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s: %dx%d KITTI-shaped synthetic stream, per frame: Harris+NMS %d kp (see detector), re-detect "
-                                   "append, KLT %d-level 15x15 of all tracks, Matches regroup, P3P-RANSAC %d hyps + device "
-                                   "replay of the sequential rule, pose refinement, State bookkeeping, per-track-pose "
-                                   "candidate DLT, cheirality; %d independent sequence(s) per GPU"
-                                   % ("cfg-5" if CONFIG == "cfg5" else "cfg-2", W, H, N_KP, MAX_LEVEL + 1, HYP, S),
+            "config": {"workload": "%s: %dx%d KITTI-shaped synthetic stream, %d frames strictly forward (0.8 m/frame), per frame: "
+                                   "Harris+NMS %d kp (see detector), re-detect append, KLT %d-level 15x15 of all tracks, Matches "
+                                   "regroup, P3P-RANSAC %d hyps + device replay of the sequential rule, pose refinement, State "
+                                   "bookkeeping, per-track-pose candidate DLT, cheirality; %d independent sequence(s) per GPU; "
+                                   "detector executed on %.0f %% of the timed steps, re-detect on %.0f %%"
+                                   % ("cfg-5" if CONFIG == "cfg5" else "cfg-2", W, H, N_FRAMES, N_KP, MAX_LEVEL + 1, HYP, S,
+                                      100 * lstats["detector_executed_fraction_of_steps"], 100 * lstats["redetect_fraction_of_steps"]),
                        "step_contains": "all of the above, device-resident (Features/State/RANSAC never leave HBM); "
                                         "landmarks are the loop's own triangulations after a host two-view bootstrap",
-                       "frames_resident": N_FRAMES, "keypoints": N_KP, "hypotheses": HYP, "sequences_per_gpu": S,
+                       "frames_resident": N_FRAMES, "stream": "frames %d -> %d pass after pass; seam = drain + vo_pipeline_rewind "
+                                                                "to the bootstrap's state of frame %d, inside the timed region"
+                                                                % (PASS_START, N_FRAMES - 1, PASS_START),
+                       "passes_started_in_timed_region": walker.passes - passes0,
+                       "keypoints": N_KP, "hypotheses": HYP, "sequences_per_gpu": S,
                        "frame_lookahead": 1 if args.lookahead else 0, "redetect_start_pose": REDETECT_POSE,
                        "detector": ("Harris + NMS on every frame" if DETECT_MARGIN < 0 else
                                     "Harris + NMS launched every frame, executed for a sequence whose track count, extrapolated "
@@ -577,59 +666,52 @@ def main():
                                "time includes what it waits for the others)" + ("" if DETECT_MARGIN < 0 else
                                "; harris_response / nms_* average over launches most sequences sit out"),
             "chain_us": chain,
-            "loop": {"features_in_median": n_in, "tracked_median": n_trk, "landmarks_p3p_median": n_tri,
-                     "inliers_median": float(np.median([r.n_inliers for r in every])),
-                     "candidates_median": float(np.median([r.n_candidates for r in every])),
-                     "ransac_iters_median": float(np.median([r.ransac_iterations for r in every])),
-                     "redetect_fraction_of_steps": float(np.mean([r.redetected for r in every])),
-                     "detector_executed_fraction_of_steps": float(np.mean([r.detector_ran for r in every])),
-                     "steps_finished_by_host_path": int(sum(r.recovered for r in every)),
-                     "refine_steps_median": float(np.median([r.refine_iterations for r in every])),
-                     "bootstrap_landmarks": n_boot},
+            "loop": dict(lstats, bootstrap_landmarks=n_boot),
             "pose_err_vs_ground_truth": {"rot_fro_median": float(np.median([e[0] for e in gt_err])),
+                                         "rot_fro_max": float(np.max([e[0] for e in gt_err])),
                                          "trans_m_median": float(np.median([e[1] for e in gt_err])),
-                                         "trans_m_per_frame": [round(e[1], 3) for e in gt_err],
+                                         "trans_m_last": round(gt_err[-1][1], 3),
+                                         "trans_m_every_8th_frame": [round(e[1], 3) for e in gt_err[::8]],
+                                         "path_m": round((N_FRAMES - 1 - PASS_START) * synthetic.STEP_Z, 1),
                                          "frames": len(gt_err),
-                                         "note": "first frames of the run vs the analytic poses of the synthetic stream, "
-                                                 "monocular scale fixed once by the bootstrap baseline"},
+                                         "steps_finished_by_host_path": int(sum(rs[0].recovered for _, rs in first_pass)),
+                                         "note": "the whole first pass (frames %d..%d) vs the analytic poses of the synthetic stream, "
+                                                 "monocular scale fixed once by the bootstrap baseline" % (PASS_START + 1, N_FRAMES - 1)},
+            "setup_s": {"render_%d_frames_%d_workers" % (len(jobs), workers): round(render_s, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            parity, base = oracle_leg(stream, state, [rs[0] for _, rs in first], first_state, ORACLE_FRAMES)
+            parity, base = oracle_leg(stream, state, [rs[0] for _, rs in first_pass[:CPU_BASELINE_FRAMES]], first_state, ORACLE_FRAMES)
             out["pose_vs_oracle"] = parity
             out["cpu_baseline"] = base
         if world == 1 and not args.no_api:
             out["api"] = api_leg(ctx)
-        if world == 1 and DETECT_MARGIN >= 0 and not args.no_api:
-            # the same loop with the detector executed on EVERY frame (what rounds 1 and early 2 timed), in the same line
+        if legs:
             pipe.close()
-            pipe2 = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL,
-                                     hyp=HYP, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=1000,
-                                     refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, sequences=S, detect_margin=-1.0)
-            for q in range(S):
-                for i in range(N_FRAMES):
-                    pipe2.set_frame(i, streams[q].image(i), seq=q)
-                pipe2.set_state(2, states[q].curr_frame.features, states[q].curr_pose, states[q].prev_pose, num_features=N_KP,
-                                seq=q)
-            order2 = walk(2, N_FRAMES, 1400)
-
-            def run2(p0, n):
-                pipe2.submit(order2[p0], order2[p0 + 1])
-                for k in range(n):
-                    if k + 1 < n:
-                        pipe2.submit(order2[p0 + k + 1], order2[p0 + k + 2])
-                    pipe2.collect_all()
-
-            run2(0, 200)
-            ctx.sync()
-            t2 = time.perf_counter()
-            run2(200, 1000)
-            ctx.sync()
-            out["detector_every_frame"] = {"frames_per_s": round(S * 1000 / (time.perf_counter() - t2), 1), "steps": 1000,
-                                           "note": "same pipeline, same stream, detect_margin < 0: Harris + NMS executed on every "
-                                                   "frame of every sequence instead of within the margin of the re-detect limit"}
-            pipe2.close()
+            pipe = None
+            if DETECT_MARGIN >= 0:
+                # the same loop with the detector executed on EVERY frame (what rounds 1 and early 2 timed), in the same line
+                p2 = make_pipeline(ctx, streams, states, S, -1.0)
+                out["detector_every_frame"] = dict(timed_leg(ctx, p2, S, 100, 1000),
+                                                   note="same pipeline, same stream, detect_margin < 0: Harris + NMS executed on every "
+                                                        "frame of every sequence instead of within the margin of the re-detect limit")
+                p2.close()
+            if S != S_LEG:
+                # throughput configuration: 16 independent sequences (16 scenes) per GPU advancing through the same launches
+                t_b = time.perf_counter()
+                leg_states = [bootstrap_state(st) for st in leg_streams]
+                out["setup_s"]["bootstrap_%d_sequences" % S_LEG] = round(time.perf_counter() - t_b, 1)
+                p3 = make_pipeline(ctx, leg_streams, leg_states, S_LEG, DETECT_MARGIN)
+                out["sequences_16"] = dict(timed_leg(ctx, p3, S_LEG, 30, 2 * (N_FRAMES - 1 - PASS_START)),
+                                           note="16 scenes (seeds 3023..3038), each bootstrapped by itself, one pipeline: every launch "
+                                                "of the loop carries all 16 sequences; two passes over the stream timed, seams included")
+                p3.close()
+                if DETECT_MARGIN >= 0:
+                    p4 = make_pipeline(ctx, leg_streams, leg_states, S_LEG, -1.0)
+                    out["sequences_16_detector_every_frame"] = timed_leg(ctx, p4, S_LEG, 30, 2 * (N_FRAMES - 1 - PASS_START))
+                    p4.close()
         print(json.dumps(out), flush=True)
-    pipe.close()
+    if pipe is not None:
+        pipe.close()
     ctx.close()
     if exchange:
         dist.destroy_process_group()

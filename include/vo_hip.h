@@ -374,7 +374,10 @@ typedef struct vo_step_result {
 } vo_step_result;
 int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out);
 void vo_pipeline_destroy(vo_pipeline* p);
-/* frame store: copies a host image into slot idx of the frame store (synchronous)            */
+/* frame store: copies a host image into slot idx of the frame store.  The caller's buffer is free on return (it is
+ * copied into a pinned staging buffer of that slot); the transfer itself is queued in front of the pyramid that reads
+ * the slot and the call does not wait for it.  A slot that a step in flight reads is refused (VO_EINVAL), and so is the
+ * slot of the frame submitted last once a state exists: the next step tracks FROM that image.                       */
 int vo_pipeline_set_frame(vo_pipeline* p, int idx, const uint8_t* img);
 int vo_pipeline_seed(vo_pipeline* p, const vo_pcg64* rng);
 int vo_pipeline_get_rng(vo_pipeline* p, vo_pcg64* rng);      /* estimator generator state after the last collected step */
@@ -390,6 +393,13 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
                           const double* landmarks, const double* tracks, const double* poses,
                           const double* T_wc, const double* T_cw, const double* T_wc_prev,
                           const double* T_cw_prev, int num_features);
+/* A stream that is walked more than once (bench.py: 100 resident frames, pass after pass): _checkpoint keeps a copy of
+ * every sequence's Features / State as they are now -- nothing in flight -- in HBM; _rewind puts that copy back as the
+ * state of the frame it was taken at and queues that frame's pyramid and detection, all asynchronously on the pipeline's
+ * streams (nothing in flight; no host synchronisation).  What lives on the reference's estimator object across frames
+ * (RANSAC.n_iterations / outlier_ratio [ref: src/vo/algorithms/ransac.py:47-56], the generator) is NOT rewound.      */
+int vo_pipeline_checkpoint(vo_pipeline* p);
+int vo_pipeline_rewind(vo_pipeline* p);
 /* Downloads the current Features (arrays sized to the capacity vo_pipeline_feature_cap returns;
  * any pointer may be NULL); n_out: feature count.  Nothing may be in flight.                  */
 int vo_pipeline_feature_cap(vo_pipeline* p);

@@ -457,3 +457,62 @@ def test_pipeline_records_for_the_shared_map(ctx):
         np.testing.assert_array_equal(Tm[3], [0, 0, 0, 1])
         assert len(lm) == min(r.n_triangulated, cap)
         np.testing.assert_array_equal(lm, land[: len(lm)])       # (NaN where the cheirality check dropped one)
+
+
+def test_rewind_restarts_the_pass_and_the_estimator_goes_on(ctx):
+    """vo_pipeline_checkpoint / _rewind (the seam of bench.py's forward stream): after a rewind the loop starts again
+    from the checkpointed Features / State -- asynchronously, with look-ahead around it -- while the estimator's RANSAC
+    fields and generator go on, as on the reference's estimator object (ransac.py:47-56).  Oracle: the same loop with
+    its state set back and its RANSAC object kept."""
+    from vo import synthetic
+    H, W, N, F = 240, 320, 300, 6
+    stream = synthetic.Stream(F, H, W)
+    feats, T = start_state(stream, N, 0.83)
+    pipe = make_pipe(ctx, stream, N, 256, redetect_start_pose="current")
+    pipe.set_state(0, feats, T, T)
+    pipe.checkpoint()
+    orc = OracleLoop(stream, N, 15, 2, refine_iters=20, redetect_start_pose="current")
+    pairs = [(k, k + 1) for k in range(F - 1)]
+    for p in range(3):
+        orc.set_state(0, feats, T, T)
+        if p > 0:
+            pipe.rewind()
+        if p == 1:                       # look-ahead across the pass; the last step checked in full
+            refs = [orc.step(b) for _, b in pairs]
+            rs = run_all(pipe, pairs, True)
+            for r, ref in zip(rs, refs):
+                assert (r.n_tracked, r.n_triangulated, r.n_inliers, r.draws_consumed, r.ransac_iterations, r.n_candidates,
+                        r.n_landmarks) == (ref["n_tracked"], ref["n_tri"], ref["n_inliers"], ref["draws"], ref["iters"],
+                                           ref["n_cand"], ref["n_landmarks"])
+            check_step(rs[-1], refs[-1], pipe, orc.rs.rng)
+        else:
+            for a, b in pairs:
+                ref = orc.step(b)
+                check_step(pipe.step(a, b), ref, pipe, orc.rs.rng)
+    pipe.close()
+
+
+def test_few_landmarks_step_keeps_every_feature_through_the_host_path(ctx):
+    """4 <= triangulated tracks < 8: the device-side sampler does not apply and the step is finished by the host path
+    (recover_step).  The regroup that finds this runs in several workgroups; "few landmarks" must not stop any of them
+    from writing its features (it used to be raised in the word they all read on entry).  Every array against the
+    oracle after the step."""
+    from vo import synthetic
+    H, W, N, F = 480, 640, 1200, 3
+    stream = synthetic.Stream(F, H, W)
+    feats, T = initial_features(stream, 0, N)
+    n_tri = int((feats.state == 2).sum())
+    keep = np.ones(feats.length, dtype=bool)
+    keep[6:n_tri] = False                       # six landmarks, every matched track
+    feats = subsample(feats, keep)
+    assert feats.length > 256 and int((feats.state == 2).sum()) == 6
+    pipe = make_pipe(ctx, stream, N, 256, redetect_start_pose="current")
+    pipe.set_state(0, feats, T, T)
+    orc = OracleLoop(stream, N, 15, 2, refine_iters=20, redetect_start_pose="current")
+    orc.set_state(0, feats, T, T)
+    ref = orc.step(1)
+    r = pipe.step(0, 1)
+    assert r.recovered == 1 and (r.reserved & 1), "the step was meant to leave the device-only path with few landmarks"
+    assert r.n_features_in > 256
+    check_step(r, ref, pipe, orc.rs.rng)
+    pipe.close()

@@ -92,6 +92,11 @@ struct vo_pipeline {
   int last_fbuf = 0;
   hipEvent_t evA = nullptr, evB = nullptr;
   double* d_newkp = nullptr;         // scratch of the bookkeeping entry point
+  // vo_pipeline_checkpoint / _rewind: a copy of one Features buffer (all sequences) and of the control blocks
+  char* d_ckpt_feat = nullptr;
+  vo_seq_ctl* d_ckpt_ctl = nullptr;
+  size_t feat_block = 0;             // bytes of one Features buffer (F[0] and F[1] are consecutive blocks of feat_mem)
+  int ckpt_frame = -1;
   int32_t* d_pairs = nullptr;
   long n_recovered = 0;
   // Detection worker: a second host thread enqueues the detection of every step (6 launches) while the caller's
@@ -144,6 +149,19 @@ __global__ __launch_bounds__(64) void detect_decide_kernel(const vo_seq_ctl* __r
   const int n2 = ctl[q].n2;
   const int lost = max(ctl[q].n_in - (ctl[q].redetected ? n_det : 0) - n2, 0);
   go[q] = (force || limit < 0.0 || (limit > 0.0 && (double)(n2 - 4 * lost) < (double)ctl[q].num_features * limit)) ? 1 : 0;
+}
+
+// vo_pipeline_rewind: the control block as it was at the checkpoint, except what lives on the reference's estimator
+// object (RANSAC.n_iterations / outlier_ratio, ransac.py:47-56) and the generator position, which go on
+__global__ __launch_bounds__(64) void ctl_rewind_kernel(vo_seq_ctl* __restrict__ ctl, const vo_seq_ctl* __restrict__ saved, int S) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= S) return;
+  vo_seq_ctl c = saved[q];
+  c.n_iterations = ctl[q].n_iterations;
+  c.outlier_ratio = ctl[q].outlier_ratio;
+  c.raw_pos = ctl[q].raw_pos;
+  c.step = ctl[q].step;
+  ctl[q] = c;
 }
 
 template <typename T>
@@ -249,7 +267,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (q) (void)hipStreamSynchronize(q->stream);
   void* dev[] = {p->d_det_go, p->d_img, p->d_pyr, p->d_kp, p->d_scores[0], p->d_scores[1], p->feat_mem, p->d_ctl, p->d_next, p->d_err,
                  p->d_status, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_samples, p->d_masks, p->d_best_mask, p->d_table,
-                 p->d_raws, p->d_newkp, p->d_pairs};
+                 p->d_raws, p->d_newkp, p->d_pairs, p->d_ckpt_feat, p->d_ckpt_ctl};
   for (void* q : dev)
     if (q) (void)hipFree(q);
   void* pin[] = {p->h_stage, p->h_res, (void*)p->h_seq};
@@ -339,6 +357,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     char* mem = nullptr;
     PA(dev_alloc(ctx, &mem, 2 * fb));
     p->feat_mem = mem;
+    p->feat_block = fb;
     if (mem) {
       char* q = mem;
       p->F[0] = carve(q, cap, S);
@@ -438,6 +457,9 @@ int vo_pipeline_set_frame_seq(vo_pipeline* p, int seq, int idx, const uint8_t* i
   for (int k = 0; k < p->n_flight; ++k)
     VO_REQUIRE(ctx, p->flight[k].prev_idx != idx && p->flight[k].next_idx != idx,
                "pipeline_set_frame: slot %d belongs to a step in flight", idx);
+  // the frame submitted last is what the next step tracks FROM (and what a skipped detection is made up from)
+  VO_REQUIRE(ctx, !(p->have_state && p->primed && idx == p->prev_frame),
+             "pipeline_set_frame: slot %d holds the frame the next step starts from", idx);
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   // Through a pinned staging buffer of this (sequence, slot), as one DMA queued on the tracker's stream -- in front of
   // the pyramid that reads the slot; the detector's stream waits for evImg.  The call does not wait for the GPU (the
@@ -768,16 +790,58 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
 }
 
 // pyramid and detection of the frame the handed-over states belong to, all sequences, synchronously
-static int prime(vo_pipeline* p) {
+static int prime(vo_pipeline* p, bool wait = true) {
   vo_ctx* ctx = p->ctx;
   VO_TRY(worker_idle(p));
   sync_prof(p);
   VO_TRY(enqueue_pyramid(p, p->prev_frame, p->slot));
   VO_TRY(enqueue_detection(p, p->prev_frame, p->slot, true));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(p->trk->stream));
-  VO_HIP_TRY(ctx, hipStreamSynchronize(p->det->stream));
+  if (wait) {        // (not needed for order: the tracker sits behind the pyramid on its stream and waits for evDet)
+    VO_HIP_TRY(ctx, hipStreamSynchronize(p->trk->stream));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(p->det->stream));
+  }
   p->primed = true;
   return VO_OK;
+}
+
+extern "C" int vo_pipeline_checkpoint(vo_pipeline* p) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, p->have_state, "pipeline_checkpoint: no state was handed over");
+  VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_checkpoint: %d submitted step(s) not collected", p->n_flight);
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!p->d_ckpt_feat) {
+    VO_TRY(dev_alloc(ctx, &p->d_ckpt_feat, p->feat_block));
+    VO_TRY(dev_alloc(ctx, &p->d_ckpt_ctl, (size_t)p->S));
+  }
+  hipStream_t st = ctx->stream;
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_feat, (char*)p->feat_mem + (size_t)p->cur * p->feat_block, p->feat_block,
+                                 hipMemcpyDeviceToDevice, st));
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_ctl, p->d_ctl, (size_t)p->S * sizeof(vo_seq_ctl), hipMemcpyDeviceToDevice, st));
+  VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  p->ckpt_frame = p->prev_frame;
+  return VO_OK;
+}
+
+extern "C" int vo_pipeline_rewind(vo_pipeline* p) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, p->ckpt_frame >= 0, "pipeline_rewind: no checkpoint");
+  VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_rewind: %d submitted step(s) not collected", p->n_flight);
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  VO_TRY(worker_idle(p));
+  hipStream_t st = ctx->stream;
+  // every step has been collected: its chain -- tracker included -- is done, nothing reads the Features any more
+  VO_HIP_TRY(ctx, hipMemcpyAsync((char*)p->feat_mem + (size_t)p->cur * p->feat_block, p->d_ckpt_feat, p->feat_block,
+                                 hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(ctl_rewind_kernel, dim3(vo_cdiv(p->S, 64)), dim3(64), 0, st, p->d_ctl, p->d_ckpt_ctl, p->S);
+  VO_TRY(vo_check_launch(ctx, "ctl_rewind_kernel"));
+  // the next step's tracker waits for "the previous step's regroup": that event now stands for the restored state
+  if (p->steps_submitted > 0) VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[(p->steps_submitted - 1) & 1], st));
+  else VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+  p->slot = 0;
+  p->prev_frame = p->ckpt_frame;
+  return prime(p, false);            // pyramid + detector of that frame, queued on their streams
 }
 
 int vo_pipeline_get_state_seq(vo_pipeline* p, int seq, int32_t* n_out, double* kp, uint8_t* state,
@@ -997,7 +1061,8 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   if (h.fault & VO_FAULT_NO_DETECTION) return vo_set_error(ctx, VO_EHIP, "pipeline: the detector's keypoints are missing");
   const int n = h.n_tri;
   if (n < 4) return vo_set_error(ctx, VO_ETRACKING, "pipeline: only %d triangulated tracks survive, no pose", n);
-  if (h.fault) VO_HIP_TRY(ctx, mcpy(st, &ctl->fault, &zero, 4, hipMemcpyHostToDevice));   // (few landmarks)
+  // (fewer than 8 landmarks is no fault here: the regroup leaves it in ctl->few, and the sequential sampler below draws from
+  //  any population of 4 or more)
   const vo_feat B = vo_feat_seq(p->F[1 - f.fcur], (size_t)q);
   double* dR = p->d_R + (size_t)q * c.hyp * 9;
   double* dt = p->d_t + (size_t)q * c.hyp * 3;
@@ -1054,6 +1119,7 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   p->raw_gen[q] = p->rng[q];
   p->pos_known[q] = p->gen_upto[q];
   h.fault = 0;
+  h.few = 0;
   h.n_p3p = n;
   h.n_iterations = rs.n_iterations;
   h.outlier_ratio = rs.outlier_ratio;

@@ -406,12 +406,19 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   }
   vo_seq_ctl* ctl = job.ctl;
   if (threadIdx.x == 0) ctl->ts[3] = wall_clock64();
-  if (ctl->fault) {
-    if (job.tail && job.res && threadIdx.x == 0) {
-      ctl->ts[4] = wall_clock64();
-      write_fault_record(ctl, ctl->fault, job.res, job.seq_word, job.seq);
+  {
+    // a fault of an earlier step (sticky) or of this step's regroup, which leaves "few landmarks" in its own word
+    const int entry_fault = ctl->fault | (job.do_replay ? ctl->few : 0);
+    if (entry_fault) {
+      if (threadIdx.x == 0) {
+        ctl->fault = entry_fault;
+        if (job.tail && job.res) {
+          ctl->ts[4] = wall_clock64();
+          write_fault_record(ctl, entry_fault, job.res, job.seq_word, job.seq);
+        }
+      }
+      return;
     }
-    return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const double* X = job.B.land;

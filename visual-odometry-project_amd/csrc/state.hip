@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
   if (fault) {
     if (blockIdx.x == 0 && tid == 0) {
       ctl->fault = fault;
+      ctl->few = 0;
       ctl->n_in = 0;
       ctl->n_p3p = 0;
       ctl->redetected = 0;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
     ctl->n_new = T2;
     const int few = T0 < 8 ? VO_FAULT_FEW_LANDMARKS : 0;   // (population below what the device-side sampler handles)
     ctl->n_p3p = few ? 0 : T0;
-    if (few) ctl->fault = few;
+    ctl->few = few;                    // (not into ctl->fault: this launch's other workgroups read that word on entry)
   }
 }
 

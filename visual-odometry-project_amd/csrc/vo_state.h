@@ -58,6 +58,10 @@ struct vo_seq_ctl {
   int32_t fault;           // sticky: every later kernel of this and the following steps leaves the state alone
   int32_t step;            // steps completed
   int32_t solve_flag;      // raised by the solve kernel (population < 8)
+  int32_t few;             // VO_FAULT_FEW_LANDMARKS found by THIS step's regroup; the pose kernel ORs it into `fault`.  (Not
+                           // written to `fault` by the regroup itself: its other workgroups read that word on entry, and one
+                           // dispatched after block 0 had retired would skip its features.)
+  int32_t pad0;
   // ---- RANSAC: persists across frames like the reference's estimator object ----
   int64_t n_iterations;
   double outlier_ratio;

@@ -138,6 +138,8 @@ _SIGS = {
     "vo_ransac_num_iterations": (C.c_int64, [_d, _d, _i]),
     "vo_ransac_replay": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "vo_pipeline_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "vo_pipeline_checkpoint": (_i, [_vp]),
+    "vo_pipeline_rewind": (_i, [_vp]),
     "vo_pipeline_destroy": (None, [_vp]),
     "vo_pipeline_set_frame": (_i, [_vp, _i, _vp]),
     "vo_pipeline_seed": (_i, [_vp, _vp]),

@@ -112,6 +112,15 @@ class Pipeline:
                                                               _ptr(land), _ptr(tracks), _ptr(poses), _ptr(T_wc),
                                                               _ptr(T_cw), _ptr(T_wc_prev), _ptr(T_cw_prev), nf))
 
+    def checkpoint(self):
+        """Keeps a copy of every sequence's Features / State as they are now (nothing in flight) in HBM."""
+        self.ctx._chk(self.ctx._lib.vo_pipeline_checkpoint(self._h))
+
+    def rewind(self):
+        """Puts the checkpoint back (asynchronously, nothing in flight): the next submit starts from its frame again.
+        The estimator's RANSAC fields and generator go on, as they would on the reference's estimator object."""
+        self.ctx._chk(self.ctx._lib.vo_pipeline_rewind(self._h))
+
     # ---- outputs ----
     def get_state(self, seq=0):
         """dict with the reference's Features arrays of the current frame (shapes as in

@@ -40,64 +40,105 @@ def _hash_u8(i, j, surf, seed):
     return (h & np.uint64(0xFF)).astype(np.float32)
 
 
-def render(k, H, W, seed=2023, noise_sigma=2.0):
-    """Frame k: (image uint8 (H, W), depth float32 (H, W), T_world_cam (4, 4), K (3, 3))."""
+def render(k, H, W, seed=2023, noise_sigma=2.0, want_depth=True, rows=32):
+    """Frame k: (image uint8 (H, W), depth float32 (H, W) or None, T_world_cam (4, 4), K (3, 3)).
+    Evaluated in blocks of `rows` image rows (cache-sized; every pixel's arithmetic and the order of the
+    generator's draws are those of the whole-image evaluation, so the frames do not depend on `rows`)."""
     K = intrinsics(H, W)
     T = pose_world_cam(k)
     R, C = T[:3, :3], T[:3, 3]
     u = (np.arange(W, dtype=np.float64) - K[0, 2]) / K[0, 0]
     v = (np.arange(H, dtype=np.float64) - K[1, 2]) / K[1, 1]
-    dx_c, dy_c = np.meshgrid(u, v)
-    dz_c = np.ones_like(dx_c)
-    # ray directions in the world (camera z component is 1, so the ray parameter is the depth)
-    dx = R[0, 0] * dx_c + R[0, 1] * dy_c + R[0, 2] * dz_c
-    dy = R[1, 0] * dx_c + R[1, 1] * dy_c + R[1, 2] * dz_c
-    dz = R[2, 0] * dx_c + R[2, 1] * dy_c + R[2, 2] * dz_c
-    big = np.float64(1e30)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        t_planes = [
-            np.where(dy > 0, (GROUND_Y - C[1]) / dy, big),
-            np.where(dy < 0, (CEIL_Y - C[1]) / dy, big),
-            np.where(dx > 0, (WALL_X - C[0]) / dx, big),
-            np.where(dx < 0, (-WALL_X - C[0]) / dx, big),
-            np.where(dz > 0, (END_Z - C[2]) / dz, big),
-        ]
-    t = np.stack(t_planes)
-    surf = np.argmin(t, axis=0)
-    depth = np.min(t, axis=0)
-    px, py, pz = C[0] + depth * dx, C[1] + depth * dy, C[2] + depth * dz
-    # surface coordinates (a, b) per plane
-    a = np.select([surf <= 1, surf <= 3], [px, py], default=px)
-    b = np.select([surf <= 1, surf <= 3], [pz, pz], default=py)
-    # level of detail: cell size doubles every time the depth doubles past 20 m
-    lod = np.floor(np.log2(np.maximum(depth / 20.0, 1.0))).astype(np.int64)
-    cell = 0.25 * np.exp2(lod.astype(np.float64))
-    ci = np.floor(a / cell).astype(np.int64)
-    cj = np.floor(b / cell).astype(np.int64)
-    tex = _hash_u8(ci, cj, surf * 16 + lod, seed)
     rng = np.random.default_rng(1000 + k + 7919 * (seed - 2023))
-    img = tex + rng.normal(0.0, noise_sigma, size=tex.shape).astype(np.float32)
-    img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
-    return img, depth.astype(np.float32), T, K
+    img = np.empty((H, W), np.uint8)
+    depth_out = np.empty((H, W), np.float32) if want_depth else None
+    big = np.float64(1e30)
+    for r0 in range(0, H, rows):
+        r1 = min(H, r0 + rows)
+        dx_c = np.broadcast_to(u, (r1 - r0, W))
+        dy_c = np.broadcast_to(v[r0:r1, None], (r1 - r0, W))
+        # ray directions in the world (camera z component is 1, so the ray parameter is the depth)
+        dx = R[0, 0] * dx_c + R[0, 1] * dy_c + R[0, 2] * 1.0
+        dy = R[1, 0] * dx_c + R[1, 1] * dy_c + R[1, 2] * 1.0
+        dz = R[2, 0] * dx_c + R[2, 1] * dy_c + R[2, 2] * 1.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            planes = (
+                np.where(dy > 0, (GROUND_Y - C[1]) / dy, big),
+                np.where(dy < 0, (CEIL_Y - C[1]) / dy, big),
+                np.where(dx > 0, (WALL_X - C[0]) / dx, big),
+                np.where(dx < 0, (-WALL_X - C[0]) / dx, big),
+                np.where(dz > 0, (END_Z - C[2]) / dz, big),
+            )
+        # nearest plane, the first one on ties (argmin over the planes)
+        depth = planes[0].copy()
+        surf = np.zeros(depth.shape, np.int64)
+        for i in range(1, 5):
+            m = planes[i] < depth
+            depth[m] = planes[i][m]
+            surf[m] = i
+        px, py, pz = C[0] + depth * dx, C[1] + depth * dy, C[2] + depth * dz
+        # surface coordinates (a, b) per plane
+        a = np.where(surf <= 1, px, np.where(surf <= 3, py, px))
+        b = np.where(surf <= 3, pz, py)
+        # level of detail: cell size doubles every time the depth doubles past 20 m
+        lod = np.floor(np.log2(np.maximum(depth / 20.0, 1.0))).astype(np.int64)
+        cell = 0.25 * np.exp2(lod.astype(np.float64))
+        ci = np.floor(a / cell).astype(np.int64)
+        cj = np.floor(b / cell).astype(np.int64)
+        tex = _hash_u8(ci, cj, surf * 16 + lod, seed)
+        im = tex + rng.normal(0.0, noise_sigma, size=tex.shape).astype(np.float32)
+        img[r0:r1] = np.clip(np.rint(im), 0, 255).astype(np.uint8)
+        if want_depth:
+            depth_out[r0:r1] = depth.astype(np.float32)
+    return img, depth_out, T, K
+
+
+def _render_image(args):
+    k, H, W, seed = args
+    return render(k, H, W, seed, want_depth=False)[0]
+
+
+def render_images(jobs, workers=0):
+    """Images of many frames, jobs = [(k, H, W, seed), ...], rendered by `workers` processes (spawned: safe to call
+    from a process that holds a GPU context; 0 = in this process)."""
+    if workers <= 1 or len(jobs) < 4:
+        return [_render_image(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+        return pool.map(_render_image, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
 
 
 class Stream:
-    """n frames rendered up front; ``order(steps)`` walks them back and forth so that
-    consecutive frames are always neighbours (any number of steps from n frames)."""
+    """n frames of one scene (`seed`), forward from frame `start`.  Frames are rendered when first asked for
+    (`prefetch` renders many at once, in worker processes); depth maps only on request."""
 
     def __init__(self, n_frames, H, W, seed=2023, start=0):
-        self.H, self.W, self.n = H, W, n_frames
-        self.frames = [render(start + k, H, W, seed) for k in range(n_frames)]
-        self.K = self.frames[0][3]
+        self.H, self.W, self.n, self.seed, self.start = H, W, n_frames, seed, start
+        self.K = intrinsics(H, W)
+        self._img, self._depth = {}, {}
+
+    def prefetch(self, frames=None, workers=0):
+        todo = [i for i in (range(self.n) if frames is None else frames) if i not in self._img]
+        for i, im in zip(todo, render_images([(self.start + i, self.H, self.W, self.seed) for i in todo], workers)):
+            self._img[i] = im
+        return self
 
     def image(self, i):
-        return self.frames[i][0]
+        if i not in self._img:
+            if not 0 <= i < self.n:
+                raise IndexError(i)
+            self._img[i] = _render_image((self.start + i, self.H, self.W, self.seed))
+        return self._img[i]
 
     def depth(self, i):
-        return self.frames[i][1]
+        if i not in self._depth:
+            if not 0 <= i < self.n:
+                raise IndexError(i)
+            self._depth[i] = render(self.start + i, self.H, self.W, self.seed)[1]
+        return self._depth[i]
 
     def T_world_cam(self, i):
-        return self.frames[i][2]
+        return pose_world_cam(self.start + i)
 
     def order(self, steps):
         idx, d, out = 0, 1, [0]
