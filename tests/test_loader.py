@@ -9,22 +9,7 @@ import pytest
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def make_kitti_dir(root):
-    from PIL import Image
-    g = np.load(os.path.join(G, "kitti_harris.npz"))
-    d = os.path.join(root, "kitti", "05", "image_0")
-    os.makedirs(d)
-    os.makedirs(os.path.join(root, "kitti", "poses"))
-    for k in (0, 1):
-        Image.fromarray(g["image%d" % k]).save(os.path.join(d, "%06d.png" % k))
-    P0 = g["calib_P0"]
-    P1 = P0.copy()
-    P1[0, 3] = -379.8145                                   # (the right camera's row differs in its 4th column only)
-    with open(os.path.join(root, "kitti", "05", "calib.txt"), "w") as f:
-        for name, P in (("P0", P0), ("P1", P1), ("P2", P0), ("P3", P0)):
-            f.write(name + ": " + " ".join("%.12e" % v for v in P.reshape(-1)) + "\n")
-    np.savetxt(os.path.join(root, "kitti", "poses", "05.txt"), g["poses05_head"].reshape(-1, 12), fmt="%.6e")
-    return g
+from kitti_fixture import make_kitti_dir  # noqa: E402
 
 
 def test_kitti_sequence_reads_the_reference_layout(tmp_path):
@@ -47,6 +32,20 @@ def test_kitti_sequence_reads_the_reference_layout(tmp_path):
     with pytest.raises(StopIteration):
         next(seq)
     assert len(list(Sequence("kitti", path=str(tmp_path), increment=2))) == 1
+
+
+def test_kitti_sequence_all_six_frames(tmp_path):
+    from vo.primitives import Sequence
+    g = make_kitti_dir(str(tmp_path), frames=range(6))
+    seq = Sequence("kitti", path=str(tmp_path))
+    assert len(seq) == 6
+    frames = list(seq)
+    assert [f.frame_id for f in frames] == list(range(6))
+    for k, f in enumerate(frames):
+        assert np.array_equal(f.image[:, :, 1], g["image%d" % k])
+    # the car drives forward ~0.56 m per frame (poses/05.txt)
+    z = [seq.ground_truth_pose(k)[2, 3] for k in range(6)]
+    assert np.all(np.diff(z) > 0.5) and np.all(np.diff(z) < 0.6)
 
 
 def test_parking_and_invalid_datasets(tmp_path):

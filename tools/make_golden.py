@@ -367,6 +367,22 @@ def golden_harris_kitti():
     print("harris_kitti:", out["image0"].shape, "kp0[0..3]=", out["keypoints0"][:3, :, 0].tolist())
 
 
+def golden_kitti_frames():
+    """Frames 2..5 of the reference's KITTI test data (tests/test_data/kitti/05/image_0; frames 0 and 1 are in
+    kitti_harris.npz with the calibration row and the first six ground-truth poses): with them the headless driver runs
+    bootstrap (frames 0, 2) + three steady-state frames on real images against poses/05.txt.  Data files
+    of the reference's tests, read with PIL and stored as arrays; no reference code is involved."""
+    from PIL import Image
+    d = "/root/reference/tests/test_data/kitti/05/image_0"
+    out = {}
+    for k in (2, 3, 4, 5):
+        img = np.array(Image.open(os.path.join(d, "%06d.png" % k)))
+        assert img.dtype == np.uint8 and img.shape == (370, 1226)
+        out["image%d" % k] = img
+    np.savez_compressed(os.path.join(OUT, "kitti_frames.npz"), **out)
+    print("kitti_frames:", sorted(out))
+
+
 def golden_dlt_candidates():
     """triangulate_candidates (triangulation.py:38-86) with 2000 tracks, each with its own start pose
     (proj1[i] = K inv(pose_start_i)[:3]) -- the shape the per-frame loop calls it at (main.py:279-283)."""
@@ -418,6 +434,7 @@ if __name__ == "__main__":
     _import_reference()
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["harris", "dlt", "ransac", "bookkeeping", "bootstrap", "helpers", "harris_full",
-                             "harris_kitti", "dlt_candidates"]
+                             "harris_kitti", "dlt_candidates", "kitti_frames"]
     for w in which:
         globals()["golden_" + w]()
+    # (python tools/make_golden.py kitti_frames: data files only)
