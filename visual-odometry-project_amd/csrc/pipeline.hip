@@ -74,7 +74,8 @@ struct vo_pipeline {
   uint32_t ring_len = 0;
   uint32_t* h_stage = nullptr;
   size_t stage_cap = 0;
-  std::vector<uint64_t> gen_upto, pos_known;
+  std::vector<uint64_t> gen_upto, pos_known, pos_dev;   // generated up to / the estimator's position after the last closed
+                                                        // step / the device's position (ahead of it while a step continues)
   std::vector<vo_pcg64> raw_gen, rng;
   hipEvent_t evRaw = nullptr;
   bool raw_pending = false, seeded = false, have_state = false, primed = false;
@@ -98,7 +99,8 @@ struct vo_pipeline {
   size_t feat_block = 0;             // bytes of one Features buffer (F[0] and F[1] are consecutive blocks of feat_mem)
   int ckpt_frame = -1;
   int32_t* d_pairs = nullptr;
-  long n_recovered = 0;
+  long n_recovered = 0, n_continued = 0;
+  bool pose_fault_hook = true;       // debug_fault_every < 0 applies to submitted steps, not to what recover_step re-enqueues
   // Detection worker: a second host thread enqueues the detection of every step (6 launches) while the caller's
   // thread enqueues pyramid, tracker and the main-stream chain (6 launches): a dozen launches and half a dozen event
   // calls per step cost one thread 70-150 us on a loaded host, more than the GPU needs for the step.
@@ -162,6 +164,13 @@ __global__ __launch_bounds__(64) void ctl_rewind_kernel(vo_seq_ctl* __restrict__
   c.raw_pos = ctl[q].raw_pos;
   c.step = ctl[q].step;
   ctl[q] = c;
+}
+
+// a step whose RANSAC loop wants another batch of hypotheses (VO_FAULT_CONTINUE) goes on: the fault word is cleared and the
+// population is what the step's regroup counted (a later step's regroup, enqueued behind the open step, has zeroed n_p3p)
+__global__ void ctl_resume_kernel(vo_seq_ctl* __restrict__ ctl) {
+  ctl->fault = 0;
+  ctl->n_p3p = ctl->n_tri;
 }
 
 template <typename T>
@@ -284,10 +293,10 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (q) vo_destroy(q);
   if (getenv("VO_DEBUG_TIMING") && p->dbg_steps > 0)
     fprintf(stderr, "[vo_pipeline] %ld steps x %d sequence(s): host %.1f us enqueueing (worker wait %.1f, tracker %.1f, raws %.1f, "
-            "chain %.1f), %.1f us waiting per step; %ld finished through the host path\n",
+            "chain %.1f), %.1f us waiting per step; %ld finished through the host path, %ld further batches of hypotheses\n",
             p->dbg_steps, p->S, 1e6 * p->dbg_submit / p->dbg_steps, 1e6 * p->dbg_part[0] / p->dbg_steps,
             1e6 * p->dbg_part[1] / p->dbg_steps, 1e6 * p->dbg_part[2] / p->dbg_steps, 1e6 * p->dbg_part[3] / p->dbg_steps,
-            1e6 * p->dbg_wait / p->dbg_steps, p->n_recovered);
+            1e6 * p->dbg_wait / p->dbg_steps, p->n_recovered, p->n_continued);
   delete p;
 }
 
@@ -379,7 +388,13 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_pairs, (size_t)cap * 2));
   // n_iterations as a step function of the outlier ratio (state_device.h, table_lookup): a batch of `hyp`
   // samples cannot finish a rule that needs more than `hyp` iterations, so hyp + 1 thresholds suffice
-  p->table_len = Hyp + 1;
+  // -- unless the loop continues over several launches (VO_FAULT_CONTINUE): then the table holds the whole budget
+  //    (every bound up to max_iterations; an unbounded budget: up to 65536, beyond that the host's loop takes over)
+  {
+    const int64_t mi = cfg->ransac_max_iterations;
+    const int64_t want = mi >= 0 ? std::min<int64_t>(mi, 65536) : 65536;
+    p->table_len = (int)std::max<int64_t>(Hyp + 1, want + 1);
+  }
   p->table.assign((size_t)p->table_len + 1, 0.0);
   vo_ransac_build_table(cfg->ransac_confidence, 4, p->table_len, p->table.data());
   PA(dev_alloc(ctx, &p->d_table, p->table.size()));
@@ -423,6 +438,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   }
   p->gen_upto.assign(Sz, 0);
   p->pos_known.assign(Sz, 0);
+  p->pos_dev.assign(Sz, 0);
   p->raw_gen.resize(Sz);
   p->rng.resize(Sz);
   p->slot_seq.assign(4 * Sz, 0u);
@@ -545,8 +561,9 @@ static int enqueue_pyramid(vo_pipeline* p, int frame, int s) {
 static int ensure_raws(vo_pipeline* p, int q) {
   vo_ctx* ctx = p->ctx;
   const uint64_t need = (uint64_t)7 * p->cfg.hyp;
-  if (p->gen_upto[q] >= p->pos_known[q] + 4 * need) return VO_OK;
-  const uint64_t target = p->pos_known[q] + 16 * need;
+  const uint64_t pos = std::max(p->pos_known[q], p->pos_dev[q]);
+  if (p->gen_upto[q] >= pos + 4 * need) return VO_OK;
+  const uint64_t target = pos + 16 * need;
   const size_t m = (size_t)(target - p->gen_upto[q]);        // <= stage_cap
   if (p->raw_pending) {
     VO_HIP_TRY(ctx, hipEventSynchronize(p->evRaw));          // the staging buffer's last copy (long done)
@@ -592,6 +609,7 @@ static vo_pose_job make_pose_job(vo_pipeline* p, const vo_feat& B, int do_replay
   j.seq = 0u;
   static const int stamps = getenv("VO_POSE_STAMPS") ? 1 : 0;
   j.stamps = stamps;
+  j.debug_fault_every = 0;
   return j;
 }
 
@@ -634,6 +652,8 @@ static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool 
   return VO_OK;
 }
 
+static int enqueue_pose_half(vo_pipeline* p, const vo_pipeline::flight_t& f, int q0, int Sn, unsigned seq);
+
 // the main-stream chain of one step (the tracker's event must have been recorded);
 // first_half_only: stop behind the regroup (recover_step continues on the host)
 static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool first_half_only, int debug_fault_every,
@@ -650,12 +670,24 @@ static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fi
   ap.n_det = c.n_keypoints;
   ap.frac = c.redetect_fraction;
   ap.pose_mode = c.redetect_start_pose;
-  ap.debug_fault_every = debug_fault_every;
+  ap.debug_fault_every = debug_fault_every > 0 ? debug_fault_every : 0;
   ap.det_go = p->d_det_go + (size_t)f.a * p->S + q0;
   VO_TRY(vo_state_regroup_klt(ctx, ctl, A, B, p->d_next + q * p->cap * 2, p->d_status + q * p->cap, p->d_err + q * p->cap,
                               (float)c.klt_err_threshold, ap, p->cap, Sn));
   VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], ctx->stream));
   if (first_half_only) return VO_OK;
+  return enqueue_pose_half(p, f, q0, Sn, seq);
+}
+
+// hypotheses + pose kernel of one step (the second half of its main-stream chain; also the next batch of a step whose
+// RANSAC loop continues)
+static int enqueue_pose_half(vo_pipeline* p, const vo_pipeline::flight_t& f, int q0, int Sn, unsigned seq) {
+  vo_ctx* ctx = p->ctx;
+  const int debug_pose_fault = p->pose_fault_hook && p->cfg.debug_fault_every < 0 ? -p->cfg.debug_fault_every : 0;
+  const vo_pipeline_config& c = p->cfg;
+  const size_t q = (size_t)q0;
+  const vo_feat B = vo_feat_seq(p->F[1 - f.fcur], q);
+  vo_seq_ctl* ctl = p->d_ctl + q0;
   vo_hyp_batch hb;
   hb.S = Sn;
   hb.X = (size_t)p->cap * 3;
@@ -672,6 +704,7 @@ static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fi
   job.res = p->m_res + (size_t)f.rslot * p->S + q;
   job.seq_word = p->m_seq + (size_t)f.rslot * p->S + q;
   job.seq = seq;
+  job.debug_fault_every = debug_pose_fault;
   VO_TRY(vo_frame_pose(ctx, job, Sn));
   return VO_OK;
 }
@@ -1071,10 +1104,12 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   uint64_t* dmasks = p->d_masks + (size_t)q * c.hyp * p->words;
   uint64_t* dbest = p->d_best_mask + (size_t)q * p->words;
   vo_ransac_state rs;
-  rs.outlier_ratio = h.outlier_ratio;
+  // (a step that had walked some batches on the device before it met this fault is redone from its start: the fields
+  //  the estimator object held then, and the host's generator, which follows closed steps only)
+  rs.outlier_ratio = h.cont > 0 ? h.outlier_ratio0 : h.outlier_ratio;
   rs.confidence = c.ransac_confidence;
   rs.max_iterations = c.ransac_max_iterations;
-  rs.n_iterations = h.n_iterations;
+  rs.n_iterations = h.cont > 0 ? h.n_iterations0 : h.n_iterations;
   rs.s = 4;
   rs.adaptive = 1;
   vo_pcg64 g = p->rng[q];
@@ -1118,8 +1153,10 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   }
   p->raw_gen[q] = p->rng[q];
   p->pos_known[q] = p->gen_upto[q];
+  p->pos_dev[q] = p->gen_upto[q];
   h.fault = 0;
   h.few = 0;
+  h.cont = 0;
   h.n_p3p = n;
   h.n_iterations = rs.n_iterations;
   h.outlier_ratio = rs.outlier_ratio;
@@ -1149,6 +1186,29 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   return VO_OK;
 }
 
+// Sequence q's step of flight f is open: its RANSAC loop has walked the launch's `hyp` samples and wants more
+// (VO_FAULT_CONTINUE; the loop's state is in the control block, the generator position moved on).  The next batch --
+// hypotheses + pose kernel for that sequence alone -- is launched until the record is a closed step's or a real fault's.
+// Nothing is recomputed and nothing comes back but the records: the loop stays on the device (ransac.py:90-121 with
+// max_iterations beyond one launch, as src/main.py:194-201 configures it).
+static int continue_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, vo_step_result* out) {
+  vo_ctx* ctx = p->ctx;
+  for (long round = 0; out->fault == VO_FAULT_CONTINUE; ++round) {
+    if (round >= (1 << 16))
+      return vo_set_error(ctx, VO_ETRACKING, "pipeline: the RANSAC rule is not done after %ld batches of %d samples", round, p->cfg.hyp);
+    p->pos_dev[q] = out->raw_pos;
+    VO_TRY(ensure_raws(p, q));
+    const unsigned seq = ++p->seq;
+    p->slot_seq[(size_t)f.rslot * p->S + q] = seq;
+    hipLaunchKernelGGL(ctl_resume_kernel, dim3(1), dim3(1), 0, ctx->stream, p->d_ctl + q);
+    VO_TRY(vo_check_launch(ctx, "ctl_resume_kernel"));
+    VO_TRY(enqueue_pose_half(p, f, q, 1, seq));
+    VO_TRY(wait_record(p, f.rslot, q, seq, out->raw_pos, out));
+    ++p->n_continued;
+  }
+  return VO_OK;
+}
+
 extern "C" {
 
 int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
@@ -1165,8 +1225,14 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
   }
   for (int q = 0; q < p->S; ++q) {
     vo_step_result* out = &outs[q];
-    if (out->fault) {
-      int rc = recover_step(p, f, q, out);
+    const bool was_open = out->fault == VO_FAULT_CONTINUE;
+    int rc = was_open ? continue_step(p, f, q, out) : VO_OK;
+    if (rc != VO_OK) {
+      p->n_flight = 0;
+      return rc;
+    }
+    if (out->fault || was_open) {
+      rc = out->fault ? recover_step(p, f, q, out) : VO_OK;
       // steps submitted behind it saw the fault and did nothing for this sequence: their main-stream chains are
       // enqueued again for it alone (pyramids and detections are done and still in place)
       for (int k = 1; rc == VO_OK && k < p->n_flight; ++k) {
@@ -1181,7 +1247,8 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
         p->n_flight = 0;
         return rc;
       }
-    } else {
+    }
+    if (!out->recovered) {
       // the estimator's generator follows the device: 7 outputs per consumed sample
       const uint64_t delta = out->raw_pos - p->pos_known[q];
       if (delta > 0) {
@@ -1189,6 +1256,7 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
         vo_rng_raw32(&p->rng[q], (int)delta, tmp.data());
       }
       p->pos_known[q] = out->raw_pos;
+      p->pos_dev[q] = out->raw_pos;
     }
   }
   p->flight[0] = p->flight[1];

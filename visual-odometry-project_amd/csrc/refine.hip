@@ -435,7 +435,7 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   for (int k = 0; k < RF_PT; ++k) cache[k] = load_point(X, x, cap, nullptr, nullptr, k * RF_T + tid);
   if (tid == 0) s_state = 0;
   __syncthreads();
-  if (job.do_replay && wv == 0) replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table, first, true);
+  if (job.do_replay && wv == 0) replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table, first, true, job.debug_fault_every);
   __syncthreads();
   if (tid == 0 && job.stamps) ctl->ts[5] = wall_clock64();
   if (ctl->fault) {                             // (raised by the replay: the host finishes this step)

@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
     ctl->ts[1] = wall_clock64();
     ctl->ts[6] = ctl->ts[0];          // this step's tracker start (the next step's tracker overwrites ts[0] meanwhile)
   }
-  int fault = ctl->fault;
+  const int entry_fault = ctl->fault;
+  int fault = entry_fault;
   const int n = ctl->n;
   if (ap.debug_fault_every > 0 && (ctl->step % ap.debug_fault_every) == ap.debug_fault_every - 1) fault |= VO_FAULT_FORCED;
   // `length < self._num_features * 0.8` (klt.py:208-212)
@@ -231,11 +232,13 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
   if (redetect && ap.det_go && !ap.det_go[blockIdx.y]) fault |= VO_FAULT_NO_DETECTION;
   if (fault) {
     if (blockIdx.x == 0 && tid == 0) {
-      ctl->fault = fault;
+      if (!entry_fault) {               // raised here.  (A fault of an EARLIER step, still open: that step's counts stay --
+        ctl->fault = fault;             //  a step waiting for its next batch of hypotheses, VO_FAULT_CONTINUE, reports them
+        ctl->n_in = 0;                  //  when it closes.)
+        ctl->redetected = 0;
+      }
       ctl->few = 0;
-      ctl->n_in = 0;
-      ctl->n_p3p = 0;
-      ctl->redetected = 0;
+      ctl->n_p3p = 0;                   // this step's hypothesis kernel has nothing to do
     }
     return;
   }

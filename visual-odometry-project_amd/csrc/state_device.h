@@ -83,7 +83,7 @@ __device__ __forceinline__ void replay_fetch(const replay_args& a, int lane, int
 // ch: working storage; fetched0: it already holds the chunk of sbase = 0 (the pose kernel requests it in front of its
 // staging of the table and the coordinates, so that the replay does not start with a memory round trip of its own)
 __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const replay_args& a, int lane,
-                                            const double* tb, replay_chunk& ch, bool fetched0) {
+                                            const double* tb, replay_chunk& ch, bool fetched0, int debug_fault_every = 0) {
   if (lane == 0) {            // counters the bookkeeping kernels of this step add to
     ctl->n_cand = 0;
     ctl->n_dropped = 0;
@@ -94,8 +94,16 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
   const int N = ctl->n_p3p;
   long long n_it = ctl->n_iterations;
   double orat = ctl->outlier_ratio;
-  long long n = 0;
-  int best = -1, best_idx = -1, consumed = -1, hyp_valid = 0;
+  // cont > 0: the loop has walked `cont` batches of `hyp` samples already (VO_FAULT_CONTINUE) and goes on where it stopped
+  const int cont = ctl->cont;
+  const int consumed_before = cont ? ctl->consumed : 0;
+  const int best_idx_before = cont ? ctl->best_idx : -1;
+  long long n = cont ? ctl->n_done : 0;
+  int best = cont ? ctl->best_count : -1, best_idx = -1, consumed = -1, hyp_valid = cont ? ctl->hyp_valid : 0;
+  if (!cont && lane == 0) {
+    ctl->n_iterations0 = n_it;
+    ctl->outlier_ratio0 = orat;
+  }
   bool risky_seen = false;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int sbase = 0; sbase < hyp; sbase += 1024) {
@@ -150,12 +158,16 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
     }
   }
   int fault = 0;
+  bool more = false;                              // the rule wants samples beyond this batch
   if (consumed < 0) {
     if (n >= n_it) consumed = hyp;                // the loop ends exactly behind the last sample of the batch
-    else fault |= VO_FAULT_UNFINISHED;            // (also: no hypothesis had a solution)
+    else more = true;
   }
   if (risky_seen) fault |= VO_FAULT_RISKY_DRAW;
-  if (!fault && best_idx < 0) fault |= VO_FAULT_UNFINISHED;
+  if (debug_fault_every > 0 && !more && (ctl->step % debug_fault_every) == debug_fault_every - 1) fault |= VO_FAULT_FORCED;
+  // a bound beyond the table (an unbounded max_iterations and a ratio whose bound the table does not hold): the host's loop
+  if (!fault && more && n_it == 0x7fffffffffffffffll) fault |= VO_FAULT_UNFINISHED;
+  if (!fault && !more && best_idx < 0 && best_idx_before < 0) fault |= VO_FAULT_UNFINISHED;   // (no hypothesis had a solution)
   if (fault) {
     if (lane == 0) {
       ctl->fault = fault;
@@ -163,19 +175,24 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
     }
     return;
   }
-  if (lane < 9) ctl->best_pose[lane] = a.R[9 * best_idx + lane];
-  if (lane < 3) ctl->best_pose[9 + lane] = a.t[3 * best_idx + lane];
-  const int wn = (N + 63) >> 6;
-  for (int w = lane; w < wn; w += 64) a.best_mask[w] = a.masks[(size_t)best_idx * a.words + w];
+  if (best_idx >= 0) {                            // the best so far lives in this batch: its pose and mask row
+    if (lane < 9) ctl->best_pose[lane] = a.R[9 * best_idx + lane];
+    if (lane < 3) ctl->best_pose[9 + lane] = a.t[3 * best_idx + lane];
+    const int wn = (N + 63) >> 6;
+    for (int w = lane; w < wn; w += 64) a.best_mask[w] = a.masks[(size_t)best_idx * a.words + w];
+  }
   if (lane == 0) {
+    if (more) consumed = hyp;
     ctl->n_iterations = n_it;
     ctl->outlier_ratio = orat;
     ctl->raw_pos += 7ull * (unsigned long long)consumed;
-    ctl->best_idx = best_idx;
+    ctl->best_idx = best_idx >= 0 ? cont * hyp + best_idx : best_idx_before;
     ctl->best_count = best;
-    ctl->consumed = consumed;
+    ctl->consumed = consumed_before + consumed;
     ctl->hyp_valid = hyp_valid;
     ctl->n_done = n;
+    ctl->cont = more ? cont + 1 : 0;
+    if (more) ctl->fault = VO_FAULT_CONTINUE;     // (n_p3p stays: the next batch draws from the same population)
   }
 }
 

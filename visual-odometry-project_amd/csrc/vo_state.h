@@ -43,7 +43,9 @@ enum {
   VO_FAULT_UNFINISHED = 4,      // the sequential rule is not done after `hyp` samples
   VO_FAULT_CAPACITY = 8,        // appending the detector's keypoints would exceed the feature capacity
   VO_FAULT_FORCED = 16,         // test hook (vo_pipeline_config.debug_fault_every)
-  VO_FAULT_NO_DETECTION = 32    // the tracks fell below the re-detect limit on a frame whose detection was skipped
+  VO_FAULT_NO_DETECTION = 32,   // the tracks fell below the re-detect limit on a frame whose detection was skipped
+  VO_FAULT_CONTINUE = 64        // not an error: the sequential rule is not done after this launch's `hyp` samples; the loop's
+                                // state is in the control block and the host launches the next batch (hypotheses + pose kernel)
 };
 
 struct vo_seq_ctl {
@@ -61,11 +63,13 @@ struct vo_seq_ctl {
   int32_t few;             // VO_FAULT_FEW_LANDMARKS found by THIS step's regroup; the pose kernel ORs it into `fault`.  (Not
                            // written to `fault` by the regroup itself: its other workgroups read that word on entry, and one
                            // dispatched after block 0 had retired would skip its features.)
-  int32_t pad0;
+  int32_t cont;            // batches of `hyp` samples this step's RANSAC loop has already walked (VO_FAULT_CONTINUE); 0 = none
   // ---- RANSAC: persists across frames like the reference's estimator object ----
   int64_t n_iterations;
   double outlier_ratio;
   uint64_t raw_pos;        // absolute index of the next unread 32-bit generator output
+  int64_t n_iterations0;   // n_iterations / outlier_ratio as the step found them (a step that continues over several batches
+  double outlier_ratio0;   // and then meets a draw NumPy might have rejected is redone from its start by the host path)
   // ---- this step ----
   int32_t best_idx, best_count, consumed, hyp_valid;
   int64_t n_done;
@@ -127,6 +131,9 @@ struct vo_pose_job {
   unsigned* seq_word;
   unsigned seq;
   int stamps;           // debug: device-clock stamps after the replay and after the refinement (record ts[6], ts[7])
+  int debug_fault_every; // test hook: every n-th step the replay raises VO_FAULT_FORCED where its loop ends (a fault from the
+                        // POSE kernel, after the step's regroup has run and -- over several batches -- after the loop's
+                        // state has moved: what a draw NumPy might have rejected does, about once in 10^3 steps)
 };
 int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job, int S = 1);   // S > 1: sequence q uses block q of every array
 
