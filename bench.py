@@ -269,7 +269,8 @@ def api_leg(ctx):
                        "P3PPoseEstimator / LandmarksTriangulator / State with host arrays between stages, Shi-Tomasi 500 "
                        "corners as the reference configures KLT; (b) vo.driver.run_on_device = host bootstrap, then one "
                        "1.7 MB image upload + one submit per frame, 2000 keypoints, 4000 hypotheses per launch, main.py's P3P "
-                       "settings (1.25 px, confidence 0.9999, up to 10000 iterations)")
+                       "settings (1.25 px, confidence 0.9999, up to 10000 iterations: a frame that needs more than one launch "
+                       "of hypotheses gets further ones, on the device)")
     except Exception as e:                                   # the headline must not depend on this leg
         out["error"] = repr(e)
     return out

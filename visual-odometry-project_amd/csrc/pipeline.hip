@@ -705,6 +705,17 @@ static int enqueue_pose_half(vo_pipeline* p, const vo_pipeline::flight_t& f, int
   job.seq_word = p->m_seq + (size_t)f.rslot * p->S + q;
   job.seq = seq;
   job.debug_fault_every = debug_pose_fault;
+  // The landmark stage as its own launch of cap / 256 workgroups per sequence.  (Round 2 had the pose kernel's one
+  // workgroup go on with it -- VO_FUSED_TAIL=1 -- which was neutral at ~450 candidates per frame on a stream that never
+  // lost a track; the forward stream triangulates ~1100 per frame, three rounds of DLTs for one workgroup: 50 us
+  // against 18 for the launch, its boundary included; step period 152 -> 121 us.)
+  static const bool split_tail = getenv("VO_FUSED_TAIL") == nullptr;
+  if (split_tail) {
+    job.tail = 0;
+    VO_TRY(vo_frame_pose(ctx, job, Sn));
+    VO_TRY(vo_state_landmarks(ctx, ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, job.res, job.seq_word, seq, Sn));
+    return VO_OK;
+  }
   VO_TRY(vo_frame_pose(ctx, job, Sn));
   return VO_OK;
 }

@@ -110,7 +110,8 @@ def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int =
     image upload and one call, and nothing but the pose record comes back.  KLT tracker mode with the Harris
     detector (BASELINE.json configs[1]); P3P-RANSAC as main.py:194-201 configures it (1.25 px, confidence 0.9999)
     with `hyp` hypotheses solved and scored per launch (a frame whose sequential rule needs more -- main.py allows
-    10000 iterations -- is finished by the host path; with 4000 none of the synthetic stream's frames is).  redetect_start_pose: "identity" is the reference's
+    10000 iterations -- gets further launches of hypotheses until the rule is done; the loop's state stays on the
+    device).  redetect_start_pose: "identity" is the reference's
     update_features (klt.py:148-153: re-detected keypoints start their track at np.eye(4), so away from the origin
     they triangulate against a wrong baseline and can take the estimate with them); "current" starts them at the
     pose of the frame they were found on."""
