@@ -486,6 +486,7 @@ def main():
     state = states[0]
     pipe = make_pipeline(ctx, streams, states, S, DETECT_MARGIN)
     n_boot = int((state.curr_frame.features.state == 2).sum())
+    boot_info = getattr(state, "bootstrap_info", {})
     walker = Walker(pipe, N_FRAMES)
     batch = {"fill": 0, "buf": 0}
 
@@ -696,6 +697,11 @@ def main():
                                          "note": "the whole first pass (frames %d..%d) vs the analytic poses of the synthetic stream, "
                                                  "monocular scale fixed once by the bootstrap baseline" % (PASS_START + 1, N_FRAMES - 1)},
             "setup_s": {"render_%d_frames_%d_workers" % (len(jobs), workers): round(render_s, 1)},
+            "bootstrap": {"relative_pose_ms": round(1e3 * boot_info.get("relative_pose_seconds", 0.0), 3),
+                          "correspondences": boot_info.get("correspondences"), "inliers": boot_info.get("inliers"),
+                          "note": "triangulate_matches of frames 0 and 2 (triangulation.py:88-350): 8-point RANSAC hypotheses + "
+                                  "counts, closing fit, E decomposition, four cheirality votes and the triangulation on the "
+                                  "device; the sequential accept rule and the Python classes around it on the host; untimed"},
         }
         if world == 1 and not args.no_cpu_baseline:
             parity, base = oracle_leg(stream, state, [rs[0] for _, rs in first_pass[:CPU_BASELINE_FRAMES]], first_state, ORACLE_FRAMES)

@@ -172,6 +172,34 @@ int vo_triangulate_dlt_dev(vo_ctx* ctx, const double* d_x1, const double* d_x2, 
                            const double* d_C1, int c1_per_point, const double* d_C2,
                            double* d_X);
 
+/* ---- two-view bootstrap ----------------------------------------------------------
+ * [ref: src/vo/landmarks/triangulation.py:110-350, src/vo/helpers.py:31-54; called once per sequence, src/main.py:204-230]
+ * vo_fundamental_hypotheses: the model_fn / error_fn pair of _find_fundamental_matrix_ransac (:134-145) for Hyp samples
+ *   at once -- samples: Hyp*8 indices into the N correspondences p1, p2 (N*2 each; the reference hands the loop
+ *   Hartley-normalised points, :147-149).  Per sample: Kronecker rows (:203-205), null vector of the 8x9 system
+ *   (:209-212), rank-2 projection (:214-217) -> F Hyp*9 row-major.  normalize_samples != 0: the sample's own Hartley
+ *   normalisation around the fit (_find_fundamental_matrix(is_normalized=False), :195-198, :220-221).  error_kind 0:
+ *   (p2^T F p1)^2 (:140-145); 1: the larger squared distance to the epipolar lines of the two images.  inlier =
+ *   error < threshold (src/vo/algorithms/ransac.py:104-106); counts Hyp, masks Hyp*ceil(N/64) words (nullable).
+ *   The sequential accept / adapt rule over (counts) is vo_ransac_replay's (every sample has a model: valid = 1).
+ * vo_fundamental_fit: _find_fundamental_matrix (:165-222) over the correspondences whose mask byte is set (NULL: all):
+ *   what RANSAC's closing model_fn(population[inliers]) computes (ransac.py:123-127).  normalize as above.
+ * vo_essential_decompose: _decompose_essential_matrix (:245-277): E 3x3 -> M4 4*12, [R_j | (-1)^i T] at index 2i+j.
+ *   The four candidates are the reference's set; which of the two rotations is "R_0" and which sign of T comes first
+ *   depends on the signs the SVD routine picks (LAPACK's in the reference) and may differ.
+ * vo_relative_pose: _find_relative_pose (:279-350) given F: E = K2^T F K1, the four candidates, the cheirality votes
+ *   over the correspondences whose inliers byte is set (NULL: all) by DLT against K1 [I|0] (:313-332, strict `>`),
+ *   the winner's triangulation of ALL N correspondences -> M 12 (3x4), X N*3 (frame 1), mask_out N (nullable):
+ *   inliers & in front of both cameras (:341-348), M4 48 (nullable).                                              */
+int vo_fundamental_hypotheses(vo_ctx* ctx, const double* p1, const double* p2, int N, const int32_t* samples, int Hyp,
+                              int normalize_samples, int error_kind, double threshold, double* F, int32_t* counts,
+                              uint64_t* masks);
+int vo_fundamental_fit(vo_ctx* ctx, const double* p1, const double* p2, int N, const uint8_t* mask, int normalize,
+                       double* F);
+int vo_essential_decompose(vo_ctx* ctx, const double* E, double* M4);
+int vo_relative_pose(vo_ctx* ctx, const double* x1, const double* x2, int N, const uint8_t* inliers, const double* K1,
+                     const double* K2, const double* F, double* M, double* X, uint8_t* mask_out, double* M4);
+
 /* ---- P3P hypotheses + reprojection scoring -------------------------------------
  * [ref: src/vo/pose_estimation/p3p.py:51-79]   model_fn: cv2.solvePnP(P3P) on the 4
  *       sampled correspondences -> (R, t) world->camera, or None

@@ -168,21 +168,94 @@ def test_triangulate_candidates_like_reference_test(ctx):
     assert np.allclose(X, Xt, atol=1e-4)                                  # tests/test_triangulation.py:282
 
 
+def same_up_to_scale(A, B, tol):
+    """F and E are defined up to scale and sign: compared as unit Frobenius-norm matrices with the sign of B."""
+    A, B = A / np.linalg.norm(A), B / np.linalg.norm(B)
+    if np.sum(A * B) < 0:
+        A = -A
+    return np.abs(A - B).max() < tol
+
+
+def same_candidate_set(M4, ref, tol):
+    """_decompose_essential_matrix's four [R | +-T]: the same set; the order depends on the SVD routine's signs."""
+    used = set()
+    for m in M4:
+        hit = [k for k in range(4) if k not in used and np.abs(m - ref[k]).max() < tol]
+        if not hit:
+            return False
+        used.add(hit[0])
+    return len(used) == 4
+
+
 def test_bootstrap_matches_reference_golden(ctx):
+    """The device bootstrap (csrc/bootstrap.hip) against the reference's own outputs (tests/golden/bootstrap.npz,
+    use_opencv=False): 8-point F and E up to scale / sign, the four decompositions as a set, M, the landmarks; through
+    RANSAC (the reference's sampler and sequential rule on the host, hypotheses + counts + closing fit on the device)
+    the golden's inlier mask exactly."""
     from vo.landmarks import LandmarksTriangulator
     cam1, cam2 = cameras()
     g = np.load(os.path.join(G, "bootstrap.npz"))
-    tri = LandmarksTriangulator(camera1=cam1, camera2=cam2, use_ransac=False, use_opencv=False)
-    assert np.allclose(tri._find_fundamental_matrix(g["x1"], g["x2"]), g["F"], rtol=1e-9, atol=1e-12)
-    assert np.allclose(tri._find_essential_matrix(g["x1"], g["x2"]), g["E"], rtol=1e-9, atol=1e-9)
-    assert np.allclose(tri._decompose_essential_matrix(g["E"]), g["M4"], atol=1e-12)
+    tri = LandmarksTriangulator(camera1=cam1, camera2=cam2, use_ransac=False, use_opencv=False, context=ctx)
+    assert same_up_to_scale(tri._find_fundamental_matrix(g["x1"], g["x2"]), g["F"], 1e-9)
+    assert same_up_to_scale(tri._find_essential_matrix(g["x1"], g["x2"]), g["E"], 1e-9)
+    assert same_candidate_set(tri._decompose_essential_matrix(g["E"]), g["M4"], 1e-9)
     M, X = tri._find_relative_pose(g["x1"], g["x2"])
     assert np.allclose(M, g["M"], atol=1e-9) and np.allclose(X, g["X_tri"], rtol=1e-7, atol=1e-7)
     tri_r = LandmarksTriangulator(camera1=cam1, camera2=cam2, use_ransac=True, use_opencv=False, outlier_ratio=0.5,
-                                  ransac_threshold=1e-3, ransac_confidence=0.99)
+                                  ransac_threshold=1e-3, ransac_confidence=0.99, context=ctx)
     Mr, Xr, inl = tri_r._find_relative_pose(g["x1"], g["x2_outliers"])
     assert np.array_equal(inl, g["inliers_ransac"]) and np.allclose(Mr, g["M_ransac"], atol=1e-9)
     assert np.allclose(Xr, g["X_ransac"], rtol=1e-6, atol=1e-6)
+
+
+def test_bootstrap_kernels_match_the_oracle(ctx):
+    """Hypotheses, counts and masks of a batch of samples, the closing fit and the relative pose against
+    oracle/bootstrap_np.py (itself pinned to the reference's golden) on a noisy two-view scene with gross outliers: both
+    error kinds, population-normalised and per-sample-normalised fits, at the bootstrap's size (2000 correspondences)."""
+    from oracle import bootstrap_np as bo
+    cam1, cam2 = cameras()
+    rng = np.random.default_rng(11)
+    n = 2000
+    X = rng.uniform(-1, 1, size=(n, 3, 1))
+    X[:, 2] = X[:, 2] * 5 + 10
+    x1 = cam1.project_points_world_frame(X) + rng.normal(0, 0.2, size=(n, 2, 1))
+    x2 = cam2.project_points_world_frame(X) + rng.normal(0, 0.2, size=(n, 2, 1))
+    bad = rng.permutation(n)[:500]
+    x2[bad] += rng.uniform(-50, 50, size=(500, 2, 1))
+    samples = np.stack([rng.choice(n, size=8, replace=False) for _ in range(300)]).astype(np.int32)
+    p1n, _ = bo.normalize_points(x1)
+    p2n, _ = bo.normalize_points(x2)
+    for (a, b, norm, kind, thr) in ((p1n, p2n, False, 0, 1e-4), (x1, x2, True, 1, 1.0)):
+        F, counts, masks = ctx.fundamental_hypotheses(a, b, samples, thr, norm, kind, want_masks=True)
+        pop = np.stack([a, b], axis=1)
+        differ = 0
+        for h in range(len(samples)):
+            Fo = bo.find_fundamental_matrix(a[samples[h]], b[samples[h]], is_normalized=not norm)
+            assert same_up_to_scale(F[h], Fo, 1e-7), h
+            # decisions with the DEVICE's F through the oracle's error function: identical but for errors within rounding
+            # of the threshold
+            err = (bo.algebraic_errors if kind == 0 else bo.epipolar_errors)(F[h], pop)
+            inl = err < thr
+            near = np.abs(err - thr) < 1e-9 * thr
+            assert np.array_equal(inl[~near], masks[h][~near]) and counts[h] == masks[h].sum()
+            differ += int(near.sum())
+        assert differ < 5
+    # closing fit over a mask, both normalisations
+    mask = np.ones(n, dtype=bool)
+    mask[bad] = False
+    assert same_up_to_scale(ctx.fundamental_fit(x1, x2, mask, normalize=True), bo.find_fundamental_matrix(x1[mask], x2[mask]), 1e-9)
+    assert same_up_to_scale(ctx.fundamental_fit(p1n, p2n, mask, normalize=False),
+                            bo.find_fundamental_matrix(p1n[mask], p2n[mask], True), 1e-9)
+    # relative pose with and without an inlier mask
+    K1, K2 = cam1.intrinsic_matrix, cam2.intrinsic_matrix
+    Fm = bo.find_fundamental_matrix(x1[mask], x2[mask])
+    for inl in (None, mask):
+        M, Xd, m_out, M4 = ctx.relative_pose(x1, x2, K1, K2, Fm, inl)
+        Mo, Xo, mo, M4o = bo.find_relative_pose(x1, x2, K1, K2, Fm, inl)
+        assert same_candidate_set(M4, M4o, 1e-9) and np.allclose(M, Mo, atol=1e-9)
+        assert np.array_equal(m_out, mo)
+        ok = np.isfinite(Xo[:, :, 0]).all(axis=1)
+        assert np.allclose(Xd[ok], Xo[ok][:, :, 0], rtol=1e-6, atol=1e-6)
 
 
 # ---------------- trackers ----------------

@@ -105,6 +105,10 @@ static inline int vo_check_launch(vo_ctx* ctx, const char* what) {
 
 static inline int vo_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+struct vo_cam2 {      // the two intrinsic matrices of the two-view bootstrap (bootstrap.hip), row-major
+  double K1[9], K2[9];
+};
+
 // ---- internal entry points shared between translation units (not part of the C ABI) ----
 // P3P hypotheses + inlier counts of the frame loop (p3p.hip): sample indices derived on the device from raw
 // generator outputs in a ring, population size and stream position read on the device.

@@ -134,6 +134,10 @@ _SIGS = {
     "vo_min_eigen_map": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vo_sift": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "vo_sift_capacity": (_i, [_i, _i]),
+    "vo_fundamental_hypotheses": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
+    "vo_fundamental_fit": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "vo_essential_decompose": (_i, [_vp, _vp, _vp]),
+    "vo_relative_pose": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vo_rng_choice": (_i, [_vp, _i, _i, _i, _vp]),
     "vo_ransac_num_iterations": (C.c_int64, [_d, _d, _i]),
     "vo_ransac_replay": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -410,6 +414,56 @@ class Context:
         X = np.empty((n, 3), np.float64)
         self._chk(self._lib.vo_triangulate_dlt(self._h, _ptr(x1), _ptr(x2), n, _ptr(C1), per_point, _ptr(C2), _ptr(X)))
         return X
+
+    # ---- two-view bootstrap ----
+    def fundamental_hypotheses(self, p1, p2, samples, threshold, normalize_samples=False, error_kind=0, want_masks=False):
+        """8-point F of every sample (samples (Hyp, 8)) and its inlier count over all correspondences:
+        (F (Hyp, 3, 3), counts (Hyp,)[, masks (Hyp, N) bool]).  error_kind 0: (p2^T F p1)^2; 1: squared epipolar distance."""
+        p1 = _c(np.asarray(p1).reshape(-1, 2), np.float64)
+        p2 = _c(np.asarray(p2).reshape(-1, 2), np.float64)
+        samples = _c(np.asarray(samples).reshape(-1, 8), np.int32)
+        n, h = p1.shape[0], samples.shape[0]
+        F = np.empty((h, 3, 3), np.float64)
+        counts = np.empty(h, np.int32)
+        words = (n + 63) // 64
+        masks = np.empty((h, words), np.uint64) if want_masks else None
+        self._chk(self._lib.vo_fundamental_hypotheses(self._h, _ptr(p1), _ptr(p2), n, _ptr(samples), h,
+                                                      int(bool(normalize_samples)), int(error_kind), float(threshold),
+                                                      _ptr(F), _ptr(counts), _ptr(masks)))
+        if want_masks:
+            bits = np.unpackbits(masks.view(np.uint8).reshape(h, words * 8), axis=1, bitorder="little")[:, :n]
+            return F, counts, bits.astype(bool)
+        return F, counts
+
+    def fundamental_fit(self, p1, p2, mask=None, normalize=True):
+        """The 8-point fit over all (masked) correspondences: F (3, 3)."""
+        p1 = _c(np.asarray(p1).reshape(-1, 2), np.float64)
+        p2 = _c(np.asarray(p2).reshape(-1, 2), np.float64)
+        m = None if mask is None else _c(np.asarray(mask).reshape(-1), np.uint8)
+        F = np.empty((3, 3), np.float64)
+        self._chk(self._lib.vo_fundamental_fit(self._h, _ptr(p1), _ptr(p2), p1.shape[0], _ptr(m), int(bool(normalize)), _ptr(F)))
+        return F
+
+    def essential_decompose(self, E):
+        E = _c(np.asarray(E).reshape(3, 3), np.float64)
+        M4 = np.empty((4, 3, 4), np.float64)
+        self._chk(self._lib.vo_essential_decompose(self._h, _ptr(E), _ptr(M4)))
+        return M4
+
+    def relative_pose(self, x1, x2, K1, K2, F, inliers=None):
+        """(M (3, 4), X (N, 3), mask (N,) bool, M4 (4, 3, 4)): the cheirality vote over the four decompositions of
+        E = K2^T F K1 and the winner's triangulation of all correspondences."""
+        x1 = _c(np.asarray(x1).reshape(-1, 2), np.float64)
+        x2 = _c(np.asarray(x2).reshape(-1, 2), np.float64)
+        K1 = _c(np.asarray(K1).reshape(3, 3), np.float64)
+        K2 = _c(np.asarray(K2).reshape(3, 3), np.float64)
+        F = _c(np.asarray(F).reshape(3, 3), np.float64)
+        inl = None if inliers is None else _c(np.asarray(inliers).reshape(-1), np.uint8)
+        n = x1.shape[0]
+        M, X, mask, M4 = np.empty((3, 4)), np.empty((n, 3)), np.empty(n, np.uint8), np.empty((4, 3, 4))
+        self._chk(self._lib.vo_relative_pose(self._h, _ptr(x1), _ptr(x2), n, _ptr(inl), _ptr(K1), _ptr(K2), _ptr(F), _ptr(M),
+                                             _ptr(X), _ptr(mask), _ptr(M4)))
+        return M, X, mask.astype(bool), M4
 
     # ---- P3P ----
     def p3p_hypotheses(self, X, x, K, samples, thr_sq, want_masks=False):

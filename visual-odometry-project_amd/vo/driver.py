@@ -34,8 +34,9 @@ def make_estimators(camera, ransac_threshold=0.25):
 
 
 def bootstrap(sequence: Sequence, tracker_mode: str = "klt", tracker_setup=None, ransac_threshold=0.25):
-    """main.py:204-230: frames 0 and 2 -> (state, tracker, triangulator, pose_estimator).  Runs on the host
-    (8-point RANSAC, essential-matrix decomposition, cheirality) with the DLT passes on the GPU."""
+    """main.py:204-230: frames 0 and 2 -> (state, tracker, triangulator, pose_estimator).  The 8-point RANSAC's
+    hypotheses, counts and closing fit, the essential-matrix decomposition and the cheirality votes run on the GPU
+    (csrc/bootstrap.hip); the host keeps the sequential accept rule and the bookkeeping classes."""
     camera = sequence.get_camera()
     triangulator, pose_estimator = make_estimators(camera, ransac_threshold)
     init_frame = next(sequence)
@@ -47,7 +48,10 @@ def bootstrap(sequence: Sequence, tracker_mode: str = "klt", tracker_setup=None,
     tracker = Tracker(init_frame, mode=tracker_mode)
     matches = tracker.trackFeatures(state.curr_frame, new_frame)
     state.update_from_matches(matches)
+    t0 = time.perf_counter()
     M, landmarks, inliers = triangulator.triangulate_matches(matches)
+    state.bootstrap_info = {"relative_pose_seconds": time.perf_counter() - t0, "correspondences": int(len(inliers)),
+                            "inliers": int(np.sum(inliers))}
     f2 = matches.frame2.features
     outliers = np.zeros(shape=(f2.length,), dtype=bool)
     outliers[f2.match_inliers] = ~inliers

@@ -1,16 +1,18 @@
 """Landmark triangulation and two-view bootstrap (reference: src/vo/landmarks/triangulation.py).
 
 Every triangulation is the batched HIP DLT kernel (vo_triangulate_dlt).  The two-view
-bootstrap (8-point F, optional RANSAC, E decomposition, cheirality vote) runs once per
-sequence and stays host NumPy as in the reference; its four cheirality passes use the
-same DLT kernel.  `use_opencv` is accepted for signature compatibility; both values run
+bootstrap runs on the device as well (csrc/bootstrap.hip): 8-point hypotheses of a whole
+batch of RANSAC samples and their inlier counts in two launches, the closing fit over all
+inliers, and E decomposition + the four cheirality votes + the final triangulation in one
+kernel; the host keeps the reference's sequential accept / adapt rule over the counts and
+its generator.  `use_opencv` is accepted for signature compatibility; both values run
 these routines (the reference's cv2.findFundamentalMat / cv2.triangulatePoints have no
 counterpart here)."""
 import numpy as np
 
 from vo import _native
 from vo.algorithms import RANSAC
-from vo.helpers import normalize_points, to_homogeneous_coordinates
+from vo.helpers import normalize_points
 from vo.primitives import Features, Matches
 from vo.sensors import Camera
 
@@ -64,63 +66,48 @@ class LandmarksTriangulator:
         return self._find_relative_pose(points1, points2)
 
     def _find_fundamental_matrix(self, points1: np.ndarray, points2: np.ndarray, is_normalized: bool = False):
-        """Normalised 8-point algorithm with the rank-2 constraint (triangulation.py:165-222)."""
+        """Normalised 8-point algorithm with the rank-2 constraint (triangulation.py:165-222): Hartley normalisation,
+        normal matrix, its smallest eigenvector and the rank-2 projection in one kernel (vo_fundamental_fit)."""
         assert points1.shape == points2.shape, "Input points dimension mismatch"
         assert points1.shape[0] >= 8, "Not enough points for 8-point algorithm"
         assert points1.shape[1] == 2, "Points must have two rows for (u,v)"
         assert points1.shape[2] == 1, "Points must be a column vector"
-        if not is_normalized:
-            points1, T1 = normalize_points(points1)
-            points2, T2 = normalize_points(points2)
-        p1 = to_homogeneous_coordinates(points1)[:, :, 0]
-        p2 = to_homogeneous_coordinates(points2)[:, :, 0]
-        Q = (p1[:, :, None] * p2[:, None, :]).reshape(-1, 9)         # rows kron(p1_i, p2_i)
-        _, _, Vh = np.linalg.svd(Q, full_matrices=True)
-        F = Vh[-1, :].reshape(3, 3).T
-        U, S, Vh = np.linalg.svd(F)
-        S[-1] = 0
-        F = U @ np.diag(S) @ Vh
-        return F if is_normalized else T2.T @ F @ T1
+        return self._context().fundamental_fit(points1, points2, None, normalize=not is_normalized)
+
+    def _ransac_fundamental(self, points1, points2, threshold, normalize_samples, error_kind, max_iterations=np.inf,
+                            batch_size=2048):
+        """The reference's RANSAC loop (src/vo/algorithms/ransac.py:69-129, s = 8) with its model_fn / error_fn calls
+        batched: every batch of samples drawn ahead from a copy of the generator is solved and scored by two launches
+        (vo_fundamental_hypotheses), the sequential accept / adapt rule is replayed over the counts, the generator moves by
+        what the loop consumed; the closing fit over all inliers is vo_fundamental_fit.  Returns (F, inlier mask, RANSAC)."""
+        ctx = self._context()
+        n = points1.shape[0]
+        ransac = RANSAC(s_points=8, population=np.arange(n), model_fn=None, error_fn=None, inlier_threshold=threshold,
+                        outlier_ratio=self._outlier_ratio, confidence=self._ransac_confidence, max_iterations=max_iterations)
+
+        def batch_fn(samples):
+            F, counts, masks = ctx.fundamental_hypotheses(points1, points2, samples, threshold, normalize_samples, error_kind,
+                                                          want_masks=True)
+            return np.ones(len(samples), np.uint8), counts, lambda b: (F[b], masks[b])
+
+        _, inliers, _ = ransac.find_best_model_batched(n, batch_fn, batch_size=batch_size)
+        F = ctx.fundamental_fit(points1, points2, inliers, normalize=normalize_samples)   # ransac.py:123-127
+        return F, inliers, ransac
 
     def _find_fundamental_matrix_ransac(self, points1: np.ndarray, points2: np.ndarray):
-        """8-point inside RANSAC on normalised points, algebraic error (triangulation.py:110-163)."""
-        def model_fn(population):
-            return self._find_fundamental_matrix(population[:, 0], population[:, 1], is_normalized=True)
-
-        def error_fn(F, points):
-            p1 = to_homogeneous_coordinates(points[:, 0])
-            p2 = to_homogeneous_coordinates(points[:, 1])
-            return np.sum((p2.transpose((0, 2, 1)) @ F @ p1) ** 2, axis=(1, 2))
-
+        """8-point inside RANSAC (triangulation.py:110-163)."""
         if self._use_opencv:
-            # cv2.findFundamentalMat(FM_RANSAC, ransacReprojThreshold, confidence) as main.py:185-193
-            # configures it: a correspondence is an inlier when its squared distance to the
-            # epipolar line, in pixels and in both images, is within the threshold squared; F is
-            # re-fitted on all inliers (triangulation.py:126-133 hands this to OpenCV).
-            def model_px(population):
-                return self._find_fundamental_matrix(population[:, 0], population[:, 1], is_normalized=False)
-
-            def error_px(F, points):
-                p1 = to_homogeneous_coordinates(points[:, 0])[:, :, 0]
-                p2 = to_homogeneous_coordinates(points[:, 1])[:, :, 0]
-                l2 = p1 @ F.T                                          # epipolar lines in image 2
-                l1 = p2 @ F                                            # epipolar lines in image 1
-                num = np.sum(p2 * l2, axis=1) ** 2
-                d2 = num / (l2[:, 0] ** 2 + l2[:, 1] ** 2)
-                d1 = num / (l1[:, 0] ** 2 + l1[:, 1] ** 2)
-                return np.maximum(d1, d2)
-
-            ransac_px = RANSAC(s_points=8, population=np.stack([points1, points2], axis=1), model_fn=model_px,
-                               error_fn=error_px, inlier_threshold=self._ransac_reproj_threshold ** 2,
-                               outlier_ratio=self._outlier_ratio, confidence=self._ransac_confidence,
-                               max_iterations=2000)
-            return ransac_px.find_best_model()
-        points1, T1 = normalize_points(points1)
-        points2, T2 = normalize_points(points2)
-        ransac_F = RANSAC(s_points=8, population=np.stack([points1, points2], axis=1), model_fn=model_fn,
-                          error_fn=error_fn, inlier_threshold=self._ransac_reproj_threshold,
-                          outlier_ratio=self._outlier_ratio, confidence=self._ransac_confidence)
-        F, inliers = ransac_F.find_best_model()
+            # cv2.findFundamentalMat(FM_RANSAC, ransacReprojThreshold, confidence) as main.py:185-193 configures it is
+            # not reproducible (OpenCV's own sampler).  This route: a correspondence is an inlier when its squared
+            # distance to the epipolar line, in pixels and in both images, is within the threshold squared; every sample
+            # is fitted in its own Hartley frame; at most 2000 iterations; F re-fitted on all inliers.
+            F, inliers, _ = self._ransac_fundamental(points1, points2, self._ransac_reproj_threshold ** 2, True, 1,
+                                                     max_iterations=2000)
+            return F, inliers
+        # the reference's own route: the whole population normalised once (helpers.py:31-54), algebraic error
+        p1, T1 = normalize_points(points1)
+        p2, T2 = normalize_points(points2)
+        F, inliers, _ = self._ransac_fundamental(p1, p2, self._ransac_reproj_threshold, False, 0)
         return T2.T @ F @ T1, inliers
 
     def _find_essential_matrix(self, points1: np.ndarray, points2: np.ndarray):
@@ -132,42 +119,21 @@ class LandmarksTriangulator:
         return K2.T @ self._find_fundamental_matrix(points1, points2) @ K1
 
     def _decompose_essential_matrix(self, E: np.ndarray) -> np.ndarray:
-        """The four [R | +-T] candidates (triangulation.py:245-277)."""
-        U, _, Vh = np.linalg.svd(E)
-        T = U[:, 2:]
-        W = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]])
-        R = np.stack([U @ W @ Vh, U @ W.T @ Vh])
-        for i in range(2):
-            if np.linalg.det(R[i]) < 0:
-                R[i] *= -1
-        M = np.zeros((4, 3, 4))
-        for i in range(2):
-            for j in range(2):
-                M[2 * i + j] = np.concatenate([R[j], (-1) ** i * T], axis=-1)
-        return M
+        """The four [R | +-T] candidates (triangulation.py:245-277); the same set as the reference's, in the order this
+        library's SVD gives (vo_essential_decompose)."""
+        return self._context().essential_decompose(E)
 
     def _find_relative_pose(self, points1: np.ndarray, points2: np.ndarray):
         """Relative pose camera1 -> camera2 by cheirality vote over the four decompositions, and
-        the triangulation of ALL input points with the winner (triangulation.py:279-350)."""
+        the triangulation of ALL input points with the winner (triangulation.py:279-350): one kernel
+        (vo_relative_pose) behind the fundamental matrix."""
+        K1 = np.asarray(self.camera1.intrinsic_matrix, np.float64)
+        K2 = np.asarray(self.camera2.intrinsic_matrix, np.float64)
         if self._use_ransac:
-            E, inliers = self._find_essential_matrix(points1, points2)
-            p1_in, p2_in = points1[inliers], points2[inliers]
+            F, inliers = self._find_fundamental_matrix_ransac(points1, points2)
         else:
-            E = self._find_essential_matrix(points1, points2)
-            p1_in, p2_in = points1, points2
-        M2 = self._decompose_essential_matrix(E)
-        M1 = np.hstack((np.eye(3), np.zeros((3, 1))))
-        K1, K2 = self.camera1.intrinsic_matrix, self.camera2.intrinsic_matrix
-        best_valid, best_inliers, best_M = -1, None, None
-        for m in range(M2.shape[0]):
-            X1 = self._linear_triangulation(p1_in, p2_in, K1 @ M1, K2 @ M2[m])
-            X2 = M2[m][:, :3] @ X1 + M2[m][:, 3:]
-            in_front = ((X1[:, -1] >= 0) & (X2[:, -1] >= 0)).flatten()
-            if in_front.sum() > best_valid:
-                best_valid, best_inliers, best_M = in_front.sum(), in_front, M2[m]
-        landmarks = self._linear_triangulation(points1, points2, K1 @ M1, K2 @ best_M)
+            F, inliers = self._find_fundamental_matrix(points1, points2), None
+        M, X, mask, _ = self._context().relative_pose(points1, points2, K1, K2, F, inliers)
         if self._use_ransac:
-            mask = np.zeros((points1.shape[0],), dtype=bool)
-            mask[inliers] = best_inliers
-            return best_M, landmarks, mask
-        return best_M, landmarks
+            return M, X.reshape(-1, 3, 1), mask
+        return M, X.reshape(-1, 3, 1)
