@@ -476,10 +476,11 @@ def main():
     recs = [torch.zeros(EXCHANGE_EVERY * S * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
     gathered = [torch.zeros(world * EXCHANGE_EVERY * S * rec_len, dtype=torch.float64, device="cuda") for _ in range(2)]
     torch.cuda.synchronize()
-    comp = torch.cuda.Stream()
+    comp = torch.cuda.Stream(priority=-1 if os.environ.get("VO_BENCH_MAIN_PRIORITY") == "high" else 0)
     comm = torch.cuda.Stream()
     os.environ["VO_DEVICE"] = str(local)
-    ctx = _native.Context(local, stream=comp.cuda_stream)
+    # (VO_BENCH_OWN_STREAM=1: the library creates the main stream itself -- under VO_STREAM_CUS on a subset of the compute units)
+    ctx = _native.Context(local, stream=None if os.environ.get("VO_BENCH_OWN_STREAM") else comp.cuda_stream)
     _native.set_default_context(ctx)      # the host classes of the bootstrap run on the same context / stream
     stream = streams[0]
     states = [bootstrap_state(st) for st in streams]
@@ -488,7 +489,13 @@ def main():
     n_boot = int((state.curr_frame.features.state == 2).sum())
     boot_info = getattr(state, "bootstrap_info", {})
     walker = Walker(pipe, N_FRAMES)
-    batch = {"fill": 0, "buf": 0}
+    # the records of EXCHANGE_EVERY frames per all-gather, double-buffered (vo.sharding.RecordExchange; covered with CPU
+    # tensors and gloo by tests/test_sharding_gloo.py)
+    xchg = sharding.RecordExchange(
+        recs, gathered, rec_len, EXCHANGE_EVERY, S,
+        post=lambda r, q, buf, off: pipe.export_state_post(r, cap, buf.data_ptr() + off * 8, seq=q),
+        join=lambda: pipe.export_state_join(comm.cuda_stream),
+        gather=lambda src, dst: (sharding.allgather_records(src, dst), None)[1])
 
     def run(n, record=False, lookahead=None):
         # Default: one frame of look-ahead, as a camera stream gives it -- frame k+1 is submitted (all of its GPU
@@ -503,14 +510,9 @@ def main():
                 # The record of every collected step is queued on the pipeline's stream (no host synchronisation);
                 # every EXCHANGE_EVERY frames the records gathered so far go to all ranks in ONE all-gather on the
                 # side stream (fewer, larger collectives: issuing one costs the host ~45 us, a third of a step).
-                for q in range(S):
-                    pipe.export_state_post(rs[q], cap, recs[batch["buf"]].data_ptr() + batch["fill"] * rec_len * 8, seq=q)
-                    batch["fill"] += 1
-                if batch["fill"] == EXCHANGE_EVERY * S or left[0] == 0:
-                    pipe.export_state_join(comm.cuda_stream)
-                    sharding.allgather_records(recs[batch["buf"]], gathered[batch["buf"]])
-                    batch["buf"] ^= 1
-                    batch["fill"] = 0
+                xchg.post(rs)
+                if left[0] == 0:
+                    xchg.flush()
             if record:
                 out.append((b, rs))
 

@@ -486,6 +486,31 @@ int vo_pipeline_get_state_seq(vo_pipeline* p, int seq, int32_t* n_out, double* k
 int vo_pipeline_get_rng_seq(vo_pipeline* p, int seq, vo_pcg64* rng);
 int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs);
 
+/* ---- shared map over RCCL ------------------------------------------------------------------
+ * The reference is one process and one thread (README.md:49); frame streams shard at sequence granularity (one
+ * process per GPU) and the ranks share {pose, landmarks} through ONE collective: an all-gather of a
+ * fixed-size record per rank, [T_cw 4x4 (16) | n (1) | n landmarks x 3, n <= cap] float64 = 17 + 3 cap doubles
+ * (what vo_pipeline_export_state_post writes).  A host that is not PyTorch (bench.py drives the same exchange through
+ * torch.distributed) makes a communicator from an id rank 0 creates and hands to the other ranks by its own means
+ * (MPI, a file, a socket):
+ *   vo_comm_unique_id   128 bytes (ncclUniqueId)
+ *   vo_comm_create      ncclCommInitRank on the context's device; collective: every rank calls it
+ *   vo_allgather_state_dev  ncclAllGather of doubles_per_rank doubles per rank, device pointers, asynchronous on
+ *                       `stream` (NULL: the context's).  One or several frames' records per call: records of k frames
+ *                       posted back to back are one message of k (17 + 3 cap) doubles.
+ *   vo_allgather_state  host arrays, one record, synchronous: pose16 (T_cw), landmarks n*3 -> all: world records.
+ * RCCL is opened at the first call (the process's own copy if it has one), not linked.                          */
+#define VO_COMM_ID_BYTES 128
+typedef struct vo_comm vo_comm;
+int vo_comm_unique_id(vo_ctx* ctx, void* id128);
+int vo_comm_create(vo_ctx* ctx, int world, int rank, const void* id128, vo_comm** out);
+void vo_comm_destroy(vo_comm* c);
+int vo_comm_world(const vo_comm* c);
+int vo_allgather_state_dev(vo_ctx* ctx, vo_comm* c, const double* d_records, size_t doubles_per_rank, double* d_all,
+                           void* stream);
+int vo_allgather_state(vo_ctx* ctx, vo_comm* c, const double* pose16, const double* landmarks, int n, int cap,
+                       double* all);
+
 #ifdef __cplusplus
 }
 #endif

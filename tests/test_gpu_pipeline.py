@@ -567,3 +567,49 @@ def test_ransac_budget_beyond_one_launch_stays_on_the_device(ctx, hyp, max_it, c
             ref["n_tracked"], ref["n_tri"], ref["n_inliers"], ref["draws"], ref["iters"], ref["best_index"])
     check_step(rs[-1], refs[-1], pipe, orc.rs.rng)
     pipe.close()
+
+
+def test_comm_world_of_one_and_host_thread_budget(ctx):
+    """vo_comm_* / vo_allgather_state (RCCL opened at run time) with the one rank a one-GPU box offers: the record comes
+    back as rank 0's row, from host arrays and from device records; and the same frames through a pipeline that keeps to
+    one host thread and never spins (VO_HOST_THREADS_BUDGET=1) give the same records."""
+    from vo import _native, sharding, synthetic
+    comm = _native.Comm(ctx, 1, 0, _native.Comm.unique_id(ctx))
+    T = np.arange(16.0).reshape(4, 4)
+    lm = np.random.default_rng(3).normal(size=(11, 3))
+    out = comm.allgather_state(T, lm, 8)
+    assert out.shape == (1, 17 + 24)
+    (T2, l2), = sharding.unpack_records(out[0], 1, 8)
+    assert np.array_equal(T2, T) and np.array_equal(l2, lm[:8])
+    H, W, N, F = 240, 320, 300, 5
+    stream = synthetic.Stream(F, H, W)
+    feats, Tw = start_state(stream, N, 1.0)
+    pairs = [(k, k + 1) for k in range(F - 1)]
+    pipe = make_pipe(ctx, stream, N, 256)
+    pipe.set_state(0, feats, Tw, Tw)
+    ref = run_all(pipe, pairs, True)
+    # device records through the communicator
+    L = sharding.record_length(N)
+    d_rec, d_all = ctx.alloc(L * 8), ctx.alloc(L * 8)
+    pipe.export_state_post(ref[-1], N, d_rec)
+    pipe.export_state_join(None)
+    comm.allgather_dev(d_rec, L, d_all)
+    ctx.sync()
+    got = ctx.download(d_all, (L,), np.float64)
+    (Tg, lg), = sharding.unpack_records(got, 1, N)
+    assert np.allclose(Tg[:3, :3], np.array(ref[-1].R_refined).reshape(3, 3)) and len(lg) == ref[-1].n_triangulated
+    ctx.free(d_rec)
+    ctx.free(d_all)
+    pipe.close()
+    comm.close()
+    os.environ["VO_HOST_THREADS_BUDGET"] = "1"
+    try:
+        pipe = make_pipe(ctx, stream, N, 256)
+        pipe.set_state(0, feats, Tw, Tw)
+        got = run_all(pipe, pairs, True)
+        pipe.close()
+    finally:
+        del os.environ["VO_HOST_THREADS_BUDGET"]
+    for a, b in zip(ref, got):
+        assert (a.n_tracked, a.n_inliers, a.draws_consumed, a.n_landmarks, list(a.t_refined)) == (
+            b.n_tracked, b.n_inliers, b.draws_consumed, b.n_landmarks, list(b.t_refined))

@@ -23,11 +23,16 @@
 // the grid's extra dimension of every kernel.  The chain is latency-bound at one sequence
 // (single-workgroup kernels, 127 us per step with the chip almost empty); S sequences cost about the same
 // wall time per step until the image-wide kernels fill the chip.
+#include <linux/futex.h>
+#include <sys/prctl.h>
+#include <sys/syscall.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <string>
 #include <thread>
 
 #include "vo_state.h"
@@ -104,11 +109,20 @@ struct vo_pipeline {
   // Detection worker: a second host thread enqueues the detection of every step (6 launches) while the caller's
   // thread enqueues pyramid, tracker and the main-stream chain (6 launches): a dozen launches and half a dozen event
   // calls per step cost one thread 70-150 us on a loaded host, more than the GPU needs for the step.
+  // Host threads: this pipeline's caller and (budget 2) the detection worker.  Neither spins for long: a wait first polls
+  // for spin_us microseconds (a one-sequence step is ~120 us, the common waits are shorter), then blocks -- the worker on a
+  // futex until a job is posted, the caller in 20 us sleeps between looks at the mapped record.  VO_HOST_THREADS_BUDGET=1:
+  // no worker (the caller enqueues the detection itself, behind the step's chain) and no spinning at all -- for many ranks
+  // on few cores (a job's CPU quota); VO_HOST_SPIN_US overrides the polling window.
   std::thread worker;
   std::atomic<unsigned> job_posted{0}, job_done{0};
+  std::atomic<int> worker_asleep{0};
   std::atomic<bool> quit{false};
+  int threads_budget = 2;
+  double spin_s = 150e-6;
   flight_t jobs[4];
   int worker_rc = 0;
+  char worker_err[256] = {0};
   double dbg_part[4] = {0, 0, 0, 0};   // VO_DEBUG_TIMING: submit split into worker wait / tracker / raws / chain
   double dbg_submit = 0, dbg_wait = 0;
   long dbg_steps = 0;
@@ -205,6 +219,37 @@ double now_s() {
   return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
 
+long futex_wait(std::atomic<unsigned>* a, unsigned expect) {
+  return syscall(SYS_futex, reinterpret_cast<unsigned*>(a), FUTEX_WAIT_PRIVATE, expect, nullptr, nullptr, 0);
+}
+
+long futex_wake(std::atomic<unsigned>* a) {
+  return syscall(SYS_futex, reinterpret_cast<unsigned*>(a), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+}
+
+// a short sleep between two looks at something another agent writes (the kernel's default timer slack would round
+// 20 us up to 70: one microsecond of slack for this thread, set once)
+void nap(long ns) {
+  static thread_local bool slack_set = false;
+  if (!slack_set) {
+    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+    slack_set = true;
+  }
+  timespec ts{0, ns};
+  nanosleep(&ts, nullptr);
+}
+
+// polls `done` for at most spin_s seconds, then between naps
+template <typename F>
+void wait_until(double spin_s, F done) {
+  const double t_end = now_s() + spin_s;
+  for (unsigned it = 0;; ++it) {
+    if (done()) return;
+    if ((it & 15) != 15 || now_s() < t_end) __builtin_ia32_pause();
+    else nap(5000);
+  }
+}
+
 uint32_t next_pow2(uint64_t v) {
   uint32_t r = 1;
   while (r < v) r <<= 1;
@@ -267,7 +312,8 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
   if (p->worker.joinable()) {          // the worker first: it enqueues on the detection stream
-    p->quit.store(true, std::memory_order_release);
+    p->quit.store(true, std::memory_order_seq_cst);
+    futex_wake(&p->job_posted);
     p->worker.join();
   }
   // every stream next: nothing may still read what is freed below
@@ -347,8 +393,44 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   // (VO_ONE_STREAM=1, measurements only: every kernel on the caller's stream, so that a kernel trace shows each
   // kernel's duration without the others running beside it)
   void* side = getenv("VO_ONE_STREAM") ? (void*)ctx->stream : nullptr;
-  if (vo_create(ctx->device, side, &p->det) != VO_OK || vo_create(ctx->device, side, &p->trk) != VO_OK)
-    rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
+  {
+    // VO_SIDE_PRIORITY=low: tracker and detection streams at the device's least priority (measurement knob)
+    const char* sp = getenv("VO_SIDE_PRIORITY");
+    const char* saved = getenv("VO_STREAM_PRIORITY");
+    std::string keep = saved ? saved : "";
+    if (sp) setenv("VO_STREAM_PRIORITY", sp, 1);
+    // Tracker and detection streams keep off the first 32 compute units when the pipeline runs one or two sequences with
+    // the detector gated: the next frame's pyramid (858 workgroups) reaches the GPU beside the hypothesis kernel's 144,
+    // and that kernel then takes 44 us instead of 23 -- its workgroups wait for a place behind the pyramid's -- unless
+    // some compute units stay out of the side streams' reach (measured: 32 of the 256 are enough, 16 are not; step period
+    // 122 -> 102 us).  With many sequences, or the detector on every frame, the side streams' kernels are the throughput and
+    // the mask costs more than it gives (16 sequences: -5 %).  VO_SIDE_CUS="lo-hi" overrides, "all" switches it off.
+    const char* sc = getenv("VO_SIDE_CUS");
+    std::string auto_mask;
+    if (!sc && p->S <= 2 && p->detect_limit >= 0.0 && !side) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount >= 128) {
+        auto_mask = "32-" + std::to_string(prop.multiProcessorCount - 1);
+        sc = auto_mask.c_str();
+      }
+    }
+    if (sc && !strcmp(sc, "all")) sc = nullptr;
+    const char* saved_c = getenv("VO_STREAM_CUS");
+    std::string keep_c = saved_c ? saved_c : "";
+    const char* dc = getenv("VO_DET_CUS");     // (the detection stream's own range; default: VO_SIDE_CUS)
+    if (dc || sc) setenv("VO_STREAM_CUS", dc ? dc : sc, 1);
+    else unsetenv("VO_STREAM_CUS");
+    if (vo_create(ctx->device, side, &p->det) != VO_OK) rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
+    if (sc) setenv("VO_STREAM_CUS", sc, 1);
+    else unsetenv("VO_STREAM_CUS");
+    if (vo_create(ctx->device, side, &p->trk) != VO_OK) rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
+    if (sp) {
+      if (saved) setenv("VO_STREAM_PRIORITY", keep.c_str(), 1);
+      else unsetenv("VO_STREAM_PRIORITY");
+    }
+    if (saved_c) setenv("VO_STREAM_CUS", keep_c.c_str(), 1);
+    else unsetenv("VO_STREAM_CUS");
+  }
   const int N = cfg->n_keypoints, Hyp = cfg->hyp;
   const size_t px = (size_t)cfg->H * cfg->W, Sz = (size_t)S;
   p->px = px;
@@ -453,7 +535,10 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
       (void)hipStreamSynchronize(q);
     }
   }
-  p->worker = std::thread(worker_main, p);
+  if (const char* e = getenv("VO_HOST_THREADS_BUDGET")) p->threads_budget = atoi(e) <= 1 ? 1 : 2;
+  if (p->threads_budget == 1) p->spin_s = 0.0;
+  if (const char* e = getenv("VO_HOST_SPIN_US")) p->spin_s = 1e-6 * (double)std::max(0, atoi(e));
+  if (p->threads_budget >= 2) p->worker = std::thread(worker_main, p);
   *out = p;
   return VO_OK;
 }
@@ -525,15 +610,21 @@ int vo_pipeline_get_rng(vo_pipeline* p, vo_pcg64* rng) { return vo_pipeline_get_
 // ---- launches; (q0, Sn): sequences q0 .. q0 + Sn - 1 (all of them, or one when a step is redone) ----
 
 // Harris + NMS of frame slot `frame` into keypoint slot `s` on the detection stream; evDet[s] when done
-static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force) {
+// (err_buf: the worker thread's private error text -- the pipeline context's buffer belongs to the caller's thread)
+static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force, char* err_buf = nullptr) {
   const vo_pipeline_config& c = p->cfg;
   p->det_flip ^= 1;
   vo_ctx* det = p->det;
   double* scores = p->d_scores[p->det_flip];
   det->nms_kp_f32 = nullptr;
   int* go = p->d_det_go + (size_t)s * p->S;
-  if (hipStreamWaitEvent(det->stream, p->evImg[frame], 0) != hipSuccess)     // the frame's upload (tracker's stream)
+  if (hipStreamWaitEvent(det->stream, p->evImg[frame], 0) != hipSuccess) {   // the frame's upload (tracker's stream)
+    if (err_buf) {
+      snprintf(err_buf, 256, "detection: hipStreamWaitEvent failed");
+      return VO_EHIP;
+    }
     return vo_set_error(p->ctx, VO_EHIP, "detection: hipStreamWaitEvent failed");
+  }
   hipLaunchKernelGGL(detect_decide_kernel, dim3(vo_cdiv(p->S, 64)), dim3(64), 0, det->stream, p->d_ctl, p->S, p->detect_limit,
                      c.n_keypoints, force ? 1 : 0, go);
   int rc = vo_check_launch(det, "detect_decide_kernel");
@@ -544,7 +635,13 @@ static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force) {
     rc = vo_nms_keypoints_batch_dev(det, scores, p->S, c.H, c.W, c.n_keypoints, c.nms_radius, p->kp(0, s), p->det_stride(),
                                     go);
   if (rc == VO_OK && hipEventRecord(p->evDet[s], det->stream) != hipSuccess) rc = VO_EHIP;
-  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "detection: %s", vo_last_error(det));
+  if (rc != VO_OK) {
+    if (err_buf) {
+      snprintf(err_buf, 256, "detection: %s", vo_last_error(det));
+      return rc;
+    }
+    return vo_set_error(p->ctx, rc, "detection: %s", vo_last_error(det));
+  }
   return VO_OK;
 }
 
@@ -725,16 +822,26 @@ static void worker_main(vo_pipeline* p) {
   (void)hipSetDevice(p->ctx->device);
   unsigned seen = 0;
   long idle = 0;
+  double idle_since = 0.0;
   for (;;) {
     if (p->job_posted.load(std::memory_order_acquire) == seen) {
       if (p->quit.load(std::memory_order_acquire)) return;
-      if (++idle < 200000) __builtin_ia32_pause();            // a step is ~100 us: stay hot between steps
-      else std::this_thread::sleep_for(std::chrono::microseconds(200));
+      // a step is ~120 us: stay hot between the steps of a running stream, then sleep until a job is posted
+      if (idle == 0) idle_since = now_s();
+      if ((++idle & 63) != 0 || now_s() - idle_since < p->spin_s) {
+        __builtin_ia32_pause();
+      } else {
+        p->worker_asleep.store(1, std::memory_order_seq_cst);
+        if (p->job_posted.load(std::memory_order_seq_cst) == seen && !p->quit.load(std::memory_order_seq_cst))
+          futex_wait(&p->job_posted, seen);
+        p->worker_asleep.store(0, std::memory_order_seq_cst);
+        idle = 0;
+      }
       continue;
     }
     idle = 0;
     const vo_pipeline::flight_t j = p->jobs[seen & 3];
-    const int rc = enqueue_detection(p, j.next_idx, j.b, false);
+    const int rc = enqueue_detection(p, j.next_idx, j.b, false, p->worker_err);
     if (rc != VO_OK) p->worker_rc = rc;
     ++seen;
     p->job_done.store(seen, std::memory_order_release);
@@ -745,15 +852,16 @@ static int worker_check(vo_pipeline* p) {
   if (p->worker_rc != VO_OK) {
     const int rc = p->worker_rc;
     p->worker_rc = VO_OK;
-    return rc;                       // (the text is in the pipeline context's error buffer)
+    return vo_set_error(p->ctx, rc, "%s", p->worker_err);
   }
   return VO_OK;
 }
 
 // waits (host) until the worker has enqueued everything it was given
 static int worker_idle(vo_pipeline* p) {
+  if (p->threads_budget < 2) return VO_OK;
   const unsigned posted = p->job_posted.load(std::memory_order_relaxed);
-  while (p->job_done.load(std::memory_order_acquire) != posted) __builtin_ia32_pause();
+  wait_until(50e-6, [&] { return p->job_done.load(std::memory_order_acquire) == posted; });
   return worker_check(p);
 }
 
@@ -770,6 +878,10 @@ int vo_pipeline_set_state_seq(vo_pipeline* p, int seq, int idx, int n, const dou
   VO_REQUIRE(ctx, (n == 0 || (kp && state && landmarks && tracks && poses)) && T_wc && T_cw && T_wc_prev && T_cw_prev,
              "pipeline_set_state: null pointer");
   VO_REQUIRE(ctx, p->n_flight == 0, "pipeline_set_state: %d submitted step(s) not collected", p->n_flight);
+  // the sequences step together through one frame slot: the states of one hand-over all belong to the same frame
+  VO_REQUIRE(ctx, !(p->S > 1 && p->have_state && !p->primed && idx != p->prev_frame),
+             "pipeline_set_state: sequence %d is handed over for frame %d, the others of this hand-over for frame %d", seq, idx,
+             p->prev_frame);
   VO_TRY(worker_idle(p));
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -982,16 +1094,33 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   f.seq = ++p->seq;
   f.rslot = (int)(p->steps_submitted & 3);
   f.k = p->steps_submitted;
-  sync_prof(p);
   // The detection of `next` (half of the step's launches, needed only by the NEXT step) goes to the worker thread;
   // this thread enqueues the pyramid, the tracker and the main-stream chain.  The tracker waits for the event behind
   // the detection of `prev`: the worker must have recorded it (it was posted a whole step ago).
-  const unsigned my = p->job_posted.load(std::memory_order_relaxed);
   double tq = now_s();
-  while ((int)(p->job_done.load(std::memory_order_acquire) - my) < 0) __builtin_ia32_pause();
-  VO_TRY(worker_check(p));
-  p->jobs[my & 3] = f;
-  p->job_posted.store(my + 1, std::memory_order_release);
+  // WHEN the detection's seven launches reach the GPU matters more than who makes them.  Arriving beside the hypothesis
+  // kernel -- the worker used to get them at the start of submit -- they cost that kernel 20 us (hypotheses -> pose 43 us
+  // against 23.5: a chain of launches that mostly return at once still keeps the command processor busy while the
+  // 144 workgroups of the hypotheses are being dispatched), 121 against 108 us per step.  So they are handed to the worker
+  // behind the step's chain -- unless the detector executes on every frame (detect_margin < 0): its kernels are then real
+  // work the next step's tracker waits for, and an early start pays (16 sequences: 19.2k against 17.4k frames/s).
+  const bool detect_early = p->detect_limit < 0.0;
+  auto post_detection = [&]() -> int {
+    const unsigned my = p->job_posted.load(std::memory_order_relaxed);
+    p->jobs[my & 3] = f;
+    p->job_posted.store(my + 1, std::memory_order_seq_cst);
+    if (p->worker_asleep.load(std::memory_order_seq_cst)) futex_wake(&p->job_posted);
+    return VO_OK;
+  };
+  if (p->threads_budget >= 2) {
+    const unsigned my = p->job_posted.load(std::memory_order_relaxed);
+    wait_until(50e-6, [&] { return (int)(p->job_done.load(std::memory_order_acquire) - my) >= 0; });
+    VO_TRY(worker_check(p));
+    sync_prof(p);                      // (the worker is idle: the detection context's profiling flags are ours to write)
+    if (detect_early) VO_TRY(post_detection());
+  } else {
+    sync_prof(p);
+  }
   double tn = now_s();
   p->dbg_part[0] += tn - tq;
   tq = tn;
@@ -1005,6 +1134,8 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   tq = tn;
   VO_TRY(enqueue_chain(p, f, false, c.debug_fault_every, 0, p->S, f.seq));
   for (int q = 0; q < p->S; ++q) p->slot_seq[(size_t)f.rslot * p->S + q] = f.seq;
+  if (p->threads_budget < 2) VO_TRY(enqueue_detection(p, f.next_idx, f.b, false));   // (needed by the NEXT step only)
+  else if (!detect_early) VO_TRY(post_detection());
   p->dbg_part[3] += now_s() - tq;
   p->flight[p->n_flight++] = f;
   ++p->steps_submitted;
@@ -1036,14 +1167,22 @@ static int wait_record(vo_pipeline* p, int rslot, int q, unsigned seq, uint64_t 
   volatile unsigned* w = p->seq_h(rslot, q);
   const double t0 = now_s();
   long it = 0;
+  bool spinning = p->spin_s > 0.0;
   for (;;) {
     if (*w == seq) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       memcpy(out, (const void*)p->res_h(rslot, q), sizeof(*out));
       if (record_fits(out, seq) && out->raw_pos >= floor) return VO_OK;
     }
-    __builtin_ia32_pause();
-    if ((++it & 0xffff) == 0 && now_s() - t0 > 5.0) {
+    // poll for spin_s, then look every 20 us (the GPU cannot wake a host thread; a blocking stream wait would also wait
+    // for the look-ahead step queued behind this one)
+    if (spinning) {
+      __builtin_ia32_pause();
+      if ((++it & 31) == 0 && now_s() - t0 > p->spin_s) spinning = false;
+      continue;
+    }
+    nap(20000);
+    if ((++it & 0xff) == 0 && now_s() - t0 > 5.0) {
       VO_HIP_TRY(p->ctx, hipStreamSynchronize(p->ctx->stream));
       memcpy(out, (const void*)p->res_h(rslot, q), sizeof(*out));
       if (*w == seq && record_fits(out, seq)) return VO_OK;
@@ -1303,6 +1442,9 @@ int vo_pipeline_bookkeeping(vo_pipeline* p, int phases, const double* new_kp, in
   if (phases & 1) {
     VO_REQUIRE(ctx, new_kp && pairs && T_wc && T_cw && n2 >= 0 && n2 <= p->cap && M >= 0 && M <= n2,
                "pipeline_bookkeeping: bad arguments");
+    for (int k = 0; k < M; ++k)
+      VO_REQUIRE(ctx, pairs[2 * k] >= 0 && pairs[2 * k] < p->cap && pairs[2 * k + 1] >= 0 && pairs[2 * k + 1] < n2,
+                 "pipeline_bookkeeping: pair %d = (%d, %d) is out of range", k, (int)pairs[2 * k], (int)pairs[2 * k + 1]);
     VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_newkp, new_kp, (size_t)n2 * 16, hipMemcpyHostToDevice, st));
     VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_pairs, pairs, (size_t)M * 8, hipMemcpyHostToDevice, st));
     VO_TRY(vo_state_regroup_pairs(ctx, p->d_ctl, p->F[p->cur], p->F[1 - p->cur], p->d_pairs, M, p->d_newkp, n2, p->cap));

@@ -65,7 +65,25 @@ int vo_create(int device, void* stream, vo_ctx** out) {
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
   } else {
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    // VO_STREAM_PRIORITY (read per creation; the pipeline sets it around its side streams): "low" / "high" ask the runtime
+    // for the least / greatest priority the device offers -- work of a low-priority queue is dispatched behind that of the
+    // others when both have workgroups waiting
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char* pr = getenv("VO_STREAM_PRIORITY");
+    hipError_t e;
+    // VO_STREAM_CUS="lo-hi" (read per creation, as above): the stream's kernels run on compute units lo..hi only
+    const char* cus = getenv("VO_STREAM_CUS");
+    int lo = 0, hi = -1;
+    if (cus && sscanf(cus, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi >= lo && hi < 1024) {
+      uint32_t mask[32] = {0};
+      for (int k = lo; k <= hi; ++k) mask[k >> 5] |= 1u << (k & 31);
+      e = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)((hi >> 5) + 1), mask);
+    } else if (pr && (pr[0] == 'l' || pr[0] == 'h'))
+      e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest);
+    else
+      e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
       delete c;
       return VO_EHIP;
     }

@@ -138,6 +138,12 @@ _SIGS = {
     "vo_fundamental_fit": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp]),
     "vo_essential_decompose": (_i, [_vp, _vp, _vp]),
     "vo_relative_pose": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vo_comm_unique_id": (_i, [_vp, _vp]),
+    "vo_comm_create": (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "vo_comm_destroy": (None, [_vp]),
+    "vo_comm_world": (_i, [_vp]),
+    "vo_allgather_state_dev": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "vo_allgather_state": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "vo_rng_choice": (_i, [_vp, _i, _i, _i, _vp]),
     "vo_ransac_num_iterations": (C.c_int64, [_d, _d, _i]),
     "vo_ransac_replay": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -551,6 +557,48 @@ class Context:
     def patch_descriptors_dev(self, d_img, H, W, d_kp, N, r, d_desc):
         self._chk(self._lib.vo_patch_descriptors_dev(self._h, C.c_void_p(d_img), H, W, C.c_void_p(d_kp), int(N),
                                                      int(r), C.c_void_p(d_desc)))
+
+
+class Comm:
+    """RCCL communicator of the shared-map exchange for hosts without torch.distributed (vo_comm_*): rank 0 makes the
+    id (`Comm.unique_id(ctx)`, 128 bytes) and hands it to the other ranks by its own means; every rank then constructs
+    Comm(ctx, world, rank, id)."""
+
+    @staticmethod
+    def unique_id(ctx):
+        buf = C.create_string_buffer(128)
+        ctx._chk(ctx._lib.vo_comm_unique_id(ctx._h, buf))
+        return buf.raw
+
+    def __init__(self, ctx, world, rank, uid):
+        assert len(uid) == 128
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
+        h = C.c_void_p()
+        ctx._chk(ctx._lib.vo_comm_create(ctx._h, self.world, self.rank, C.c_char_p(uid), C.byref(h)))
+        self._h = h
+
+    def allgather_state(self, T_cw, landmarks, cap):
+        """One record per rank, host arrays, synchronous: (world, 17 + 3 cap) float64."""
+        T = _c(np.asarray(T_cw).reshape(16), np.float64)
+        lm = _c(np.asarray(landmarks).reshape(-1, 3), np.float64)
+        out = np.empty((self.world, 17 + 3 * int(cap)), np.float64)
+        self.ctx._chk(self.ctx._lib.vo_allgather_state(self.ctx._h, self._h, _ptr(T), _ptr(lm), lm.shape[0], int(cap), _ptr(out)))
+        return out
+
+    def allgather_dev(self, d_records, doubles_per_rank, d_all, stream=None):
+        self.ctx._chk(self.ctx._lib.vo_allgather_state_dev(self.ctx._h, self._h, C.c_void_p(d_records), int(doubles_per_rank),
+                                                           C.c_void_p(d_all), C.c_void_p(stream or 0)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.vo_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def rng_choice(pcg, pop, s, count):

@@ -66,27 +66,36 @@ class RANSAC:
         ``batch_fn(samples (B, s) int32) -> (valid (B,), counts (B,), fetch)`` evaluates B
         hypotheses at once and ``fetch(b) -> (model, inlier mask)`` returns hypothesis b.
         Returns (model, mask, iterations counted)."""
+        import ctypes as C
         from vo import _native
+        lib = _native.load()
         self.population = np.arange(n_population)
-        best_n, best, n = -1, None, 0
-        while n < self.n_iterations:
+        # the sequential accept / adapt rule over the batch's (valid, count) is vo_ransac_replay (csrc/ransac_host.hip: the
+        # loop of ransac.py:90-121 with the reference's own formula for the bound) -- a Python loop over 2000 hypotheses per
+        # batch cost the two-view bootstrap more than its kernels
+        st = _native.RansacState(float(self.outlier_ratio), float(self.confidence),
+                                 -1 if self.max_iterations == np.inf else int(self.max_iterations),
+                                 int(min(self.n_iterations, 2 ** 62)), int(self.s), 1 if self.adaptive else 0)
+        n_done, best_count, best_idx = C.c_int64(0), C.c_int32(-1), C.c_int32(-1)
+        consumed, finished = C.c_int(0), C.c_int(0)
+        best, batches = None, 0
+        while not finished.value:
             spec = _native.Pcg64.from_generator(self.rng)             # speculative copy of the generator
             samples = _native.rng_choice(spec, n_population, self.s, batch_size)
             valid, counts, fetch = batch_fn(samples)
-            consumed, winner = 0, -1
-            for b in range(batch_size):
-                if n >= self.n_iterations:
-                    break
-                consumed += 1
-                if not valid[b]:
-                    continue
-                if counts[b] > best_n:
-                    best_n, winner = int(counts[b]), b
-                    self._accept(best_n)
-                n += 1
-            if winner >= 0:
-                best = fetch(winner)
+            valid = np.ascontiguousarray(valid, np.uint8)
+            counts = np.ascontiguousarray(counts, np.int32)
+            before = best_idx.value
+            rc = lib.vo_ransac_replay(C.byref(st), valid.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                      int(batch_size), int(n_population), C.byref(n_done), C.byref(best_count),
+                                      C.byref(best_idx), int(batches * batch_size), C.byref(consumed), C.byref(finished))
+            if rc != 0:
+                raise _native.VoError(rc, "vo_ransac_replay")
+            if best_idx.value != before:
+                best = fetch(best_idx.value - batches * batch_size)
             real = _native.Pcg64.from_generator(self.rng)             # advance by exactly what was consumed
-            _native.rng_choice(real, n_population, self.s, consumed)
+            _native.rng_choice(real, n_population, self.s, consumed.value)
             real.to_generator(self.rng)
-        return best[0], best[1], n
+            batches += 1
+        self.outlier_ratio, self.n_iterations = float(st.outlier_ratio), int(st.n_iterations)
+        return best[0], best[1], int(n_done.value)

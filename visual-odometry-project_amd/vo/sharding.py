@@ -43,3 +43,67 @@ def allgather_records(record, out=None):
         out = torch.empty(world * record.numel(), dtype=record.dtype, device=record.device)
     dist.all_gather_into_tensor(out, record)
     return out
+
+
+class RecordExchange:
+    """The exchange of the per-frame records, double-buffered: the records of `every` frames x `sequences` sequences are
+    written back to back into batch buffer b (`post`); when the buffer is full -- or at `flush` -- the producer and the
+    collective are ordered (`join`), ONE all-gather ships the buffer to every rank (`gather`) and the next records go to
+    the other buffer.  `every` = 1 is SURVEY.md 8e's one collective per frame; larger values send fewer, larger messages
+    (issuing a collective costs the host about a third of a one-sequence step).
+
+    A buffer is written again only after the all-gather that reads it has been ordered behind: on the GPU through
+    stream order (`join` = vo_pipeline_export_state_join: later records are written after everything the collective's
+    stream held), with CPU tensors by waiting for the gather's work handle.  The device and the CPU form are this one
+    class; the callables differ:
+        post(result, q, buffer, offset)   write sequence q's record of `result` at buffer[offset : offset + rec_len]
+        join()                            order producer and collective both ways (None: nothing to do)
+        gather(src, dst)                  all-gather src into dst; may return a handle with .wait()
+        on_gathered(dst, n_records)       optional: called once the batch in dst is complete on this rank
+    """
+
+    def __init__(self, buffers, gathered, rec_len, every, sequences, post, gather, join=None, on_gathered=None):
+        assert len(buffers) == 2 and len(gathered) == 2
+        self.buffers, self.gathered = buffers, gathered
+        self.rec_len, self.every, self.S = int(rec_len), int(every), int(sequences)
+        self.post_fn, self.gather_fn, self.join_fn, self.on_gathered = post, gather, join, on_gathered
+        self.fill, self.buf = 0, 0
+        self.pending = [None, None]          # per buffer: (handle or None, records in flight)
+        self.collectives = 0
+
+    def _settle(self, b):
+        """The collective that last read buffer b (and wrote gathered[b]) is complete on the host's side."""
+        if self.pending[b] is not None:
+            handle, n = self.pending[b]
+            if handle is not None:
+                handle.wait()
+            self.pending[b] = None
+            if self.on_gathered is not None:
+                self.on_gathered(self.gathered[b], n)
+
+    def post(self, results):
+        """The records of one collected frame (one StepResult per sequence)."""
+        if self.fill == 0:
+            self._settle(self.buf)           # (the gather that read this buffer two batches ago)
+        for q in range(self.S):
+            self.post_fn(results[q], q, self.buffers[self.buf], self.fill * self.rec_len)
+            self.fill += 1
+        if self.fill == self.every * self.S:
+            self.flush()
+
+    def flush(self):
+        """Ships what has been posted so far (a partial batch travels as a whole buffer: fixed message size)."""
+        if self.fill == 0:
+            return
+        if self.join_fn is not None:
+            self.join_fn()
+        handle = self.gather_fn(self.buffers[self.buf], self.gathered[self.buf])
+        self.pending[self.buf] = (handle, self.fill)
+        self.collectives += 1
+        self.buf ^= 1
+        self.fill = 0
+
+    def finish(self):
+        self.flush()
+        for b in (self.buf, self.buf ^ 1):
+            self._settle(b)
