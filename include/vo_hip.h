@@ -395,11 +395,17 @@ typedef struct vo_step_result {
   uint64_t ts[8];               /* device clock (100 MHz ticks) at the start of: tracker, regroup, hypotheses, pose,
                                    landmark stage, at the end of the step (the record's last write); [6], [7]:
                                    inside the pose kernel, RANSAC replay done / refinement done               */
-  uint32_t seq_head, seq_tail;  /* internal; the last two words.  In the mapped record: seq_tail = the step's sequence
-                                   number, seq_head = that number XOR every other 32-bit word of the record, so that a
-                                   copy taken while some of its lines were still on their way is recognised; in what
-                                   the collect calls return both equal the number                                  */
+  uint32_t seq_head, seq_tail;  /* internal; the last two words.  In the mapped record: seq_head = the step's sequence
+                                   number XOR every other 32-bit word of the record, seq_tail = the number + a
+                                   position-weighted sum of those words, so that a copy taken while some of its lines
+                                   were still on their way is recognised (vo_record_check); in what the collect calls
+                                   return both equal the number                                                    */
 } vo_step_result;
+/* The self-check of a result record in mapped host memory (the GPU's stores to host memory arrive line by line, in no
+ * particular order): _seal closes a record for step `seq` the way the device does, _check returns 1 when the copy is one
+ * whole record of that step.  Host arithmetic only.                                                              */
+void vo_record_seal(vo_step_result* rec, unsigned seq);
+int vo_record_check(const vo_step_result* rec, unsigned seq);
 int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out);
 void vo_pipeline_destroy(vo_pipeline* p);
 /* frame store: copies a host image into slot idx of the frame store.  The caller's buffer is free on return (it is

@@ -166,3 +166,50 @@ def test_no_cpu_fallback_without_gpu():
         return
     c.close()
     pytest.skip("GPU present")
+
+
+def test_result_record_check_rejects_spliced_records():
+    """The GPU writes a step's result record to mapped host memory, where its seven 64-byte lines arrive in no particular
+    order: a copy may hold some lines of the slot's previous record.  vo_record_check (the test the pipeline's collect
+    applies to every copy, 64 bits of check) must accept whole records only -- here every possible splice of an old and a
+    new record at line granularity, deterministic."""
+    import ctypes as C
+    from vo import _native
+    lib = _native.load()
+    rng = np.random.default_rng(5)
+
+    def record(seq, seed):
+        r = _native.StepResult()
+        raw = np.random.default_rng(seed).integers(0, 256, size=C.sizeof(r), dtype=np.uint8)
+        C.memmove(C.byref(r), raw.ctypes.data, C.sizeof(r))
+        lib.vo_record_seal(C.byref(r), seq)
+        return r
+
+    size = C.sizeof(_native.StepResult)
+    lines = (size + 63) // 64
+    old, new = record(41, 1), record(45, 2)
+    assert lib.vo_record_check(C.byref(new), 45) == 1 and lib.vo_record_check(C.byref(old), 41) == 1
+    assert lib.vo_record_check(C.byref(new), 41) == 0 and lib.vo_record_check(C.byref(old), 45) == 0
+    ob, nb = bytes(old), bytes(new)
+    for mask in range(1, 2 ** lines - 1):                      # every mix with at least one old and one new line
+        mixed = b"".join((nb if (mask >> k) & 1 else ob)[64 * k:64 * (k + 1)] for k in range(lines))
+        buf = C.create_string_buffer(mixed, size)
+        assert lib.vo_record_check(buf, 45) == 0 and lib.vo_record_check(buf, 41) == 0, mask
+    # records that differ in one field only (the common case: consecutive steps of a quiet stream)
+    a = record(7, 3)
+    b = _native.StepResult.from_buffer_copy(bytes(a))
+    b.n_inliers += 1
+    lib.vo_record_seal(C.byref(b), 11)
+    ab, bb = bytes(a), bytes(b)
+    for mask in range(1, 2 ** lines - 1):
+        mixed = b"".join((bb if (mask >> k) & 1 else ab)[64 * k:64 * (k + 1)] for k in range(lines))
+        if mixed in (ab, bb):
+            continue
+        buf = C.create_string_buffer(mixed, size)
+        assert lib.vo_record_check(buf, 11) == 0 and lib.vo_record_check(buf, 7) == 0, mask
+    # flipped bits anywhere in the data words are caught
+    for _ in range(200):
+        raw = bytearray(nb)
+        k = int(rng.integers(0, size - 8))
+        raw[k] ^= 1 << int(rng.integers(0, 8))
+        assert lib.vo_record_check(C.create_string_buffer(bytes(raw), size), 45) == 0

@@ -835,9 +835,9 @@ __device__ __forceinline__ void stage16(const uint8_t* __restrict__ img, int pit
 }
 
 template <int WIN, int LPK>
-__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, vo_klt_batch B, int max_iter,
-                                                         double eps2, float min_eig_thr, float* __restrict__ next_xy,
-                                                         uint8_t* __restrict__ status, float* __restrict__ err) {
+__device__ __forceinline__ void klt_track16_body(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, vo_klt_batch B, int max_iter,
+                                                 double eps2, float min_eig_thr, float* __restrict__ next_xy,
+                                                 uint8_t* __restrict__ status, float* __restrict__ err) {
   typedef klt_rows<WIN> G;
   constexpr int win = WIN, ww = WIN * WIN, RS = G::RS, n1 = G::n1, n3 = G::n3, K16_PITCH = G::PITCH;
   constexpr int KPW = 64 / LPK;                        // keypoints per wave
@@ -1101,6 +1101,28 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
     next_xy[2 * i + 1] = ny;
     status[i] = ok ? 1 : 0;
     err[i] = e_out;
+  }
+}
+
+// The kernel: (optionally) a device-side gate in front of the body -- the previous flight's regroup has published the
+// features this launch tracks -- and an arrival behind it, so that this flight's regroup can poll for the tracker's end
+// instead of waiting for a stream event.
+template <int WIN, int LPK>
+__global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* __restrict__ prev_xy, int N, const int* __restrict__ d_n, vo_klt_source src, vo_klt_batch B, int max_iter,
+                                                         double eps2, float min_eig_thr, float* __restrict__ next_xy,
+                                                         uint8_t* __restrict__ status, float* __restrict__ err) {
+  const size_t coff = (size_t)blockIdx.y * B.ctl;
+  if (src.gate_wait && src.gate_want) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(src.gate_wait) + coff);
+    if (!vo_gate_wait(w, src.gate_want) && threadIdx.x == 0 && src.gate_fault)
+      atomicOr(reinterpret_cast<int*>(reinterpret_cast<char*>(src.gate_fault) + coff), (int)VO_FAULT_GATE_BIT);
+  }
+  klt_track16_body<WIN, LPK>(P, prev_xy, N, d_n, src, B, max_iter, eps2, min_eig_thr, next_xy, status, err);
+  if (src.gate_set) {
+    __threadfence();
+    if (threadIdx.x == 0)
+      vo_gate_arrive(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(src.gate_cnt) + coff), gridDim.x,
+                     reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(src.gate_set) + coff), src.gate_set_to);
   }
 }
 

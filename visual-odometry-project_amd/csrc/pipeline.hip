@@ -36,6 +36,7 @@
 #include <thread>
 
 #include "vo_state.h"
+#include "state_device.h"
 
 #pragma clang fp contract(off)
 
@@ -120,6 +121,11 @@ struct vo_pipeline {
   std::atomic<bool> quit{false};
   int threads_budget = 2;
   double spin_s = 150e-6;
+  // Device-side gates instead of stream events between the tracker's stream and the main stream (vo_seq_ctl): used for
+  // the launches of vo_pipeline_submit when the side streams keep off some compute units (one or two sequences), so
+  // that a polling kernel can never keep the kernel it waits for from running.  After anything was enqueued again for
+  // one sequence (host path, a continuing RANSAC loop, a rewind) the next submit also waits for the events.
+  bool gates = false, gate_resync = false;
   flight_t jobs[4];
   int worker_rc = 0;
   char worker_err[256] = {0};
@@ -177,6 +183,10 @@ __global__ __launch_bounds__(64) void ctl_rewind_kernel(vo_seq_ctl* __restrict__
   c.outlier_ratio = ctl[q].outlier_ratio;
   c.raw_pos = ctl[q].raw_pos;
   c.step = ctl[q].step;
+  c.gate_regroup = ctl[q].gate_regroup;
+  c.gate_regroup_cnt = ctl[q].gate_regroup_cnt;
+  c.gate_klt = ctl[q].gate_klt;
+  c.gate_klt_cnt = ctl[q].gate_klt_cnt;
   ctl[q] = c;
 }
 
@@ -415,6 +425,16 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
       }
     }
     if (sc && !strcmp(sc, "all")) sc = nullptr;
+    {
+      const int w = cfg->klt_win;
+      const char* g = getenv("VO_GATES");
+      // Off unless VO_GATES=1.  Measured: the two event waits they replace cost 17-19 us each, but every polling
+      // workgroup needs an acquire at agent scope when its gate opens and a release before it arrives, and on this part
+      // those are an invalidate / a write-back of the XCD's L2: with ~1000 tracker workgroups per frame the hypothesis and
+      // pose kernels running beside them lose their cached population over and over (hypotheses -> pose 23 -> 40 us,
+      // pose 34 -> 45, step 103 -> 133 us).  The gates would need the gated data to bypass L2 altogether.
+      p->gates = sc != nullptr && p->S <= 2 && !side && (w == 15 || w == 17 || w == 21) && g && g[0] == '1';
+    }
     const char* saved_c = getenv("VO_STREAM_CUS");
     std::string keep_c = saved_c ? saved_c : "";
     const char* dc = getenv("VO_DET_CUS");     // (the detection stream's own range; default: VO_SIDE_CUS)
@@ -712,13 +732,14 @@ static vo_pose_job make_pose_job(vo_pipeline* p, const vo_feat& B, int do_replay
 
 // tracker of one step, on its own stream: it needs the previous step's regroup (the features' positions) and this
 // frame's pyramid, nothing of the previous step's pose estimation, which runs beside it on the main stream
-static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool with_pyramid, int q0, int Sn) {
+static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool with_pyramid, int q0, int Sn,
+                           bool gated = false) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
   const vo_feat A = vo_feat_seq(p->F[f.fcur], (size_t)q0);
   hipStream_t ts = p->trk->stream;
   if (with_pyramid) VO_TRY(enqueue_pyramid(p, f.next_idx, f.b));
-  if (f.k > 0 && hipEventQuery(p->evRegroup[(f.k - 1) & 1]) != hipSuccess)
+  if ((!gated || p->gate_resync) && f.k > 0 && hipEventQuery(p->evRegroup[(f.k - 1) & 1]) != hipSuccess)
     VO_HIP_TRY(ctx, hipStreamWaitEvent(ts, p->evRegroup[(f.k - 1) & 1], 0));
   if (hipEventQuery(p->evDet[f.a]) != hipSuccess) VO_HIP_TRY(ctx, hipStreamWaitEvent(ts, p->evDet[f.a], 0));
   vo_seq_ctl* ctl = p->d_ctl + q0;
@@ -730,6 +751,14 @@ static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool 
   src.n_det = c.n_keypoints;
   src.ts = &ctl->ts[0];
   src.det_go = p->d_det_go + (size_t)f.a * p->S + q0;
+  if (gated) {
+    src.gate_wait = &ctl->gate_regroup;
+    src.gate_want = (uint32_t)f.k;                    // published by the regroup of flight k - 1 (or a state hand-over)
+    src.gate_set = &ctl->gate_klt;
+    src.gate_cnt = &ctl->gate_klt_cnt;
+    src.gate_set_to = (uint32_t)f.k + 1u;
+    src.gate_fault = &ctl->fault;
+  }
   vo_klt_batch kb;
   kb.S = Sn;
   kb.pyr = p->pyr_stride();
@@ -754,14 +783,16 @@ static int enqueue_pose_half(vo_pipeline* p, const vo_pipeline::flight_t& f, int
 // the main-stream chain of one step (the tracker's event must have been recorded);
 // first_half_only: stop behind the regroup (recover_step continues on the host)
 static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool first_half_only, int debug_fault_every,
-                         int q0, int Sn, unsigned seq) {
+                         int q0, int Sn, unsigned seq, bool gated = false) {
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
   const size_t q = (size_t)q0;
   const vo_feat A = vo_feat_seq(p->F[f.fcur], q), B = vo_feat_seq(p->F[1 - f.fcur], q);
   vo_seq_ctl* ctl = p->d_ctl + q0;
-  VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evKlt[f.k & 1], 0));
+  if (!gated) VO_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, p->evKlt[f.k & 1], 0));
   vo_append ap;
+  ap.gate_klt_want = gated ? (uint32_t)f.k + 1u : 0u;
+  ap.gate_regroup_set = gated ? (uint32_t)f.k + 1u : 0u;
   ap.det_kp = p->kp(q0, f.a);
   ap.det_stride = p->det_stride();
   ap.n_det = c.n_keypoints;
@@ -908,12 +939,15 @@ int vo_pipeline_set_state_seq(vo_pipeline* p, int seq, int idx, int n, const dou
   const uint64_t raw_pos = h.raw_pos;
   const int64_t n_it = h.n_iterations;
   const double orat = h.outlier_ratio;
+  const uint32_t gate_klt = h.gate_klt;
   const bool keep_ransac = p->seq_state[seq] != 0;
   memset(&h, 0, sizeof(h));
   h.n = n;
   h.n2 = n;
   h.num_features = num_features;
   h.raw_pos = raw_pos;
+  h.gate_regroup = (uint32_t)p->steps_submitted;      // the features the next flight's tracker waits for are these
+  h.gate_klt = gate_klt;
   if (keep_ransac) {
     h.n_iterations = n_it;
     h.outlier_ratio = orat;
@@ -997,6 +1031,7 @@ extern "C" int vo_pipeline_rewind(vo_pipeline* p) {
   else VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   p->slot = 0;
   p->prev_frame = p->ckpt_frame;
+  p->gate_resync = true;             // (the next tracker waits for that event, not only for its gate)
   return prime(p, false);            // pyramid + detector of that frame, queued on their streams
 }
 
@@ -1124,7 +1159,7 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   double tn = now_s();
   p->dbg_part[0] += tn - tq;
   tq = tn;
-  VO_TRY(enqueue_tracker(p, f, true, 0, p->S));
+  VO_TRY(enqueue_tracker(p, f, true, 0, p->S, p->gates));
   tn = now_s();
   p->dbg_part[1] += tn - tq;
   tq = tn;
@@ -1132,7 +1167,8 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   tn = now_s();
   p->dbg_part[2] += tn - tq;
   tq = tn;
-  VO_TRY(enqueue_chain(p, f, false, c.debug_fault_every, 0, p->S, f.seq));
+  VO_TRY(enqueue_chain(p, f, false, c.debug_fault_every, 0, p->S, f.seq, p->gates));
+  p->gate_resync = false;
   for (int q = 0; q < p->S; ++q) p->slot_seq[(size_t)f.rslot * p->S + q] = f.seq;
   if (p->threads_budget < 2) VO_TRY(enqueue_detection(p, f.next_idx, f.b, false));   // (needed by the NEXT step only)
   else if (!detect_early) VO_TRY(post_detection());
@@ -1156,11 +1192,35 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
 // state_device.h: seq_tail = the step's number, seq_head = the number XOR every other dword of the record
 static bool record_fits(vo_step_result* out, unsigned seq) {
   const unsigned* dw = reinterpret_cast<const unsigned*>(out);
-  unsigned x = 0u;
-  for (size_t k = 0; k + 2 < sizeof(*out) / 4; ++k) x ^= dw[k];
-  if (out->seq_tail != seq || out->seq_head != (seq ^ x)) return false;
+  unsigned x = 0u, y = 0u;
+  for (size_t k = 0; k + 2 < sizeof(*out) / 4; ++k) {
+    x ^= dw[k];
+    y += vo_state_dev::record_mix(dw[k], (int)k);
+  }
+  if (out->seq_tail != seq + y || out->seq_head != (seq ^ x)) return false;
   out->seq_head = seq;           // (what the caller sees: both equal the step's number)
+  out->seq_tail = seq;
   return true;
+}
+
+// The record's check as the C ABI exposes it (tests; a host that reads the mapped records itself): _seal writes the two
+// closing words the way the device does, _check says whether a copy is one whole record of step `seq`.
+extern "C" void vo_record_seal(vo_step_result* rec, unsigned seq) {
+  if (!rec) return;
+  const unsigned* dw = reinterpret_cast<const unsigned*>(rec);
+  unsigned x = 0u, y = 0u;
+  for (size_t k = 0; k + 2 < sizeof(*rec) / 4; ++k) {
+    x ^= dw[k];
+    y += vo_state_dev::record_mix(dw[k], (int)k);
+  }
+  rec->seq_head = seq ^ x;
+  rec->seq_tail = seq + y;
+}
+
+extern "C" int vo_record_check(const vo_step_result* rec, unsigned seq) {
+  if (!rec) return 0;
+  vo_step_result copy = *rec;
+  return record_fits(&copy, seq) ? 1 : 0;
 }
 
 static int wait_record(vo_pipeline* p, int rslot, int q, unsigned seq, uint64_t floor, vo_step_result* out) {
@@ -1382,6 +1442,7 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
       return rc;
     }
     if (out->fault || was_open) {
+      p->gate_resync = true;             // (what is enqueued again below is ordered by events, and so is the next submit)
       rc = out->fault ? recover_step(p, f, q, out) : VO_OK;
       // steps submitted behind it saw the fault and did nothing for this sequence: their main-stream chains are
       // enqueued again for it alone (pyramids and detections are done and still in place)

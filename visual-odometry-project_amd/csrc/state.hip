@@ -191,37 +191,12 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// klt.py:191-280 behind the tracker + Matches.__init__ (matches.py:26-212) for identity matches, many workgroups,
-// none of which waits for another: every workgroup of 256 items counts the group sizes of ALL items itself (a few
-// KB of flags, coalesced, from L2) and the sizes before its own first item, so an item's place in the new frame
-//     base(group) + #(same group before the workgroup) + #(same group before it inside the workgroup)
-// needs no communication.  The re-detect branch (klt.py:207-230 -> update_features, klt.py:117-189) is not a
-// copy: when fewer than frac * _num_features features are left, items n .. n + n_det - 1 ARE the detector's
-// keypoints of the old frame (state 0, landmark NaN, track start = the keypoint, start pose np.eye(4)) -- the
-// tracker kernel read its points the same way (vo_klt_source).
-__global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat A, vo_feat B,
-                                                                const float* __restrict__ next_xy,
-                                                                const uint8_t* __restrict__ status,
-                                                                const float* __restrict__ err, float err_thr,
-                                                                vo_append ap, int cap) {
-  __shared__ unsigned long long s_red[2][4];
-  __shared__ int s_wcnt[3][4];
+// (the body of state_regroup_klt_kernel: it returns early on several paths, the kernel's gates sit around it)
+__device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, vo_feat A, vo_feat B,
+                                                 const float* __restrict__ next_xy, const uint8_t* __restrict__ status,
+                                                 const float* __restrict__ err, float err_thr, vo_append ap, int cap,
+                                                 unsigned long long (&s_red)[2][4], int (&s_wcnt)[3][4]) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (blockIdx.y != 0) {               // several sequences per launch: grid.y = sequence
-    const size_t q = blockIdx.y;
-    ctl += q;
-    A = vo_feat_seq(A, q);
-    B = vo_feat_seq(B, q);
-    next_xy += q * (size_t)cap * 2;
-    status += q * (size_t)cap;
-    err += q * (size_t)cap;
-    ap.det_kp += q * ap.det_stride;
-  }
-  if (blockIdx.x == 0 && tid == 0) {
-    ctl->ts[1] = wall_clock64();
-    ctl->ts[6] = ctl->ts[0];          // this step's tracker start (the next step's tracker overwrites ts[0] meanwhile)
-  }
   const int entry_fault = ctl->fault;
   int fault = entry_fault;
   const int n = ctl->n;
@@ -328,6 +303,51 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
     ctl->few = few;                    // (not into ctl->fault: this launch's other workgroups read that word on entry)
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// klt.py:191-280 behind the tracker + Matches.__init__ (matches.py:26-212) for identity matches, many workgroups,
+// none of which waits for another: every workgroup of 256 items counts the group sizes of ALL items itself (a few
+// KB of flags, coalesced, from L2) and the sizes before its own first item, so an item's place in the new frame
+//     base(group) + #(same group before the workgroup) + #(same group before it inside the workgroup)
+// needs no communication.  The re-detect branch (klt.py:207-230 -> update_features, klt.py:117-189) is not a
+// copy: when fewer than frac * _num_features features are left, items n .. n + n_det - 1 ARE the detector's
+// keypoints of the old frame (state 0, landmark NaN, track start = the keypoint, start pose np.eye(4)) -- the
+// tracker kernel read its points the same way (vo_klt_source).
+__global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat A, vo_feat B,
+                                                                const float* __restrict__ next_xy,
+                                                                const uint8_t* __restrict__ status,
+                                                                const float* __restrict__ err, float err_thr,
+                                                                vo_append ap, int cap) {
+  __shared__ unsigned long long s_red[2][4];
+  __shared__ int s_wcnt[3][4];
+  const int tid = threadIdx.x;
+  if (blockIdx.y != 0) {               // several sequences per launch: grid.y = sequence
+    const size_t q = blockIdx.y;
+    ctl += q;
+    A = vo_feat_seq(A, q);
+    B = vo_feat_seq(B, q);
+    next_xy += q * (size_t)cap * 2;
+    status += q * (size_t)cap;
+    err += q * (size_t)cap;
+    ap.det_kp += q * ap.det_stride;
+  }
+  // device-side gate: this flight's tracker has published its end (instead of a stream event; vo_seq_ctl)
+  if (ap.gate_klt_want) {
+    if (!vo_gate_wait(&ctl->gate_klt, ap.gate_klt_want) && tid == 0) atomicOr(&ctl->fault, (int)VO_FAULT_GATE);
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    ctl->ts[1] = wall_clock64();
+    ctl->ts[6] = ctl->ts[0];          // this step's tracker start (the next step's tracker overwrites ts[0] meanwhile)
+  }
+  regroup_klt_body(ctl, A, B, next_xy, status, err, err_thr, ap, cap, s_red, s_wcnt);
+  if (ap.gate_regroup_set) {          // every workgroup arrives, whatever it did: the last one opens the tracker's gate
+    __syncthreads();
+    __threadfence();
+    if (tid == 0) vo_gate_arrive(&ctl->gate_regroup_cnt, gridDim.x, &ctl->gate_regroup, ap.gate_regroup_set);
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // main.py:261-268 as a kernel of its own (vo_pipeline_bookkeeping and the host recovery path; inside the frame loop

@@ -258,11 +258,19 @@ __device__ __forceinline__ void commit_pose(vo_seq_ctl* __restrict__ ctl, int ti
 // made, fences notwithstanding (the record's 64-byte lines travel as separate writes: a record whose last line had
 // arrived and whose first lines had not was seen about once in 10^4 steps, tests/pipeline_fuzz.py), so a record proves
 // itself: all of it is written every time (staged in LDS first), seq_head = the step's number XOR all other dwords,
-// seq_tail = the number.  The host takes a copy whose sum fits (pipeline.hip:wait_record) and copies again otherwise.
+// seq_tail = the number + a position-weighted sum of them (record_mix): 64 bits of check.  The host takes a copy whose
+// sums fit (pipeline.hip:wait_record, vo_record_check) and copies again otherwise.
 constexpr int REC_DW = (int)(sizeof(vo_step_result) / 4);   // seq_head and seq_tail are the last two dwords
 static_assert(sizeof(vo_step_result) % 4 == 0 && REC_DW <= 128 + 2, "record: two dwords per lane of one wave");
 static_assert(offsetof(vo_step_result, seq_head) == sizeof(vo_step_result) - 8 &&
               offsetof(vo_step_result, seq_tail) == sizeof(vo_step_result) - 4, "record: the closing words come last");
+
+// The record's second check word: the step's number plus the sum over the data dwords of (dword + golden * (k + 1)) *
+// (2k + 1), mod 2^32 -- position-dependent, so that lines of two records spliced together would have to collide in this
+// sum AND in the XOR: one in 2^64.
+__host__ __device__ inline unsigned record_mix(unsigned v, int k) {
+  return (v + 0x9e3779b9u * (unsigned)(k + 1)) * (unsigned)(2 * k + 1);
+}
 
 // The record of a step that raised a fault: what the host needs to redo it.  One work item.
 __device__ __forceinline__ void write_fault_record(const vo_seq_ctl* __restrict__ ctl, int fault, vo_step_result* __restrict__ res,
@@ -271,7 +279,7 @@ __device__ __forceinline__ void write_fault_record(const vo_seq_ctl* __restrict_
   //  launch -- this is the pose kernel of the dependent chain)
   const unsigned long long rp = ctl->raw_pos;
   const unsigned f_fault = (unsigned)fault, f_in = (unsigned)ctl->n_in, f_n2 = (unsigned)ctl->n2, f_tri = (unsigned)ctl->n_tri;
-  unsigned x = 0u;
+  unsigned x = 0u, y = 0u;
   unsigned* dst = reinterpret_cast<unsigned*>(res);
   for (int k = 0; k < REC_DW - 2; ++k) {
     unsigned v = 0u;
@@ -282,11 +290,12 @@ __device__ __forceinline__ void write_fault_record(const vo_seq_ctl* __restrict_
     if (k == (int)(offsetof(vo_step_result, raw_pos) / 4)) v = (unsigned)rp;
     if (k == (int)(offsetof(vo_step_result, raw_pos) / 4) + 1) v = (unsigned)(rp >> 32);
     x ^= v;
+    y += record_mix(v, k);
     dst[k] = v;
   }
   dst[REC_DW - 2] = seq ^ x;
   __threadfence_system();
-  dst[REC_DW - 1] = seq;
+  dst[REC_DW - 1] = seq + y;
   __threadfence_system();
   *seq_word = seq;
 }
@@ -340,14 +349,18 @@ __device__ __forceinline__ void write_step_record(vo_seq_ctl* __restrict__ ctl, 
     const bool second = tid + 64 < REC_DW - 2;
     const unsigned v0 = s_rec[tid], v1 = second ? s_rec[tid + 64] : 0u;
     unsigned x = v0 ^ v1;
+    unsigned y = record_mix(v0, tid) + (second ? record_mix(v1, tid + 64) : 0u);
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x ^= __shfl_xor(x, off);
+    for (int off = 32; off >= 1; off >>= 1) {
+      x ^= __shfl_xor(x, off);
+      y += __shfl_xor(y, off);
+    }
     dst[tid] = v0;
     if (second) dst[tid + 64] = v1;
     if (tid == 0) dst[REC_DW - 2] = seq ^ x;
     __threadfence_system();
     if (tid == 0) {
-      dst[REC_DW - 1] = seq;
+      dst[REC_DW - 1] = seq + y;
       __threadfence_system();
       *seq_word = seq;
     }

@@ -109,6 +109,30 @@ struct vo_cam2 {      // the two intrinsic matrices of the two-view bootstrap (b
   double K1[9], K2[9];
 };
 
+// ---- device-side gates between kernels of different streams (vo_seq_ctl's gate words; pipeline.hip) ----
+constexpr int VO_FAULT_GATE_BIT = 128;      // = VO_FAULT_GATE (vo_state.h)
+// poll `word` until it reaches `want` (agent scope, acquire); false after ~2 s of device clock
+__device__ __forceinline__ bool vo_gate_wait(const uint32_t* word, uint32_t want) {
+  const unsigned long long t0 = wall_clock64();
+  // (relaxed polls, ONE acquire when the word is there: an acquire at agent scope invalidates the L2 of this XCD)
+  while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > 200000000ull) return false;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
+// one arrival per workgroup (call from ONE work item after the workgroup's stores and a __threadfence()); the last of
+// `total` publishes `epoch` and resets the counter
+__device__ __forceinline__ void vo_gate_arrive(uint32_t* cnt, uint32_t total, uint32_t* word, uint32_t epoch) {
+  const uint32_t prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (prev + 1u == total) {
+    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- internal entry points shared between translation units (not part of the C ABI) ----
 // P3P hypotheses + inlier counts of the frame loop (p3p.hip): sample indices derived on the device from raw
 // generator outputs in a ring, population size and stream position read on the device.
@@ -143,6 +167,14 @@ struct vo_klt_source {
   int n_det = 0;
   unsigned long long* ts = nullptr;   // (optional) receives wall_clock64() when the kernel's first work item starts
   const int* det_go = nullptr;        // (optional, one int per sequence) 0: det_kp was not produced, nothing is appended
+  // device-side gates (vo_state.h, vo_seq_ctl): wait until *gate_wait reaches gate_want before anything is read; when
+  // all workgroups are done publish *gate_set = gate_set_to (arrivals counted in *gate_cnt).  All in the control block.
+  const uint32_t* gate_wait = nullptr;
+  uint32_t gate_want = 0;
+  uint32_t* gate_set = nullptr;
+  uint32_t* gate_cnt = nullptr;
+  uint32_t gate_set_to = 0;
+  int32_t* gate_fault = nullptr;      // receives VO_FAULT_GATE when the wait times out
 };
 // several sequences per launch (grid.y = sequence): element strides from one sequence's block to the next
 struct vo_klt_batch {

@@ -44,6 +44,7 @@ enum {
   VO_FAULT_CAPACITY = 8,        // appending the detector's keypoints would exceed the feature capacity
   VO_FAULT_FORCED = 16,         // test hook (vo_pipeline_config.debug_fault_every)
   VO_FAULT_NO_DETECTION = 32,   // the tracks fell below the re-detect limit on a frame whose detection was skipped
+  VO_FAULT_GATE = 128,          // a device-side gate was not opened within two seconds (a kernel it waits for never ran)
   VO_FAULT_CONTINUE = 64        // not an error: the sequential rule is not done after this launch's `hyp` samples; the loop's
                                 // state is in the control block and the host launches the next batch (hypotheses + pose kernel)
 };
@@ -63,6 +64,10 @@ struct vo_seq_ctl {
   int32_t few;             // VO_FAULT_FEW_LANDMARKS found by THIS step's regroup; the pose kernel ORs it into `fault`.  (Not
                            // written to `fault` by the regroup itself: its other workgroups read that word on entry, and one
                            // dispatched after block 0 had retired would skip its features.)
+  // Device-side gates between the tracker's stream and the main stream (one or two sequences; pipeline.hip): the regroup
+  // of flight j publishes gate_regroup = j + 1 when all its workgroups have written, the tracker of flight j publishes
+  // gate_klt = j + 1 likewise; the consumers poll these words instead of waiting for a stream event (17-19 us each way).
+  uint32_t gate_regroup, gate_regroup_cnt, gate_klt, gate_klt_cnt;
   int32_t cont;            // batches of `hyp` samples this step's RANSAC loop has already walked (VO_FAULT_CONTINUE); 0 = none
   // ---- RANSAC: persists across frames like the reference's estimator object ----
   int64_t n_iterations;
@@ -98,6 +103,8 @@ struct vo_append {
   int pose_mode;            // vo_pipeline_config.redetect_start_pose
   int debug_fault_every;
   const int* det_go;        // per sequence: 1 = the detector ran on the frame det_kp belongs to (NULL: it always does)
+  uint32_t gate_klt_want;   // != 0: wait until ctl->gate_klt reaches it (the tracker of this flight is done) ...
+  uint32_t gate_regroup_set; // ... and publish ctl->gate_regroup = this when every workgroup has written
 };
 
 struct vo_replay_args {

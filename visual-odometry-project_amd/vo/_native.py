@@ -147,6 +147,8 @@ _SIGS = {
     "vo_rng_choice": (_i, [_vp, _i, _i, _i, _vp]),
     "vo_ransac_num_iterations": (C.c_int64, [_d, _d, _i]),
     "vo_ransac_replay": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "vo_record_seal": (None, [_vp, C.c_uint]),
+    "vo_record_check": (_i, [_vp, C.c_uint]),
     "vo_pipeline_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "vo_pipeline_checkpoint": (_i, [_vp]),
     "vo_pipeline_rewind": (_i, [_vp]),
