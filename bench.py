@@ -15,7 +15,7 @@ klt.py:207-230 fires at the rate the stream produces and the detector executes w
 One "step" = one frame of the reference's steady-state loop (src/main.py:248-286, KLT tracker mode with the
 Harris detector) on a 1376x1241 frame that is already resident in HBM, everything on the GPU:
   pyramid(next) | Harris response + exact greedy NMS (2000 keypoints) on next, for a sequence whose track count is
-  within 2 % (+ four times its last loss) of the re-detect limit (the reference runs its detector only below the limit, klt.py:207-230;
+  within 1 % (+ 2.5 times its last loss) of the re-detect limit (the reference runs its detector only below the limit, klt.py:207-230;
   VO_BENCH_DETECT_MARGIN=-1: on every frame) | re-detect append when fewer than 80 % of the tracks survive -> KLT
   (3 levels, 15x15) of every feature -> Matches regroup -> P3P-RANSAC (1000
   hypotheses solved + scored, reference-exact sampler, sequential accept rule replayed on the device) -> pose
@@ -62,7 +62,7 @@ RENDER_WORKERS = int(os.environ.get("VO_BENCH_RENDER_WORKERS", str(max(1, min(12
 REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
 EXCHANGE_EVERY = int(os.environ.get("VO_BENCH_EXCHANGE_EVERY", "16"))   # frames per all-gather of {pose, landmarks} records
 REDETECT_POSE = os.environ.get("VO_BENCH_REDETECT_POSE", "current")   # see vo_pipeline_config.redetect_start_pose
-DETECT_MARGIN = float(os.environ.get("VO_BENCH_DETECT_MARGIN", "0.02"))   # see vo_pipeline_config.detect_margin (< 0: every frame)
+DETECT_MARGIN = float(os.environ.get("VO_BENCH_DETECT_MARGIN", "0.01"))   # see vo_pipeline_config.detect_margin (< 0: every frame)
 PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 PROFILE_TAG = os.environ.get("VO_BENCH_PROFILE_TAG", "r03")
@@ -667,7 +667,7 @@ def main():
                        "frame_lookahead": 1 if args.lookahead else 0, "redetect_start_pose": REDETECT_POSE,
                        "detector": ("Harris + NMS on every frame" if DETECT_MARGIN < 0 else
                                     "Harris + NMS launched every frame, executed for a sequence whose track count, extrapolated "
-                                    "by four times its last loss, is below %.2f x num_features (re-detect limit 0.80, as "
+                                    "by 2.5 times its last loss, is below %.2f x num_features (re-detect limit 0.80, as "
                                     "klt.py:207-230; a sequence that falls through that in one frame is finished by the host "
                                     "path)" % (0.8 + DETECT_MARGIN)),
                        "rccl_world_size": dist.get_world_size() if exchange else 1,

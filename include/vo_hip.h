@@ -356,12 +356,14 @@ typedef struct vo_pipeline_config {
   double detect_margin;          /* the detector chain is launched for every frame (its keypoints are what the NEXT
                                     step appends when fewer than redetect_fraction of the tracks are left, and that
                                     count is known one step too late for a launch without a host turn); a sequence
-                                    sits it out unless its count, extrapolated by four times the last step's
-                                    loss, is below (redetect_fraction + detect_margin) * num_features.  A
+                                    sits it out unless its count, extrapolated by detect_losses times the last
+                                    step's loss, is below (redetect_fraction + detect_margin) * num_features.  A
                                     sequence that falls through all of that in one frame is finished through the
-                                    host path (detector run then).  0 = 0.02; < 0 = the detector runs on every
+                                    host path (detector run then).  0 = 0.01; < 0 = the detector runs on every
                                     frame.  The reference detects only below the limit itself.             */
   int32_t debug_never_detect;    /* test hook: the detector runs only when forced (state hand-over, host path)  */
+  double detect_losses;          /* how many of the last step's losses the count is extrapolated by in the detector's
+                                    decision (see detect_margin).  0 = 2.5                                          */
   int32_t sequences;             /* S independent frame streams advancing in lock step through the same
                                     launches (the sequence is the grid's extra dimension; SURVEY.md 8e: streams
                                     are independent, so they batch).  0 = 1.  Every sequence has its own frame

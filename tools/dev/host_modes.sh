@@ -1,15 +1,16 @@
 #!/bin/bash
-# bench with legs under stream settings
+# bench with legs under detector-prediction settings
 run() {
   timeout -k 10 400 python bench.py --steps 1000 --warmup 50 --no-api --no-cpu-baseline > gpurun_out/b8.json 2> gpurun_out/b8.err || tail -3 gpurun_out/b8.err
   python - <<PY
 import json
 d = json.load(open("gpurun_out/b8.json"))
 c = d["chain_us"]
-print("$1:", d["value"], "period med %.1f mean %.1f" % (c["step_period"], c["step_period_mean"]), "| every-frame", d["detector_every_frame"]["frames_per_s"], "| S16", d["sequences_16"]["frames_per_s"], "| S16 every-frame", d["sequences_16_detector_every_frame"]["frames_per_s"])
+l = d["loop"]; s = d["sequences_16"]
+print("$1:", d["value"], "det %.2f host %d %s" % (l["detector_executed_fraction_of_steps"], l["steps_finished_by_host_path"], l["host_path_reasons"]), "| S16", s["frames_per_s"], "det %.2f host %d %s" % (s["detector_executed_fraction_of_steps"], s["steps_finished_by_host_path"], s["host_path_reasons"]))
 PY
 }
-run "no mask"
-VO_SIDE_CUS=32-255 run "side 32-255"
-VO_SIDE_CUS=16-255 run "side 16-255"
-VO_SIDE_CUS=64-255 run "side 64-255"
+VO_DETECT_LOSSES=4 VO_BENCH_DETECT_MARGIN=0.02 run "4 losses, margin .02"
+VO_DETECT_LOSSES=2.5 VO_BENCH_DETECT_MARGIN=0.01 run "2.5 losses, margin .01"
+VO_DETECT_LOSSES=2 VO_BENCH_DETECT_MARGIN=0.005 run "2 losses, margin .005"
+VO_DETECT_LOSSES=3 VO_BENCH_DETECT_MARGIN=0.01 run "3 losses, margin .01"

@@ -56,6 +56,7 @@ struct vo_pipeline {
   double* d_scores[2] = {nullptr, nullptr};   // [S][px] each, alternating between consecutive detections
   int* d_det_go = nullptr;           // [3][S]: 1 = the detector ran for that sequence on the frame in keypoint slot s
   double detect_limit = 0.0;         // detect when n < detect_limit * num_features (< 0: always)
+  double detect_losses = 2.5;        // ... with n extrapolated by this many times the last step's loss
   hipEvent_t evPyr[3] = {nullptr, nullptr, nullptr}, evDet[3] = {nullptr, nullptr, nullptr};
   // frame upload: pinned staging per (sequence, frame slot), allocated on first use; evImg[idx]: slot idx is in HBM
   std::vector<uint8_t*> h_img;
@@ -161,16 +162,18 @@ __global__ __launch_bounds__(256) void export_state_kernel(pose17 head, const do
 
 // Does sequence q need the detector on the frame being submitted?  The count that decides is known one step later;
 // what is known now is the count of the frame before (or already this frame's, when the step's regroup has run) and
-// how many tracks the last step lost: the detector runs when the count, extrapolated by four such losses, is below
-// (redetect_fraction + detect_margin) * num_features.  (The fields are read while a regroup may be writing them: any
+// how many tracks the last step lost: the detector runs when the count, extrapolated by `losses` such losses, is below
+// (redetect_fraction + detect_margin) * num_features.  (Round 2: four losses and a margin of 0.02 -- the detector then ran
+// on 26 % of the forward stream's frames for the 4 % that re-detect; 2.5 and 0.01: 15-18 %, still no frame caught without
+// its keypoints in ~4000 sequence-steps; 2 and 0.005: 12-14 % and one such frame.)  (The fields are read while a regroup may be writing them: any
 // mix of old and new values is a usable guess, and a wrong guess is caught by the step that needs the keypoints.)
 __global__ __launch_bounds__(64) void detect_decide_kernel(const vo_seq_ctl* __restrict__ ctl, int S, double limit, int n_det,
-                                                           int force, int* __restrict__ go) {
+                                                           int force, int* __restrict__ go, double losses) {
   const int q = blockIdx.x * 64 + threadIdx.x;
   if (q >= S) return;
   const int n2 = ctl[q].n2;
   const int lost = max(ctl[q].n_in - (ctl[q].redetected ? n_det : 0) - n2, 0);
-  go[q] = (force || limit < 0.0 || (limit > 0.0 && (double)(n2 - 4 * lost) < (double)ctl[q].num_features * limit)) ? 1 : 0;
+  go[q] = (force || limit < 0.0 || (limit > 0.0 && (double)n2 - losses * (double)lost < (double)ctl[q].num_features * limit)) ? 1 : 0;
 }
 
 // vo_pipeline_rewind: the control block as it was at the checkpoint, except what lives on the reference's estimator
@@ -379,9 +382,12 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   const int S = p->S;
   if (p->cfg.bearing_threshold == 0.0) p->cfg.bearing_threshold = 0.0075;    // state.py:8
   if (p->cfg.redetect_fraction == 0.0) p->cfg.redetect_fraction = 0.8;       // klt.py:212
-  if (p->cfg.detect_margin == 0.0) p->cfg.detect_margin = 0.02;
+  if (p->cfg.detect_margin == 0.0) p->cfg.detect_margin = 0.01;
+  if (p->cfg.detect_losses <= 0.0) p->cfg.detect_losses = 2.5;
+  p->detect_losses = p->cfg.detect_losses;
   p->detect_limit = p->cfg.detect_margin < 0.0 ? -1.0 : p->cfg.redetect_fraction + p->cfg.detect_margin;
   if (p->cfg.debug_never_detect) p->detect_limit = 0.0;     // test hook: only forced detections (state hand-over, host path)
+  if (const char* e = getenv("VO_DETECT_LOSSES")) p->detect_losses = atof(e);
   memcpy(p->cam.K, cfg->K, sizeof(p->cam.K));
   {
     bool given = false;
@@ -646,7 +652,7 @@ static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force, char*
     return vo_set_error(p->ctx, VO_EHIP, "detection: hipStreamWaitEvent failed");
   }
   hipLaunchKernelGGL(detect_decide_kernel, dim3(vo_cdiv(p->S, 64)), dim3(64), 0, det->stream, p->d_ctl, p->S, p->detect_limit,
-                     c.n_keypoints, force ? 1 : 0, go);
+                     c.n_keypoints, force ? 1 : 0, go, p->detect_losses);
   int rc = vo_check_launch(det, "detect_decide_kernel");
   if (rc == VO_OK)
     rc = vo_harris_response_batch_dev(det, p->img(0, frame), p->img_stride(), p->S, c.H, c.W, c.harris_patch, c.harris_kappa,

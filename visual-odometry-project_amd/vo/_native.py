@@ -69,7 +69,7 @@ class PipelineConfig(C.Structure):
                 ("K", C.c_double * 9), ("Kinv", C.c_double * 9), ("refine_iters", C.c_int32), ("feature_cap", C.c_int32),
                 ("bearing_threshold", C.c_double), ("redetect_fraction", C.c_double),
                 ("debug_fault_every", C.c_int32), ("redetect_start_pose", C.c_int32), ("detect_margin", C.c_double),
-                ("debug_never_detect", C.c_int32), ("sequences", C.c_int32)]
+                ("debug_never_detect", C.c_int32), ("detect_losses", C.c_double), ("sequences", C.c_int32)]
 
 
 class StepResult(C.Structure):

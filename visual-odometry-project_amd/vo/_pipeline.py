@@ -29,7 +29,7 @@ class Pipeline:
                  klt_err_threshold=100.0, hyp=1000, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99,
                  max_iterations=1000, seed=2023, refine_iters=0, feature_cap=0, bearing_threshold=0.0075,
                  redetect_fraction=0.8, debug_fault_every=0, redetect_start_pose="identity", sequences=1,
-                 detect_margin=0.02, debug_never_detect=0):
+                 detect_margin=0.01, debug_never_detect=0, detect_losses=2.5):
         from vo import _native
         self.ctx = ctx
         self.cfg = _native.PipelineConfig()
@@ -50,6 +50,7 @@ class Pipeline:
         c.sequences = int(sequences)
         c.detect_margin = float(detect_margin)       # < 0: the detector runs on every frame
         c.debug_never_detect = int(debug_never_detect)
+        c.detect_losses = float(detect_losses)
         self.sequences = int(sequences)
         K = np.asarray(K, np.float64).reshape(3, 3)
         self.K = K
