@@ -35,7 +35,7 @@ def main():
     rows.sort(key=lambda r: -r[3])
     f, w = pmc(fdir, "FETCH_SIZE"), pmc(wdir, "WRITE_SIZE")
     with open(out + "_kernel_summary.txt", "w") as o:
-        o.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 30 --no-cpu-baseline\n")
+        o.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-api --no-legs\n")
         o.write("%-34s %6s %10s %7s %9s %9s\n" % ("kernel", "calls", "avg_us", "pct", "min_us", "max_us"))
         for r in rows:
             o.write("%-34s %6d %10.2f %7.2f %9.2f %9.2f\n" % r)
