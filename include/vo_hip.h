@@ -279,6 +279,12 @@ int vo_min_eigen_map(vo_ctx* ctx, const uint8_t* img, int H, int W, int block, f
 int vo_sift_capacity(int H, int W);
 int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp, float* desc,
             int32_t* n);
+/* The same with the frame and the results in device memory, enqueued on the context's stream (no synchronisation):
+ * d_kp cap*6 float32, d_desc cap*128 float32 and / or d_desc_u8 cap*128 bytes (the descriptor values are whole numbers
+ * 0..255; either may be NULL), d_n one int32.  1 <= cap <= 4000: the final order, the duplicate filter and the cap run
+ * on the device too (one workgroup sorts the cap + ties described rows).                                          */
+int vo_sift_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap, float* d_kp, float* d_desc, uint8_t* d_desc_u8,
+                int32_t* d_n);
 
 /* ---- RANSAC control (host-side, bit-compatible with the reference) --------------
  * [ref: src/vo/algorithms/ransac.py:52, 92-94]  the sample stream of
@@ -369,6 +375,16 @@ typedef struct vo_pipeline_config {
                                     are independent, so they batch).  0 = 1.  Every sequence has its own frame
                                     store, Features, State, RANSAC object and generator; the plain entry points
                                     address sequence 0, the _seq forms any of them.                      */
+  int32_t tracker_mode;          /* 0: KLT tracker with the Harris detector (everything above); 1: SIFT
+                                    [ref: src/vo/features/tracker.py:60-61, src/vo/features/sift.py:23-56] -- per frame
+                                    detect + describe (the sift_cap strongest keypoints; the reference keeps all of them),
+                                    2-NN + ratio + first-come uniqueness against the descriptors the current Features
+                                    carry, Matches regroup from the pair list with the descriptors following their
+                                    keypoints [ref: src/vo/primitives/matches.py:51-58, 134-141], then the same pose
+                                    estimation and State bookkeeping.  One sequence per pipeline; the state handed over
+                                    needs its descriptors too (vo_pipeline_set_descriptors).                      */
+  int32_t sift_cap;              /* keypoints kept per frame in SIFT mode (0 = n_keypoints; <= 4000, <= feature_cap) */
+  double match_ratio;            /* sift.py:49; 0 = 0.8                                                            */
 } vo_pipeline_config;
 typedef struct vo_step_result {
   double R[9], t[3];            /* world -> camera pose of `next` (best hypothesis)   */
@@ -434,6 +450,9 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
  * state of the frame it was taken at and queues that frame's pyramid and detection, all asynchronously on the pipeline's
  * streams (nothing in flight; no host synchronisation).  What lives on the reference's estimator object across frames
  * (RANSAC.n_iterations / outlier_ratio [ref: src/vo/algorithms/ransac.py:47-56], the generator) is NOT rewound.      */
+/* SIFT tracker mode: the descriptors (n x 128 float32, whole numbers 0..255) of the features handed over by the last
+ * vo_pipeline_set_state, in the same order.                                                                      */
+int vo_pipeline_set_descriptors(vo_pipeline* p, const float* desc, int n);
 int vo_pipeline_checkpoint(vo_pipeline* p);
 int vo_pipeline_rewind(vo_pipeline* p);
 /* Downloads the current Features (arrays sized to the capacity vo_pipeline_feature_cap returns;

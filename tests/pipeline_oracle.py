@@ -52,7 +52,11 @@ def make_tracker(frame, n_keypoints, win, max_level, redetect_start_pose="identi
 class OracleLoop:
     def __init__(self, stream, n_keypoints, win, max_level, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99,
                  max_iterations=1000, refine_iters=20, bearing_threshold=0.0075, seed=2023,
-                 redetect_start_pose="identity"):
+                 redetect_start_pose="identity", tracker="klt", match_ratio=0.8):
+        """tracker = "sift": src/vo/features/tracker.py:60-61 -> sift.py:23-56 (detect + describe the new frame, the
+        n_keypoints strongest; 2-NN + ratio + uniqueness against the current frame's descriptors; Matches from the pairs)
+        instead of the KLT tracker."""
+        self.tracker_mode, self.match_ratio = tracker, match_ratio
         from vo.primitives import Frame
         from vo.sensors import Camera
         self.stream = stream
@@ -79,6 +83,8 @@ class OracleLoop:
         self.state.curr_pose = np.array(curr_pose, np.float64)
         self.state.prev_pose = np.array(prev_pose, np.float64)
         self.state.prev_frame = f
+        if self.tracker_mode == "sift":
+            return
         # the tracker shell: built around the frame without touching its features
         keep = f.features
         self.tracker = make_tracker(self.frame(idx), self.cfg["N"], self.cfg["win"], self.cfg["lvl"], self.cfg["redetect"])
@@ -89,8 +95,19 @@ class OracleLoop:
         st, K = self.state, self.K
         new = self.frame(next_idx)
         n_before = st.curr_frame.features.length
-        self.tracker.current_pose = st.get_pose().copy()
-        matches = self.tracker.track_features(st.curr_frame, new)
+        if self.tracker_mode == "sift":
+            from vo.primitives import Features, Matches
+            kp2, desc2 = native.sift(self.stream.image(next_idx), cap=self.cfg["N"])
+            new.features = Features(kp2[:, :2].astype(np.float64).reshape(-1, 2, 1))
+            new.features.descriptors = desc2
+            good = native.match_knn2_ratio(st.curr_frame.features.descriptors, desc2, self.match_ratio)[0]
+            if len(good) == 0:
+                good = np.empty((0, 2), dtype=int)
+            matches = Matches(st.curr_frame, new, matches=good)
+            self.n_new, self.n_pairs = len(kp2), len(good)
+        else:
+            self.tracker.current_pose = st.get_pose().copy()
+            matches = self.tracker.track_features(st.curr_frame, new)
         f2 = matches.frame2.features
         X = np.ascontiguousarray(f2.triangulated_inliers_landmarks[:, :, 0], np.float64)
         x = np.ascontiguousarray(f2.triangulated_inliers_keypoints[:, :, 0], np.float64)
@@ -146,5 +163,32 @@ def initial_features(stream, idx, n_keypoints, depth_scale=1.0):
     f.state = np.concatenate([2 * np.ones(n_tri), np.ones(n - n_tri)])
     f.landmarks[:n_tri] = land[:n_tri].reshape(-1, 3, 1)
     f.tracks = np.concatenate([np.full((n_tri, 2, 1), np.nan), kp[n_tri:].astype(np.float64)])
+    f.poses = np.concatenate([np.full((n_tri, 4, 4), np.nan), np.stack([T] * (n - n_tri))])
+    return f, T
+
+
+def initial_sift_features(stream, idx, n_keypoints):
+    """Starting state for the SIFT tracker mode: the frame's SIFT keypoints (the n strongest) with their descriptors,
+    the first two thirds triangulated from the stream's analytic depth along the keypoint's own ray, the rest matched
+    tracks that started here."""
+    from vo.primitives import Features
+    K = stream.K
+    kp6, desc = native.sift(stream.image(idx), cap=n_keypoints)
+    kp = kp6[:, :2].astype(np.float64).reshape(-1, 2, 1)
+    f = Features(keypoints=kp)
+    f.descriptors = desc
+    n = f.length
+    T = stream.T_world_cam(idx)
+    H, W = stream.image(idx).shape
+    yi = np.clip(np.rint(kp[:, 1, 0]).astype(int), 0, H - 1)
+    xi = np.clip(np.rint(kp[:, 0, 0]).astype(int), 0, W - 1)
+    z = stream.depth(idx)[yi, xi].astype(np.float64)
+    xc = (kp[:, 0, 0] - K[0, 2]) / K[0, 0] * z
+    yc = (kp[:, 1, 0] - K[1, 2]) / K[1, 1] * z
+    land = np.stack([T[r, 0] * xc + T[r, 1] * yc + T[r, 2] * z + T[r, 3] for r in range(3)], axis=1)
+    n_tri = (2 * n) // 3
+    f.state = np.concatenate([2 * np.ones(n_tri), np.ones(n - n_tri)])
+    f.landmarks[:n_tri] = land[:n_tri].reshape(-1, 3, 1)
+    f.tracks = np.concatenate([np.full((n_tri, 2, 1), np.nan), kp[n_tri:]])
     f.poses = np.concatenate([np.full((n_tri, 4, 4), np.nan), np.stack([T] * (n - n_tri))])
     return f, T

@@ -47,21 +47,23 @@ def start_state(stream, N, fraction=1.0):
     return feats, T
 
 
-def check_state(got, ref_feats, ref_pose, tol=1e-7):
+def check_state(got, ref_feats, ref_pose, tol=1e-7, land_tol=1e-6):
     n = ref_feats.length
     assert got["n"] == n
     assert np.array_equal(got["keypoints"], ref_feats.keypoints.astype(np.float64))
     assert np.array_equal(got["state"], ref_feats.state)
     assert np.array_equal(got["candidate_mask"], ref_feats.candidate_mask)
     assert np.array_equal(np.isnan(got["landmarks"]), np.isnan(ref_feats.landmarks))
-    assert np.allclose(got["landmarks"], ref_feats.landmarks, rtol=1e-6, atol=1e-6, equal_nan=True)
+    with np.errstate(invalid="ignore"):
+        dl = np.abs(got["landmarks"] - ref_feats.landmarks) / np.maximum(1.0, np.abs(ref_feats.landmarks))
+    assert not np.nanmax(dl, initial=0.0) > land_tol, "landmarks differ by %.3g (relative)" % np.nanmax(dl)
     assert np.array_equal(got["tracks"], ref_feats.tracks, equal_nan=True)
     assert np.array_equal(np.isnan(got["poses"]), np.isnan(ref_feats.poses))
     assert np.allclose(got["poses"], ref_feats.poses, atol=tol, equal_nan=True)
     assert np.allclose(got["curr_pose"], ref_pose, atol=tol)
 
 
-def check_step(r, ref, pipe, gen_ref, tol_refined=1e-7):
+def check_step(r, ref, pipe, gen_ref, tol_refined=1e-7, land_tol=1e-6):
     assert r.fault == 0
     assert r.n_tracked == ref["n_tracked"] and r.n_triangulated == ref["n_tri"]
     assert r.draws_consumed == ref["draws"] and r.ransac_iterations == ref["iters"]
@@ -72,7 +74,7 @@ def check_step(r, ref, pipe, gen_ref, tol_refined=1e-7):
     assert np.allclose(Rr, ref["R_ref"], atol=tol_refined) and np.allclose(tr, ref["t_ref"], atol=tol_refined)
     assert r.n_candidates == ref["n_cand"] and r.n_landmarks == ref["n_landmarks"]
     st = pipe.get_state()
-    check_state(st, ref["features"], ref["pose"])
+    check_state(st, ref["features"], ref["pose"], land_tol=land_tol)
     assert st["n_iterations"] == ref["n_iterations"] and st["outlier_ratio"] == ref["outlier_ratio"]
     g = np.random.default_rng(0)
     pipe.rng_state_into(g)
@@ -613,3 +615,47 @@ def test_comm_world_of_one_and_host_thread_budget(ctx):
     for a, b in zip(ref, got):
         assert (a.n_tracked, a.n_inliers, a.draws_consumed, a.n_landmarks, list(a.t_refined)) == (
             b.n_tracked, b.n_inliers, b.draws_consumed, b.n_landmarks, list(b.t_refined))
+
+
+@pytest.mark.parametrize("H,W,N,lookahead", [(240, 320, 300, False), (480, 640, 600, True)])
+def test_sift_tracker_mode_matches_oracle_loop(ctx, H, W, N, lookahead):
+    """Tracker(mode="sift") (src/vo/features/tracker.py:60-61) as a device-resident loop: per frame SIFT detect +
+    describe (the N strongest), 2-NN + 0.8 ratio + first-come uniqueness on the matrix cores against the descriptors the
+    current Features carry, Matches regroup from the pair list with the descriptors following their keypoints, P3P-RANSAC,
+    refinement, State bookkeeping, candidate DLT -- nothing but images in, records out.  Against the oracle loop
+    (oracle/csrc/sift.c, match.c; the pinned bookkeeping classes) after every frame: every carried array, RANSAC
+    bookkeeping, generator state."""
+    from pipeline_oracle import initial_sift_features
+    from vo import _native, synthetic
+    F = 6
+    stream = synthetic.Stream(F, H, W)
+    feats, T = initial_sift_features(stream, 0, N)
+    pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, hyp=256, p3p_threshold=1.0, max_iterations=1000,
+                            refine_iters=20, tracker="sift", sift_cap=N)
+    for i in range(F):
+        pipe.set_frame(i, stream.image(i))
+    pipe.set_state(0, feats, T, T)
+    orc = OracleLoop(stream, N, 15, 2, refine_iters=20, tracker="sift")
+    orc.set_state(0, feats, T, T)
+    pairs = [(k, k + 1) for k in range(F - 1)]
+    if lookahead:
+        refs = [orc.step(b) for _, b in pairs]
+        rs = run_all(pipe, pairs, True)
+        for r, ref in zip(rs, refs):
+            assert (r.n_tracked, r.n_triangulated, r.n_inliers, r.draws_consumed, r.ransac_iterations, r.n_candidates,
+                    r.n_landmarks) == (ref["n_tracked"], ref["n_tri"], ref["n_inliers"], ref["draws"], ref["iters"],
+                                       ref["n_cand"], ref["n_landmarks"])
+        check_step(rs[-1], refs[-1], pipe, orc.rs.rng, land_tol=1e-4)
+    else:
+        for a, b in pairs:
+            ref = orc.step(b)
+            r = pipe.step(a, b)
+            assert r.n_features_in == orc.n_new and r.n_triangulated >= 8
+            # (landmarks: the metric's 1e-4 -- matched SIFT keypoints are triangulated at the bearing threshold's small
+            #  parallax, where the 6x4 systems are ill-conditioned and Jacobi / LAPACK part by more than in the KLT tests)
+            check_step(r, ref, pipe, orc.rs.rng, land_tol=1e-4)
+            # (a sanity bound only: at this size a frame keeps ~50 landmarks)
+            Tcw = np.linalg.inv(stream.T_world_cam(b))
+            assert np.abs(np.array(r.R_refined).reshape(3, 3) - Tcw[:3, :3]).max() < 3e-2
+            assert np.abs(np.array(r.t_refined) - Tcw[:3, 3]).max() < 0.5
+    pipe.close()

@@ -124,8 +124,19 @@ template <int KB>   // Dp = 32 * KB bytes per row
 __global__ __launch_bounds__(256) void knn2_mfma_kernel(const uint8_t* __restrict__ q, int nq, const uint8_t* __restrict__ t,
                                                         int nt, unsigned long long* __restrict__ part,
                                                         unsigned* __restrict__ arrived, int* __restrict__ best,
-                                                        double* __restrict__ d2) {
+                                                        double* __restrict__ d2, const int* __restrict__ d_nq = nullptr,
+                                                        const int* __restrict__ d_nt = nullptr) {
   constexpr int Dp = 32 * KB;
+  if (d_nq) nq = min(nq, *d_nq);                       // counts that live on the device (frame pipeline): the launch is
+  if (d_nt) nt = min(nt, *d_nt);                       // sized for the capacities
+  if ((int)blockIdx.x * 32 >= nq || nt <= 0) {         // (every split of a block of queries leaves together)
+    if (nt <= 0 && threadIdx.x < 32 && (int)blockIdx.x * 32 + (int)threadIdx.x < nq && blockIdx.y == 0) {
+      const int qi = blockIdx.x * 32 + threadIdx.x;
+      best[2 * qi] = best[2 * qi + 1] = -1;
+      d2[2 * qi] = d2[2 * qi + 1] = 0.0;
+    }
+    return;
+  }
   __shared__ unsigned s_t[4][32];                      // per wave: the tile's train terms
   __shared__ unsigned long long s_k[32][8][2];
   __shared__ int s_last;
@@ -310,10 +321,12 @@ __global__ __launch_bounds__(256) void pack_bytes_kernel(const float* __restrict
 constexpr int RU_T = 1024;
 __global__ __launch_bounds__(RU_T) void ratio_unique_kernel(const int* __restrict__ best, const double* __restrict__ d2, int nq,
                                                             double ratio, int* __restrict__ owner /* nt, preset to INT_MAX */,
-                                                            int* __restrict__ pairs, int* __restrict__ n_pairs) {
+                                                            int* __restrict__ pairs, int* __restrict__ n_pairs,
+                                                            const int* __restrict__ d_nq = nullptr) {
   __shared__ int s_scan[RU_T];
   __shared__ int s_base;
   const int tid = threadIdx.x;
+  if (d_nq) nq = min(nq, *d_nq);
   for (int i = tid; i < nq; i += RU_T) {
     const int b0 = best[2 * i], b1 = best[2 * i + 1];
     if (b0 < 0 || b1 < 0) continue;
@@ -366,6 +379,41 @@ int vo_knn2_dev(vo_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt,
     hipLaunchKernelGGL(knn2_f32_kernel, dim3(nq), dim3(MT), 0, ctx->stream, d_q, nq, d_t, nt, D, d_best, d_d2);
   }
   return vo_check_launch(ctx, "knn2_f32_kernel");
+}
+
+// Frame-pipeline form (SIFT tracker mode, sift.py:38-54): 128-byte descriptor rows already on the device, the two
+// counts too (d_nq, d_nt; the launches are sized for cap_q / cap_t).  Pairs (query, train) in query order -> d_pairs
+// (cap_q x 2), their number -> *d_npairs.  Asynchronous on the context's stream; scratch[10..14] of the context.
+int vo_match_u8_dev(vo_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, int cap_q, const uint8_t* d_t, const int32_t* d_nt,
+                    int cap_t, double ratio, int32_t* d_pairs, int32_t* d_npairs) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, d_q && d_nq && d_t && d_nt && d_pairs && d_npairs && cap_q >= 1 && cap_t >= 1, "match_u8_dev: bad arguments");
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  vo_buf* s = ctx->scratch;
+  const int qblocks = vo_cdiv(cap_q, 32), ttiles = vo_cdiv(cap_t, 32);
+  int splits = 1;
+  while (qblocks * splits < 512 && ttiles / (splits * 2) >= 4) splits *= 2;
+  VO_TRY(vo_ensure(ctx, s[10], (size_t)cap_q * 8));                      // best
+  VO_TRY(vo_ensure(ctx, s[11], (size_t)cap_q * 16));                     // d2
+  VO_TRY(vo_ensure(ctx, s[12], (size_t)cap_t * 4));                      // owner
+  VO_TRY(vo_ensure(ctx, s[13], (size_t)qblocks * splits * 64 * 8));      // partial top-2 lists
+  if (ctx->match_arrived.cap < (size_t)qblocks * 4) {
+    VO_TRY(vo_ensure(ctx, ctx->match_arrived, (size_t)qblocks * 4));
+    VO_HIP_TRY(ctx, hipMemsetAsync(ctx->match_arrived.p, 0, ctx->match_arrived.cap, st));
+  }
+  VO_HIP_TRY(ctx, hipMemsetAsync(s[12].p, 0x7f, (size_t)cap_t * 4, st));
+  VO_HIP_TRY(ctx, hipMemsetAsync(d_npairs, 0, 4, st));
+  {
+    vo_prof_scope ps(ctx, VO_K_MATCH);
+    hipLaunchKernelGGL(knn2_mfma_kernel<4>, dim3(qblocks, splits), dim3(256), 0, st, d_q, cap_q, d_t, cap_t,
+                       (unsigned long long*)s[13].p, (unsigned*)ctx->match_arrived.p, (int*)s[10].p, (double*)s[11].p,
+                       (const int*)d_nq, (const int*)d_nt);
+  }
+  VO_TRY(vo_check_launch(ctx, "knn2_mfma_kernel"));
+  hipLaunchKernelGGL(ratio_unique_kernel, dim3(1), dim3(RU_T), 0, st, (const int*)s[10].p, (const double*)s[11].p, cap_q,
+                     ratio, (int*)s[12].p, (int*)d_pairs, (int*)d_npairs, (const int*)d_nq);
+  return vo_check_launch(ctx, "ratio_unique_kernel");
 }
 
 int vo_match_knn2_ratio(vo_ctx* ctx, const float* q, int nq, const float* t, int nt, int D, double ratio,

@@ -100,6 +100,17 @@ struct vo_pipeline {
   int last_fbuf = 0;
   hipEvent_t evA = nullptr, evB = nullptr;
   double* d_newkp = nullptr;         // scratch of the bookkeeping entry point
+  // SIFT tracker mode (vo_pipeline_config.tracker_mode = 1; src/vo/features/tracker.py:60-61, sift.py:23-56): the frame's
+  // keypoints and descriptors are made by the SIFT kernels on the tracker's stream, matched against the descriptors the
+  // current Features carry (bytes, regrouped with them: matches.py:51-58, 134-141) on the matrix cores, and regrouped
+  // from the explicit pair list -- nothing of it leaves HBM.  One sequence per pipeline in this mode.
+  int sift_cap = 0;
+  float* d_skp = nullptr;            // [3][sift_cap * 6]   keypoint rows of the frame in slot s
+  uint8_t* d_sdesc = nullptr;        // [3][sift_cap * 128] its descriptors
+  int32_t* d_sn = nullptr;           // [3] its keypoint count; [3]: pairs of the step being enqueued
+  uint8_t* d_fdesc = nullptr;        // [2][cap * 128]      descriptors of the Features buffers F[0], F[1]
+  int32_t* d_srcrow = nullptr;       // [cap]               new keypoint behind every regrouped feature
+  uint8_t* d_ckpt_fdesc = nullptr;
   // vo_pipeline_checkpoint / _rewind: a copy of one Features buffer (all sequences) and of the control blocks
   char* d_ckpt_feat = nullptr;
   vo_seq_ctl* d_ckpt_ctl = nullptr;
@@ -198,6 +209,26 @@ __global__ __launch_bounds__(64) void ctl_rewind_kernel(vo_seq_ctl* __restrict__
 __global__ void ctl_resume_kernel(vo_seq_ctl* __restrict__ ctl) {
   ctl->fault = 0;
   ctl->n_p3p = ctl->n_tri;
+}
+
+// SIFT tracker mode: the new frame's keypoint rows (x, y, size, angle, response, octave; float) as the float64 pairs the
+// regroup takes (sift.py:18 keeps kp.pt only)
+__global__ __launch_bounds__(256) void sift_kp_f64_kernel(const float* __restrict__ rows, const int* __restrict__ n, int cap,
+                                                          double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= min(*n, cap)) return;
+  out[2 * i] = (double)rows[6 * i];
+  out[2 * i + 1] = (double)rows[6 * i + 1];
+}
+
+// ... and the descriptors of the regrouped frame: row dst of the new Features = the new keypoint src_row[dst]'s
+__global__ __launch_bounds__(256) void desc_gather_kernel(const uint8_t* __restrict__ src, const int* __restrict__ src_row,
+                                                          const vo_seq_ctl* __restrict__ ctl, int cap, uint8_t* __restrict__ dst) {
+  if (ctl->fault) return;
+  const int w = blockIdx.x * 256 + threadIdx.x;        // one 4-byte word of one row
+  const int row = w >> 5, k = w & 31;
+  if (row >= min(ctl->n2, cap)) return;
+  reinterpret_cast<unsigned*>(dst)[(size_t)row * 32 + k] = reinterpret_cast<const unsigned*>(src)[(size_t)src_row[row] * 32 + k];
 }
 
 template <typename T>
@@ -335,7 +366,8 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (q) (void)hipStreamSynchronize(q->stream);
   void* dev[] = {p->d_det_go, p->d_img, p->d_pyr, p->d_kp, p->d_scores[0], p->d_scores[1], p->feat_mem, p->d_ctl, p->d_next, p->d_err,
                  p->d_status, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_samples, p->d_masks, p->d_best_mask, p->d_table,
-                 p->d_raws, p->d_newkp, p->d_pairs, p->d_ckpt_feat, p->d_ckpt_ctl};
+                 p->d_raws, p->d_newkp, p->d_pairs, p->d_ckpt_feat, p->d_ckpt_ctl, p->d_skp, p->d_sdesc, p->d_sn, p->d_fdesc,
+                 p->d_srcrow, p->d_ckpt_fdesc};
   for (void* q : dev)
     if (q) (void)hipFree(q);
   void* pin[] = {p->h_stage, p->h_res, (void*)p->h_seq};
@@ -368,6 +400,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   VO_REQUIRE(ctx, cfg->K[0] != 0.0 && cfg->K[4] != 0.0, "pipeline: singular intrinsics");
   VO_REQUIRE(ctx, cfg->refine_iters >= 0 && cfg->refine_iters <= 100, "pipeline: refine_iters must be in 0..100");
   VO_REQUIRE(ctx, cfg->sequences >= 0 && cfg->sequences <= 256, "pipeline: sequences must be in 1..256");
+  VO_REQUIRE(ctx, cfg->tracker_mode == 0 || cfg->tracker_mode == 1, "pipeline: tracker_mode must be 0 (klt) or 1 (sift)");
+  VO_REQUIRE(ctx, cfg->tracker_mode == 0 || cfg->sequences <= 1, "pipeline: the sift tracker mode runs one sequence per pipeline");
   const int cap = cfg->feature_cap > 0 ? cfg->feature_cap : 2 * cfg->n_keypoints;
   VO_REQUIRE(ctx, cap >= cfg->n_keypoints && cap <= 32768, "pipeline: feature_cap must be in n_keypoints..32768");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -494,6 +528,18 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_best_mask, Sz * p->words));
   PA(dev_alloc(ctx, &p->d_newkp, (size_t)cap * 2));
   PA(dev_alloc(ctx, &p->d_pairs, (size_t)cap * 2));
+  if (cfg->tracker_mode == 1) {
+    p->sift_cap = cfg->sift_cap > 0 ? cfg->sift_cap : cfg->n_keypoints;
+    if (rc == VO_OK && (p->sift_cap > cap || p->sift_cap > 4000))
+      rc = vo_set_error(ctx, VO_EINVAL, "pipeline: sift_cap %d exceeds the feature capacity %d (or 4000)", p->sift_cap, cap);
+    PA(dev_alloc(ctx, &p->d_skp, (size_t)3 * p->sift_cap * 6));
+    PA(dev_alloc(ctx, &p->d_sdesc, (size_t)3 * p->sift_cap * 128));
+    PA(dev_alloc(ctx, &p->d_sn, 8));
+    PA(dev_alloc(ctx, &p->d_fdesc, (size_t)2 * cap * 128));
+    PA(dev_alloc(ctx, &p->d_srcrow, (size_t)cap));
+    if (rc == VO_OK && (hipMemset(p->d_sn, 0, 32) != hipSuccess || hipMemset(p->d_fdesc, 0, (size_t)2 * cap * 128) != hipSuccess))
+      rc = vo_set_error(ctx, VO_EHIP, "pipeline: hipMemset failed");
+  }
   // n_iterations as a step function of the outlier ratio (state_device.h, table_lookup): a batch of `hyp`
   // samples cannot finish a rule that needs more than `hyp` iterations, so hyp + 1 thresholds suffice
   // -- unless the loop continues over several launches (VO_FAULT_CONTINUE): then the table holds the whole budget
@@ -854,6 +900,51 @@ static int enqueue_pose_half(vo_pipeline* p, const vo_pipeline::flight_t& f, int
   return VO_OK;
 }
 
+// ---- SIFT tracker mode ----
+extern "C" int vo_sift_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap, float* d_kp, float* d_desc,
+                           uint8_t* d_desc_u8, int32_t* d_n);
+
+// detect + describe of the step's new frame on the tracker's stream (it depends on the image only): slot f.b
+static int enqueue_sift(vo_pipeline* p, const vo_pipeline::flight_t& f) {
+  vo_ctx* trk = p->trk;
+  const vo_pipeline_config& c = p->cfg;
+  const int rc = vo_sift_dev(trk, p->img(0, f.next_idx), c.H, c.W, p->sift_cap, p->d_skp + (size_t)f.b * p->sift_cap * 6, nullptr,
+                             p->d_sdesc + (size_t)f.b * p->sift_cap * 128, p->d_sn + f.b);
+  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "sift: %s", vo_last_error(trk));
+  VO_HIP_TRY(p->ctx, hipEventRecord(p->evPyr[f.b], trk->stream));
+  return VO_OK;
+}
+
+// main-stream chain of a step in SIFT mode: 2-NN + ratio + uniqueness against the current Features' descriptors
+// (sift.py:38-54), Matches regroup from the pair list (matches.py:26-212) with the descriptors following their
+// keypoints, then hypotheses and pose as in the KLT mode
+static int enqueue_chain_sift(vo_pipeline* p, const vo_pipeline::flight_t& f, bool first_half_only, unsigned seq) {
+  vo_ctx* ctx = p->ctx;
+  const vo_pipeline_config& c = p->cfg;
+  hipStream_t st = ctx->stream;
+  const vo_feat A = p->F[f.fcur], B = p->F[1 - f.fcur];
+  const uint8_t* descA = p->d_fdesc + (size_t)f.fcur * p->cap * 128;
+  uint8_t* descB = p->d_fdesc + (size_t)(1 - f.fcur) * p->cap * 128;
+  const uint8_t* sdesc = p->d_sdesc + (size_t)f.b * p->sift_cap * 128;
+  const float* skp = p->d_skp + (size_t)f.b * p->sift_cap * 6;
+  int32_t* n_new = p->d_sn + f.b;
+  int32_t* n_pairs = p->d_sn + 3;
+  VO_HIP_TRY(ctx, hipStreamWaitEvent(st, p->evPyr[f.b], 0));
+  VO_TRY(vo_match_u8_dev(ctx, descA, &p->d_ctl->n, p->cap, sdesc, n_new, p->sift_cap, c.match_ratio > 0.0 ? c.match_ratio : 0.8,
+                         p->d_pairs, n_pairs));
+  hipLaunchKernelGGL(sift_kp_f64_kernel, dim3(vo_cdiv(p->sift_cap, 256)), dim3(256), 0, st, skp, (const int*)n_new, p->sift_cap,
+                     p->d_newkp);
+  VO_TRY(vo_check_launch(ctx, "sift_kp_f64_kernel"));
+  VO_TRY(vo_state_regroup_pairs(ctx, p->d_ctl, A, B, p->d_pairs, p->cap, p->d_newkp, p->sift_cap, p->cap, n_pairs, n_new,
+                                p->d_srcrow));
+  hipLaunchKernelGGL(desc_gather_kernel, dim3(vo_cdiv(p->cap * 32, 256)), dim3(256), 0, st, sdesc, (const int*)p->d_srcrow,
+                     (const vo_seq_ctl*)p->d_ctl, p->cap, descB);
+  VO_TRY(vo_check_launch(ctx, "desc_gather_kernel"));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], st));
+  if (first_half_only) return VO_OK;
+  return enqueue_pose_half(p, f, 0, 1, seq);
+}
+
 // ---- detection worker ----
 static void worker_main(vo_pipeline* p) {
   (void)hipSetDevice(p->ctx->device);
@@ -985,9 +1076,31 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
                                    num_features);
 }
 
+int vo_pipeline_set_descriptors(vo_pipeline* p, const float* desc, int n) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, p->cfg.tracker_mode == 1, "pipeline_set_descriptors: the pipeline is not in sift tracker mode");
+  VO_REQUIRE(ctx, p->have_state && p->n_flight == 0, "pipeline_set_descriptors: hand the state over first (nothing in flight)");
+  VO_REQUIRE(ctx, n >= 0 && n <= p->cap && (n == 0 || desc), "pipeline_set_descriptors: bad arguments");
+  std::vector<uint8_t> b((size_t)n * 128);
+  for (size_t i = 0; i < b.size(); ++i) {
+    const float v = desc[i];
+    VO_REQUIRE(ctx, v >= 0.f && v <= 255.f && v == (float)(int)v, "pipeline_set_descriptors: descriptor values must be whole numbers 0..255");
+    b[i] = (uint8_t)v;
+  }
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n > 0)
+    VO_HIP_TRY(ctx, mcpy(ctx->stream, p->d_fdesc + (size_t)p->cur * p->cap * 128, b.data(), b.size(), hipMemcpyHostToDevice));
+  return VO_OK;
+}
+
 // pyramid and detection of the frame the handed-over states belong to, all sequences, synchronously
 static int prime(vo_pipeline* p, bool wait = true) {
   vo_ctx* ctx = p->ctx;
+  if (p->cfg.tracker_mode == 1) {      // SIFT mode: the frame's own descriptors travel with its Features
+    p->primed = true;
+    return VO_OK;
+  }
   VO_TRY(worker_idle(p));
   sync_prof(p);
   VO_TRY(enqueue_pyramid(p, p->prev_frame, p->slot));
@@ -1014,6 +1127,11 @@ extern "C" int vo_pipeline_checkpoint(vo_pipeline* p) {
   VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_feat, (char*)p->feat_mem + (size_t)p->cur * p->feat_block, p->feat_block,
                                  hipMemcpyDeviceToDevice, st));
   VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_ctl, p->d_ctl, (size_t)p->S * sizeof(vo_seq_ctl), hipMemcpyDeviceToDevice, st));
+  if (p->cfg.tracker_mode == 1) {
+    if (!p->d_ckpt_fdesc) VO_TRY(dev_alloc(ctx, &p->d_ckpt_fdesc, (size_t)p->cap * 128));
+    VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_fdesc, p->d_fdesc + (size_t)p->cur * p->cap * 128, (size_t)p->cap * 128,
+                                   hipMemcpyDeviceToDevice, st));
+  }
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
   p->ckpt_frame = p->prev_frame;
   return VO_OK;
@@ -1030,6 +1148,9 @@ extern "C" int vo_pipeline_rewind(vo_pipeline* p) {
   // every step has been collected: its chain -- tracker included -- is done, nothing reads the Features any more
   VO_HIP_TRY(ctx, hipMemcpyAsync((char*)p->feat_mem + (size_t)p->cur * p->feat_block, p->d_ckpt_feat, p->feat_block,
                                  hipMemcpyDeviceToDevice, st));
+  if (p->cfg.tracker_mode == 1)
+    VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_fdesc + (size_t)p->cur * p->cap * 128, p->d_ckpt_fdesc, (size_t)p->cap * 128,
+                                   hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(ctl_rewind_kernel, dim3(vo_cdiv(p->S, 64)), dim3(64), 0, st, p->d_ctl, p->d_ckpt_ctl, p->S);
   VO_TRY(vo_check_launch(ctx, "ctl_rewind_kernel"));
   // the next step's tracker waits for "the previous step's regroup": that event now stands for the restored state
@@ -1138,6 +1259,20 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   // The detection of `next` (half of the step's launches, needed only by the NEXT step) goes to the worker thread;
   // this thread enqueues the pyramid, the tracker and the main-stream chain.  The tracker waits for the event behind
   // the detection of `prev`: the worker must have recorded it (it was posted a whole step ago).
+  if (c.tracker_mode == 1) {
+    VO_TRY(enqueue_sift(p, f));
+    VO_TRY(ensure_raws(p, 0));
+    VO_TRY(enqueue_chain_sift(p, f, false, f.seq));
+    p->slot_seq[(size_t)f.rslot] = f.seq;
+    p->flight[p->n_flight++] = f;
+    ++p->steps_submitted;
+    p->slot = f.b;
+    p->cur = 1 - f.fcur;
+    p->prev_frame = next_idx;
+    p->dbg_submit += now_s() - t_in;
+    ++p->dbg_steps;
+    return VO_OK;
+  }
   double tq = now_s();
   // WHEN the detection's seven launches reach the GPU matters more than who makes them.  Arriving beside the hypothesis
   // kernel -- the worker used to get them at the start of submit -- they cost that kernel 20 us (hypotheses -> pose 43 us
@@ -1280,7 +1415,7 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
   // when the fault came from the pose kernel (a possibly rejected draw, an unfinished loop): the tracker below would
   // redo only the first n2 features, and the rest of d_next would be whatever the next step's tracker left there --
   // the step's own values unless that one appended a detection (found by tests/pipeline_fuzz.py, now and then).
-  VO_HIP_TRY(ctx, mcpy(st, &ctl->n2, &h.n, 4, hipMemcpyHostToDevice));
+  if (c.tracker_mode == 0) VO_HIP_TRY(ctx, mcpy(st, &ctl->n2, &h.n, 4, hipMemcpyHostToDevice));
   // tracker and regroup of this sequence alone, without the forced fault.  A regroup that needs the detector's keypoints
   // of `prev` and finds that the detection was skipped (the tracks fell through the margin within one frame -- the
   // fault this step came with, or one that another fault had hidden) says so: the keypoints are made now, once more.
@@ -1297,8 +1432,12 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
       const int one = 1;
       VO_HIP_TRY(ctx, mcpy(st, p->d_det_go + (size_t)f.a * p->S + q, &one, 4, hipMemcpyHostToDevice));
     }
-    VO_TRY(enqueue_tracker(p, f, false, q, 1));
-    VO_TRY(enqueue_chain(p, f, true, 0, q, 1, 0u));
+    if (c.tracker_mode == 1) {
+      VO_TRY(enqueue_chain_sift(p, f, true, 0u));      // (the frame's keypoints and descriptors are still in their slot)
+    } else {
+      VO_TRY(enqueue_tracker(p, f, false, q, 1));
+      VO_TRY(enqueue_chain(p, f, true, 0, q, 1, 0u));
+    }
     VO_HIP_TRY(ctx, hipStreamSynchronize(st));
     VO_HIP_TRY(ctx, mcpy(st, &h, ctl, sizeof(h), hipMemcpyDeviceToHost));
     if (!(h.fault & VO_FAULT_NO_DETECTION) || attempt > 0) break;
@@ -1456,6 +1595,10 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
         const unsigned seq = ++p->seq;
         p->slot_seq[(size_t)p->flight[k].rslot * p->S + q] = seq;
         rc = ensure_raws(p, q);
+        if (p->cfg.tracker_mode == 1) {
+          if (rc == VO_OK) rc = enqueue_chain_sift(p, p->flight[k], false, seq);
+          continue;
+        }
         if (rc == VO_OK) rc = enqueue_tracker(p, p->flight[k], false, q, 1);
         if (rc == VO_OK) rc = enqueue_chain(p, p->flight[k], false, 0, q, 1, seq);
       }

@@ -780,6 +780,200 @@ __global__ void overflow_kernel(const unsigned* cnt, unsigned cap_cand, unsigned
   if (cnt[C_CAND] > cap_cand || cnt[C_SURV] > cap_kp || cnt[C_KP] > cap_kp) *flag = 1u;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The final order of the described rows on the device (what vo_sift's host tail does with std::sort): sort by
+// (x, y, size desc, angle, response desc, octave desc) -- KeyPointsFilter::removeDuplicatedSorted's order --, drop rows
+// that repeat the previous row's (x, y, size, angle), keep the `cap` strongest by response when more are left
+// (KeyPointsFilter::retainBest: everything above the cap-th response, ties in order), write keypoints and descriptors
+// compactly in that order.  One workgroup: a bitonic sort of (128-bit key, row) pairs in LDS -- rows whose four leading
+// fields tie are settled on the rest of the row from memory --, flags and scans over the sorted order.
+constexpr int FIN_T = 1024;
+constexpr int FIN_MAX = 4096;          // rows the finalize kernel orders (the capped path describes cap + ties rows)
+
+__device__ __forceinline__ unsigned order_bits(float v) {          // order-preserving float -> uint
+  const unsigned b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// full comparison of two rows whose (x, y, size, angle) are equal: response desc, octave desc, then the descriptors'
+// bytes in memory order (what the host's memcmp sees), then the row number -- a strict total order
+__device__ bool row_tie_less(const float* __restrict__ rows, unsigned a, unsigned b) {
+  const float* ra = rows + (size_t)a * 134;
+  const float* rb = rows + (size_t)b * 134;
+  if (ra[4] != rb[4]) return ra[4] > rb[4];
+  if (ra[5] != rb[5]) return ra[5] > rb[5];
+  for (int k = 6; k < 134; ++k) {
+    const unsigned wa = __builtin_bswap32(__float_as_uint(ra[k])), wb = __builtin_bswap32(__float_as_uint(rb[k]));
+    if (wa != wb) return wa < wb;
+  }
+  return a < b;
+}
+
+// exclusive scan of up to four flags per thread in sorted-position order (position = 4 * tid + k); returns the block total
+__device__ __forceinline__ unsigned block_scan4(const unsigned (&f)[4], unsigned (&excl)[4], unsigned* s_wave /*[16]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned mine = f[0] + f[1] + f[2] + f[3];
+  unsigned inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  unsigned base = 0, total = 0;
+  for (int w = 0; w < FIN_T / 64; ++w) {
+    const unsigned v = s_wave[w];
+    if (w < wv) base += v;
+    total += v;
+  }
+  unsigned run = base + inc - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    excl[k] = run;
+    run += f[k];
+  }
+  return total;
+}
+
+__global__ __launch_bounds__(FIN_T) void sift_finalize_kernel(const float* __restrict__ rows, const unsigned* __restrict__ n_rows,
+                                                              int cap, float* __restrict__ kp_out, float* __restrict__ desc_out,
+                                                              uint8_t* __restrict__ desc_bytes, int* __restrict__ n_out,
+                                                              unsigned* __restrict__ overflow) {
+  extern __shared__ __align__(16) unsigned s_fin[];
+  unsigned* s_key = s_fin;                       // [FIN_MAX][4]
+  unsigned* s_row = s_key + 4 * FIN_MAX;         // [FIN_MAX] row number at this sorted position
+  __shared__ unsigned s_wave[FIN_T / 64];
+  __shared__ unsigned s_count;
+  const int tid = threadIdx.x;
+  const unsigned n = *n_rows;
+  if (n > (unsigned)FIN_MAX) {
+    if (tid == 0) {
+      *overflow = 1u;
+      *n_out = 0;
+    }
+    return;
+  }
+  unsigned N = 1;
+  while (N < n) N <<= 1;
+  if (N < 2) N = 2;
+  for (unsigned i = tid; i < N; i += FIN_T) {
+    if (i < n) {
+      const float* r = rows + (size_t)i * 134;
+      s_key[4 * i] = order_bits(r[0]);
+      s_key[4 * i + 1] = order_bits(r[1]);
+      s_key[4 * i + 2] = ~order_bits(r[2]);
+      s_key[4 * i + 3] = order_bits(r[3]);
+      s_row[i] = i;
+    } else {
+      s_key[4 * i] = s_key[4 * i + 1] = s_key[4 * i + 2] = s_key[4 * i + 3] = 0xffffffffu;
+      s_row[i] = 0xffffffffu;                   // padding: behind every row
+    }
+  }
+  __syncthreads();
+  auto less = [&](unsigned a, unsigned b) -> bool {      // sorted positions a, b
+    const uint4 ka = *reinterpret_cast<const uint4*>(s_key + 4 * a), kb = *reinterpret_cast<const uint4*>(s_key + 4 * b);
+    if (ka.x != kb.x) return ka.x < kb.x;
+    if (ka.y != kb.y) return ka.y < kb.y;
+    if (ka.z != kb.z) return ka.z < kb.z;
+    if (ka.w != kb.w) return ka.w < kb.w;
+    const unsigned ra = s_row[a], rb = s_row[b];
+    if (ra == 0xffffffffu || rb == 0xffffffffu) return ra < rb;     // (padding: never before a row)
+    return row_tie_less(rows, ra, rb);
+  };
+  for (unsigned k = 2; k <= N; k <<= 1) {
+    for (unsigned j = k >> 1; j > 0; j >>= 1) {
+      for (unsigned t = tid; t < N / 2; t += FIN_T) {
+        const unsigned i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+        const bool up = (i & k) == 0;
+        if (less(p, i) == up) {
+          const uint4 ki = *reinterpret_cast<const uint4*>(s_key + 4 * i), kp2 = *reinterpret_cast<const uint4*>(s_key + 4 * p);
+          *reinterpret_cast<uint4*>(s_key + 4 * i) = kp2;
+          *reinterpret_cast<uint4*>(s_key + 4 * p) = ki;
+          const unsigned ri = s_row[i];
+          s_row[i] = s_row[p];
+          s_row[p] = ri;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // sorted: position 4 * tid + k.  kept = not a repeat of the previous row's four leading fields
+  unsigned keep[4], pos[4];
+  float resp[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned sidx = 4u * tid + k;
+    keep[k] = 0;
+    resp[k] = 0.f;
+    if (sidx < n) {
+      bool dup = false;
+      if (sidx > 0) {
+        const uint4 a = *reinterpret_cast<const uint4*>(s_key + 4 * sidx), b = *reinterpret_cast<const uint4*>(s_key + 4 * (sidx - 1));
+        dup = a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+      }
+      keep[k] = dup ? 0u : 1u;
+      resp[k] = rows[(size_t)s_row[sidx] * 134 + 4];
+    }
+  }
+  unsigned n_keep = block_scan4(keep, pos, s_wave);
+  if ((int)n_keep > cap && cap > 0) {
+    // the cap-th largest response among the kept rows: the largest bit pattern v with #(resp >= v) >= cap
+    // (responses are positive: their bit patterns order like the values)
+    unsigned lo = 0u, hi = 0x7f800000u;          // invariant: count_ge(lo) >= cap > count_ge(hi + 1)
+    while (lo < hi) {
+      const unsigned mid = lo + (hi - lo + 1) / 2;
+      if (tid == 0) s_count = 0;
+      __syncthreads();
+      unsigned c = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c += (keep[k] && __float_as_uint(resp[k]) >= mid) ? 1u : 0u;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+      if ((tid & 63) == 0 && c) atomicAdd(&s_count, c);
+      __syncthreads();
+      const unsigned total = s_count;
+      __syncthreads();
+      if (total >= (unsigned)cap) lo = mid;
+      else hi = mid - 1;
+    }
+    const float thr = __uint_as_float(lo);
+    unsigned above[4], tie[4], tpos[4], dummy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      above[k] = (keep[k] && resp[k] > thr) ? 1u : 0u;
+      tie[k] = (keep[k] && resp[k] == thr) ? 1u : 0u;
+    }
+    const unsigned n_above = block_scan4(above, dummy, s_wave);
+    (void)block_scan4(tie, tpos, s_wave);
+    const unsigned ties = (unsigned)cap - n_above;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) keep[k] = (above[k] || (tie[k] && tpos[k] < ties)) ? 1u : 0u;
+    n_keep = block_scan4(keep, pos, s_wave);
+  }
+  // destination -> row, then the copy by everybody
+  __syncthreads();
+  unsigned* s_src = s_key;                        // (the keys are done)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned sidx = 4u * tid + k;
+    if (keep[k]) s_src[pos[k]] = s_row[sidx];
+  }
+  __syncthreads();
+  if (tid == 0) *n_out = (int)n_keep;
+  for (unsigned e = tid; e < n_keep * 134u; e += FIN_T) {
+    const unsigned d = e / 134u, c = e - d * 134u;
+    const float v = rows[(size_t)s_src[d] * 134 + c];
+    if (c < 6) {
+      kp_out[(size_t)d * 6 + c] = v;
+    } else {
+      if (desc_out) desc_out[(size_t)d * 128 + (c - 6)] = v;
+      if (desc_bytes) desc_bytes[(size_t)d * 128 + (c - 6)] = (uint8_t)v;     // (whole numbers 0..255 by construction)
+    }
+  }
+}
+
 taps_t make_taps(double sigma) {
   taps_t t;
   const int ks = (int)std::lrint(sigma * 8 + 1) | 1;
@@ -817,13 +1011,10 @@ int vo_sift_capacity(int H, int W) {
   return (int)(c < 65536 ? 65536 : (c > (1 << 20) ? (1 << 20) : c));
 }
 
-int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_out, float* desc_out, int32_t* n_out) {
-  if (!ctx) return VO_EINVAL;
-  VO_REQUIRE(ctx, img && kp_out && desc_out && n_out, "sift: null pointer");
-  VO_REQUIRE(ctx, H >= 16 && W >= 16, "sift: bad arguments");
-  if (cap <= 0) cap = vo_sift_capacity(H, W);   // keep every keypoint, as cv2.SIFT_create() (nfeatures = 0) does
-  *n_out = 0;
-  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+// Everything up to the described rows, enqueued on the context's stream (no host synchronisation): d_img is the frame in
+// device memory; the rows (134 floats each: x, y, size, angle, response, octave, 128 descriptor values) are left in the
+// context's scratch[3], their count in scratch[2][C_SEL], an overflow flag in scratch[2][C_OVER].
+static int sift_enqueue(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap) {
   hipStream_t st = ctx->stream;
   const float sigma = 1.6f, contrast_thr = 0.04f, edge_thr = 10.f;
   const int W0 = 2 * W, H0 = 2 * H;
@@ -849,7 +1040,6 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
     }
   }
   const unsigned cap_kp = (unsigned)vo_sift_capacity(H, W), cap_cand = 4u * cap_kp;
-  VO_TRY(vo_ensure(ctx, ctx->img, (size_t)H * W));
   VO_TRY(vo_ensure(ctx, ctx->sift_arena, total * 4));
   unsigned table_len = 1;
   while (table_len < 4u * cap_kp) table_len <<= 1;
@@ -860,10 +1050,6 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
   VO_TRY(vo_ensure(ctx, ctx->scratch[4], (size_t)cap_kp * sizeof(surv_t)));
   VO_TRY(vo_ensure(ctx, ctx->scratch[5], (size_t)table_len * 8));
   VO_TRY(vo_ensure(ctx, ctx->scratch[6], (size_t)cap_kp * 4));
-  // through the context's pinned staging buffer: a DMA each way instead of the runtime's pageable-memory path
-  VO_TRY(vo_ensure_pinned(ctx, (size_t)H * W));
-  memcpy(ctx->h_pin, img, (size_t)H * W);
-  VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, ctx->h_pin, (size_t)H * W, hipMemcpyHostToDevice, st));
   unsigned* d_cnt = (unsigned*)ctx->scratch[2].p;   // counters of this call, see C_CAND ..
   VO_HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 64, st));
   VO_HIP_TRY(ctx, hipMemsetAsync(ctx->scratch[5].p, 0, (size_t)table_len * 8, st));
@@ -927,7 +1113,7 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
     vo_prof_scope ps(ctx, VO_K_SIFT_SCALESPACE);
     // base image: doubled, blurred to sigma
     float* up = const_cast<float*>(oct[0].g[1]);   // scratch until g[1] is produced
-    hipLaunchKernelGGL(upsample2_kernel, grid2(W0, H0), dim3(256), 0, st, (const uint8_t*)ctx->img.p, H, W, up);
+    hipLaunchKernelGGL(upsample2_kernel, grid2(W0, H0), dim3(256), 0, st, d_img, H, W, up);
     blur(st, up, H0, W0, taps[0], const_cast<float*>(oct[0].g[0]));
     // the dependent chain first, the side work behind it.  (The host's launch rate, ~6 us per call, is what the small
     // octaves wait for; the same ~75 launches captured once and replayed with hipGraphLaunch were no faster: 552
@@ -978,7 +1164,71 @@ int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_ou
     vo_prof_scope ps(ctx, VO_K_SIFT_DESCRIBE);
     hipLaunchKernelGGL(descriptor_kernel, dim3(2048), dim3(DESC_T), 0, st, P, d_kps, d_sel, d_cnt + C_SEL, d_rows);
   }
-  VO_TRY(vo_check_launch(ctx, "sift descriptor_kernel"));
+  return vo_check_launch(ctx, "sift descriptor_kernel");
+}
+
+// the final order on the device (sift_finalize_kernel): rows -> d_kp (cap x 6), d_desc (cap x 128 float, nullable),
+// d_desc_u8 (cap x 128 bytes, nullable), d_n
+static int sift_finalize(vo_ctx* ctx, int cap, float* d_kp, float* d_desc, uint8_t* d_desc_u8, int* d_n) {
+  static const size_t lds = (size_t)FIN_MAX * 20;
+  static bool opted[64] = {false};
+  if (ctx->device >= 0 && ctx->device < 64 && !opted[ctx->device]) {
+    VO_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&sift_finalize_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    opted[ctx->device] = true;
+  }
+  unsigned* d_cnt = (unsigned*)ctx->scratch[2].p;
+  hipLaunchKernelGGL(sift_finalize_kernel, dim3(1), dim3(FIN_T), lds, ctx->stream, (const float*)ctx->scratch[3].p,
+                     d_cnt + C_SEL, cap, d_kp, d_desc, d_desc_u8, d_n, d_cnt + C_OVER);
+  return vo_check_launch(ctx, "sift_finalize_kernel");
+}
+
+int vo_sift_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap, float* d_kp, float* d_desc, uint8_t* d_desc_u8,
+                int32_t* d_n) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, d_img && d_kp && d_n && (d_desc || d_desc_u8), "sift_dev: null pointer");
+  VO_REQUIRE(ctx, H >= 16 && W >= 16, "sift_dev: bad arguments");
+  VO_REQUIRE(ctx, cap >= 1 && cap <= FIN_MAX - 96, "sift_dev: cap must be in 1..%d", FIN_MAX - 96);
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  VO_TRY(sift_enqueue(ctx, d_img, H, W, cap));
+  return sift_finalize(ctx, cap, d_kp, d_desc, d_desc_u8, d_n);
+}
+
+int vo_sift(vo_ctx* ctx, const uint8_t* img, int H, int W, int cap, float* kp_out, float* desc_out, int32_t* n_out) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, img && kp_out && desc_out && n_out, "sift: null pointer");
+  VO_REQUIRE(ctx, H >= 16 && W >= 16, "sift: bad arguments");
+  const bool capped = cap > 0 && cap <= FIN_MAX - 96;      // the order, duplicates and cap on the device (rows: cap + ties)
+  if (cap <= 0) cap = vo_sift_capacity(H, W);   // keep every keypoint, as cv2.SIFT_create() (nfeatures = 0) does
+  *n_out = 0;
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  // through the context's pinned staging buffer: a DMA each way instead of the runtime's pageable-memory path
+  VO_TRY(vo_ensure(ctx, ctx->img, (size_t)H * W));
+  VO_TRY(vo_ensure_pinned(ctx, (size_t)H * W));
+  memcpy(ctx->h_pin, img, (size_t)H * W);
+  VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, ctx->h_pin, (size_t)H * W, hipMemcpyHostToDevice, st));
+  VO_TRY(sift_enqueue(ctx, (const uint8_t*)ctx->img.p, H, W, cap));
+  unsigned* d_cnt = (unsigned*)ctx->scratch[2].p;
+  float* d_rows = (float*)ctx->scratch[3].p;
+  if (capped) {
+    // final rows made on the device: [n | kp cap x 6 | desc cap x 128] come back in one transfer
+    const size_t out_bytes = 16 + (size_t)cap * 134 * 4;
+    VO_TRY(vo_ensure(ctx, ctx->scratch[7], out_bytes));
+    char* d_out = (char*)ctx->scratch[7].p;
+    VO_TRY(sift_finalize(ctx, cap, (float*)(d_out + 16), (float*)(d_out + 16 + (size_t)cap * 24), nullptr, (int*)d_out));
+    VO_HIP_TRY(ctx, hipMemcpyAsync(d_out + 4, d_cnt + C_OVER, 4, hipMemcpyDeviceToDevice, st));
+    VO_TRY(vo_ensure_pinned(ctx, out_bytes));
+    VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pin, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int* head = (const int*)ctx->h_pin;
+    if (head[1]) return vo_set_error(ctx, VO_ECAPACITY, "sift: candidate / keypoint list overflow");
+    const int n = head[0];
+    memcpy(kp_out, (const char*)ctx->h_pin + 16, (size_t)n * 24);
+    memcpy(desc_out, (const char*)ctx->h_pin + 16 + (size_t)cap * 24, (size_t)n * 512);
+    *n_out = n;
+    return VO_OK;
+  }
   unsigned cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   VO_HIP_TRY(ctx, hipMemcpyAsync(cnt, d_cnt, 32, hipMemcpyDeviceToHost, st));
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));

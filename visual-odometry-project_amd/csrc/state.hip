@@ -100,11 +100,18 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
                                                              const uint8_t* __restrict__ status,
                                                              const float* __restrict__ err, float err_thr,
                                                              const int* __restrict__ pairs, int M,
-                                                             const double* __restrict__ new_kp, int n2_in, int cap) {
+                                                             const double* __restrict__ new_kp, int n2_in, int cap,
+                                                             const int* __restrict__ d_M = nullptr,
+                                                             const int* __restrict__ d_n2 = nullptr,
+                                                             int* __restrict__ src_row = nullptr) {
   __shared__ unsigned long long s_wave[RG_T / 64 + 1];
   __shared__ unsigned s_matched[PAIRS ? 1024 : 1];   // bit per new keypoint (capacity 32768)
   if (ctl->fault) return;
   const int tid = threadIdx.x;
+  if (PAIRS && d_M) {                  // counts that live on the device (SIFT tracker mode of the frame pipeline)
+    M = *d_M;
+    n2_in = min(*d_n2, cap);
+  }
   const int n_items = PAIRS ? M : ctl->n_in;
   const int per = (n_items + RG_T - 1) / RG_T;
   const int j0 = tid * per, j1 = min(j0 + per, n_items);
@@ -148,6 +155,7 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
       x = (double)next_xy[2 * j];
       y = (double)next_xy[2 * j + 1];
     }
+    if (PAIRS && src_row) src_row[pos[key]] = pairs[2 * j + 1];      // (which new keypoint ended up at this place)
     write_group(A, B, key, src, pos[key]++, x, y);
   }
   int n2 = T0 + T1 + T2;
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
       B.track[2 * p + 1] = y;
 #pragma unroll
       for (int q = 0; q < 12; ++q) B.pose[(size_t)q * B.pitch + p] = nan;
+      if (src_row) src_row[p] = k;
       ++p;
     }
     n2 += (int)tot2;
@@ -183,6 +192,11 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
     ctl->n_tri = T0;
     ctl->n_mat = T1;
     ctl->n_new = T2;
+    if (PAIRS && d_M) {
+      ctl->n_in = n2_in;               // (the record's "features in": the new frame's keypoints)
+      ctl->redetected = 0;
+      ctl->det_ran = 0;
+    }
     int fault = 0;
     if (!PAIRS && T0 < 8) fault = VO_FAULT_FEW_LANDMARKS;   // (population below what the device-side sampler handles)
     ctl->n_p3p = fault ? 0 : T0;
@@ -502,12 +516,14 @@ int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, con
 }
 
 int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const int32_t* d_pairs, int M,
-                           const double* d_new_kp, int n2_in, int cap) {
+                           const double* d_new_kp, int n2_in, int cap, const int32_t* d_M, const int32_t* d_n2,
+                           int32_t* d_src_row) {
   VO_REQUIRE(ctx, cap <= RG_T * RG_MAX_PER && n2_in <= cap && M <= cap, "state_regroup: capacity exceeded");
   {
     vo_prof_scope ps(ctx, VO_K_STATE_REGROUP);
     hipLaunchKernelGGL(state_regroup_kernel<true>, dim3(1), dim3(RG_T), 0, ctx->stream, ctl, A, B, (const float*)nullptr,
-                       (const uint8_t*)nullptr, (const float*)nullptr, 0.f, d_pairs, M, d_new_kp, n2_in, cap);
+                       (const uint8_t*)nullptr, (const float*)nullptr, 0.f, d_pairs, M, d_new_kp, n2_in, cap,
+                       (const int*)d_M, (const int*)d_n2, (int*)d_src_row);
   }
   return vo_check_launch(ctx, "state_regroup_kernel");
 }

@@ -147,6 +147,10 @@ int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x
                                int Hyp, double thr_sq, double* d_R, double* d_t, uint8_t* d_valid, int32_t* d_counts,
                                uint64_t* d_masks, uint32_t* d_flag, uint64_t* d_ts = nullptr,
                                const vo_hyp_batch* batch = nullptr);
+// SIFT tracker mode of the frame pipeline: device-resident detect + describe (sift.hip: extern "C" vo_sift_dev) and
+// matching (match.hip)
+extern "C" int vo_match_u8_dev(vo_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, int cap_q, const uint8_t* d_t,
+                               const int32_t* d_nt, int cap_t, double ratio, int32_t* d_pairs, int32_t* d_npairs);
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
 void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
 // DLT with a device-resident point count (dlt.hip)

@@ -150,8 +150,11 @@ int vo_frame_pose(vo_ctx* ctx, const vo_pose_job& job, int S = 1);   // S > 1: s
 int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const float* d_next_xy,
                          const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap, int S = 1);
 // matches.py:26-212 for an explicit match list (harris / sift trackers, tests)
+// d_M / d_n2 (optional): the pair count and the new frame's keypoint count read on the device (M and n2_in are then the
+// capacities); d_src_row (optional, cap ints): for every feature written to B, the new keypoint it is
 int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const int32_t* d_pairs, int M,
-                           const double* d_new_kp, int n2_in, int cap);
+                           const double* d_new_kp, int n2_in, int cap, const int32_t* d_M = nullptr,
+                           const int32_t* d_n2 = nullptr, int32_t* d_src_row = nullptr);
 // main.py:261-268 + state.py:17-50, 135-219: pose, outliers, bearing-angle candidates
 int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
                         double bearing_thr, int use_refined, int cap);

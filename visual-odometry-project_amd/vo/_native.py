@@ -69,7 +69,8 @@ class PipelineConfig(C.Structure):
                 ("K", C.c_double * 9), ("Kinv", C.c_double * 9), ("refine_iters", C.c_int32), ("feature_cap", C.c_int32),
                 ("bearing_threshold", C.c_double), ("redetect_fraction", C.c_double),
                 ("debug_fault_every", C.c_int32), ("redetect_start_pose", C.c_int32), ("detect_margin", C.c_double),
-                ("debug_never_detect", C.c_int32), ("detect_losses", C.c_double), ("sequences", C.c_int32)]
+                ("debug_never_detect", C.c_int32), ("detect_losses", C.c_double), ("sequences", C.c_int32),
+                ("tracker_mode", C.c_int32), ("sift_cap", C.c_int32), ("match_ratio", C.c_double)]
 
 
 class StepResult(C.Structure):
@@ -134,6 +135,7 @@ _SIGS = {
     "vo_min_eigen_map": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vo_sift": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "vo_sift_capacity": (_i, [_i, _i]),
+    "vo_sift_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "vo_fundamental_hypotheses": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
     "vo_fundamental_fit": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp]),
     "vo_essential_decompose": (_i, [_vp, _vp, _vp]),
@@ -150,6 +152,7 @@ _SIGS = {
     "vo_record_seal": (None, [_vp, C.c_uint]),
     "vo_record_check": (_i, [_vp, C.c_uint]),
     "vo_pipeline_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "vo_pipeline_set_descriptors": (_i, [_vp, _vp, _i]),
     "vo_pipeline_checkpoint": (_i, [_vp]),
     "vo_pipeline_rewind": (_i, [_vp]),
     "vo_pipeline_destroy": (None, [_vp]),
@@ -438,10 +441,16 @@ class Context:
         self._chk(self._lib.vo_fundamental_hypotheses(self._h, _ptr(p1), _ptr(p2), n, _ptr(samples), h,
                                                       int(bool(normalize_samples)), int(error_kind), float(threshold),
                                                       _ptr(F), _ptr(counts), _ptr(masks)))
+        if want_masks == "packed":          # (rows of 64-bit words; Context.unpack_mask(row, n) opens one)
+            return F, counts, masks
         if want_masks:
             bits = np.unpackbits(masks.view(np.uint8).reshape(h, words * 8), axis=1, bitorder="little")[:, :n]
             return F, counts, bits.astype(bool)
         return F, counts
+
+    @staticmethod
+    def unpack_mask(row, n):
+        return np.unpackbits(np.ascontiguousarray(row).view(np.uint8), bitorder="little")[:n].astype(bool)
 
     def fundamental_fit(self, p1, p2, mask=None, normalize=True):
         """The 8-point fit over all (masked) correspondences: F (3, 3)."""

@@ -87,8 +87,8 @@ class LandmarksTriangulator:
 
         def batch_fn(samples):
             F, counts, masks = ctx.fundamental_hypotheses(points1, points2, samples, threshold, normalize_samples, error_kind,
-                                                          want_masks=True)
-            return np.ones(len(samples), np.uint8), counts, lambda b: (F[b], masks[b])
+                                                          want_masks="packed")
+            return np.ones(len(samples), np.uint8), counts, lambda b: (F[b], ctx.unpack_mask(masks[b], n))
 
         _, inliers, _ = ransac.find_best_model_batched(n, batch_fn, batch_size=batch_size)
         F = ctx.fundamental_fit(points1, points2, inliers, normalize=normalize_samples)   # ransac.py:123-127
