@@ -277,83 +277,124 @@ def api_leg(ctx):
 
 
 def cfg3_main(args):
-    """VO_BENCH_CONFIG=cfg3: BASELINE.json configs[2] -- per frame SIFT detect + describe (cap 2000) on a 1376x1241
-    frame and brute-force L2 2-NN + ratio + uniqueness matching against the previous frame's descriptors
-    (src/vo/features/sift.py:23-56), through the C ABI's host entry points (vo_sift / vo_match_knn2_ratio: the frame
-    goes over PCIe once, keypoints and descriptors come back).  A secondary line: the default run stays cfg-2."""
+    """VO_BENCH_CONFIG=cfg3: BASELINE.json configs[2] -- the same stream with SIFT detect + describe (cap 2000) and
+    brute-force L2 2-NN + ratio + uniqueness matching in place of KLT (src/vo/features/tracker.py:60-61, sift.py:23-56),
+    as a device-resident loop (vo_pipeline_config.tracker_mode = 1): images in, pose records out; descriptors, pair
+    lists, Features and State never leave HBM.  A secondary line: the default run stays cfg-2."""
+    from vo import synthetic
+    stream = synthetic.Stream(N_FRAMES, H, W).prefetch(workers=RENDER_WORKERS)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    from vo import _native, synthetic
+    from vo import _native, driver
+    from vo.features.sift import SIFTDetector
     ctx = _native.Context(0)
-    need = args.warmup + args.steps + 8 + 1
-    stream = synthetic.Stream(N_FRAMES, H, W).prefetch(range(min(need, N_FRAMES)), workers=RENDER_WORKERS)
-    order = [k % N_FRAMES for k in range(need)]          # forward; a run longer than the stream starts over at frame 0
-    state = {"desc": ctx.sift(stream.image(order[0]), cap=2000)[1], "pos": 0}
-    counts = []
-
-    host = {"sift": 0.0, "match": 0.0, "n": 0}
-
-    def run(n):
-        for _ in range(n):
-            state["pos"] += 1
-            t_a = time.perf_counter()
-            _, d = ctx.sift(stream.image(order[state["pos"]]), cap=2000)
-            t_b = time.perf_counter()
-            pairs = ctx.match_knn2_ratio(state["desc"], d, 0.8)
-            host["match"] += time.perf_counter() - t_b
-            host["sift"] += t_b - t_a
-            host["n"] += 1
-            counts.append((len(d), len(pairs)))
-            state["desc"] = d
-
-    run(args.warmup)
+    _native.set_default_context(ctx)
+    CAP = 2000
+    saved = SIFTDetector._max_keypoints
+    SIFTDetector._max_keypoints = CAP
+    try:
+        state, _, _, _ = driver.bootstrap(ResidentSequence(stream), "sift", ransac_threshold=1.0)
+    finally:
+        SIFTDetector._max_keypoints = saved
+    feats = state.curr_frame.features
+    pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=CAP, hyp=HYP_LAUNCH, p3p_threshold=1.0, outlier_ratio=0.9,
+                            confidence=0.99, max_iterations=HYP, refine_iters=REFINE_ITERS, tracker="sift", sift_cap=CAP)
+    for i in range(N_FRAMES):
+        pipe.set_frame(i, stream.image(i))
+    pipe.set_state(PASS_START, feats, state.curr_pose, state.prev_pose, num_features=CAP)
+    pipe.checkpoint()
+    walker = Walker(pipe, N_FRAMES)
+    first_pass = []
+    ORACLE_FRAMES = 3
+    walker.run(ORACLE_FRAMES, lookahead=False, on_step=lambda b, rs: first_pass.append((b, rs[0])))
+    first_state = pipe.get_state()
+    walker.run(N_FRAMES - 1 - PASS_START - ORACLE_FRAMES, lookahead=False, on_step=lambda b, rs: first_pass.append((b, rs[0])))
+    walker.run(args.warmup)
     ctx.prof_enable(-1)
-    ctx.prof_reset()
-    run(8)
+    pipe.prof_reset()
+    walker.run(8)
     per = {}
     for kid in range(_native.K_COUNT):
-        ms, n = ctx.prof_read(kid)
+        ms, n = pipe.prof_read(kid)
         if n:
             per[ctx.kernel_name(kid)] = ms / n * 1e3
     ctx.prof_disable()
+    recs = []
     ctx.sync()
     t0 = time.perf_counter()
-    run(args.steps)
+    walker.run(args.steps, on_step=lambda b, rs: recs.extend(rs))
     ctx.sync()
     dt = time.perf_counter() - t0
-    px = H * W
-    # SURVEY 8d: scale space = base 4px f32; per octave 6 Gaussian + 5 DoG writes and equal reads at 4px / 4^o
-    ss_bytes = (4 * px * 4) * (4.0 / 3.0) * 22
-    ss_us = per.get("sift_scale_space")
-    n_desc = int(np.median([c[0] for c in counts]))
-    flops = 2.0 * n_desc * n_desc * 128
-    m_us = per.get("match_knn2")
+    st = loop_stats(recs)
+    # ground truth over the first pass; oracle of the same loop on its first frames (also the CPU baseline)
+    scale = 2 * synthetic.STEP_Z / max(np.linalg.norm(state.curr_pose[:3, 3]), 1e-12)
+    gt_err = []
+    for b, r in first_pass:
+        Twc = r.pose_world_cam()
+        gt = np.linalg.inv(stream.T_world_cam(0)) @ stream.T_world_cam(b)
+        gt_err.append((float(np.linalg.norm(Twc[:3, :3] - gt[:3, :3])), float(np.linalg.norm(scale * Twc[:3, 3] - gt[:3, 3]))))
     out = {"metric": "VO frames/sec at 1376x1241, 2k keypoints; pose err vs reference", "value": round(args.steps / dt, 2),
            "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "cfg-3: 1376x1241 synthetic stream, per frame SIFT detect + describe (2000 strongest) and "
-                                  "brute-force L2 2-NN + 0.8 ratio + uniqueness against the previous frame, host entry "
-                                  "points (PCIe-inclusive: 1.7 MB up, ~1 MB of keypoints / descriptors down per frame)",
-                      "keypoints": n_desc, "matches_median": int(np.median([c[1] for c in counts]))},
-           "roofline": {"bound": "hbm", "kernel": "sift_scale_space (upsample, fused row+column blurs, decimations; the octaves' last two layers and extrema searches on a second stream, inside the same bracket)",
-                        "avg_launch_us": None if ss_us is None else round(ss_us, 1), "algorithmic_bytes_per_launch": int(ss_bytes),
-                        "achieved": None if not ss_us else round(ss_bytes / (ss_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": None if not ss_us else round(ss_bytes / (ss_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                        "traffic": None},
-           # dense i8 MFMA peak: twice the bf16 rate (MI355X_MICROARCH.md, matrix cores) = 2 x 2.5 POP/s
-           "matcher": {"bound": "mfma", "kernel": "match_knn2 (v_mfma_i32_32x32x32_i8 on bytes offset by 128, exact integer distances)",
-                       "avg_launch_us": None if m_us is None else round(m_us, 1), "ops": flops,
-                       "achieved": None if not m_us else round(flops / (m_us * 1e-6) / 1e12, 2), "peak": 5000.0, "unit": "TOP/s",
-                       "frac": None if not m_us else round(flops / (m_us * 1e-6) / 1e12 / 5000.0, 5),
-                       "note": "2000 x 2000 x 128: 1 GOP, a launch of ~500 workgroups -- latency-bound, not MFMA-bound"},
+           "vs_baseline": None, "dtype": "f32 (SIFT) / u8 -> i32 (matching) / f64 (pose)", "data": "synthetic",
+           "config": {"workload": "cfg-3: %dx%d synthetic stream, %d frames strictly forward, per frame SIFT detect + describe (%d "
+                                  "strongest), brute-force L2 2-NN + 0.8 ratio + uniqueness against the current Features' "
+                                  "descriptors (v_mfma_i32_32x32x32_i8), Matches regroup from the pair list, P3P-RANSAC %d "
+                                  "iterations + device replay, pose refinement, State bookkeeping, candidate DLT; device-resident "
+                                  "(vo_pipeline tracker_mode = sift), frames resident in HBM" % (W, H, N_FRAMES, CAP, HYP),
+                      "keypoints": CAP, "frames_resident": N_FRAMES, "frame_lookahead": 1,
+                      "passes_started_in_timed_region": walker.passes},
+           "loop": dict(st, bootstrap_landmarks=int((feats.state == 2).sum())),
            "per_kernel_us": {k: round(v, 1) for k, v in sorted(per.items())},
-           "host_call_ms": {"vo_sift": round(1e3 * host["sift"] / max(host["n"], 1), 3),
-                            "vo_match_knn2_ratio": round(1e3 * host["match"] / max(host["n"], 1), 3),
-                            "note": "wall time of the two host entry points per frame, averaged over every call of the run "
-                                    "(the event-bracketed profiling pass included)"}}
+           "pose_err_vs_ground_truth": {"rot_fro_median": float(np.median([e[0] for e in gt_err])),
+                                        "trans_m_median": float(np.median([e[1] for e in gt_err])),
+                                        "trans_m_last": round(gt_err[-1][1], 3),
+                                        "trans_m_every_8th_frame": [round(e[1], 3) for e in gt_err[::8]],
+                                        "path_m": round((N_FRAMES - 1 - PASS_START) * synthetic.STEP_Z, 1), "frames": len(gt_err)}}
+    ss_us = per.get("sift_scale_space")
+    if ss_us:
+        ss_bytes = (4 * H * W * 4) * (4.0 / 3.0) * 22      # SURVEY 8d
+        out["roofline"] = {"bound": "hbm", "kernel": "sift_scale_space (upsample, fused row+column blurs, decimations; the octaves' "
+                           "last two layers and extrema searches on further streams, inside the same bracket)",
+                           "avg_launch_us": round(ss_us, 1), "algorithmic_bytes_per_launch": int(ss_bytes),
+                           "achieved": round(ss_bytes / (ss_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ss_bytes / (ss_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}
+    m_us = per.get("match_knn2")
+    if m_us:
+        flops = 2.0 * CAP * CAP * 128
+        out["matcher"] = {"bound": "mfma", "kernel": "match_knn2 (v_mfma_i32_32x32x32_i8 on bytes offset by 128, exact integer distances)",
+                          "avg_launch_us": round(m_us, 1), "ops": flops, "achieved": round(flops / (m_us * 1e-6) / 1e12, 2),
+                          "peak": 5000.0, "unit": "TOP/s", "frac": round(flops / (m_us * 1e-6) / 1e12 / 5000.0, 5),
+                          "note": "2000 x 2000 x 128: 1 GOP -- latency-bound, not MFMA-bound"}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from pipeline_oracle import OracleLoop
+        orc = OracleLoop(stream, CAP, WIN, MAX_LEVEL, refine_iters=REFINE_ITERS, tracker="sift")
+        orc.set_state(PASS_START, feats, state.curr_pose, state.prev_pose)
+        t1 = time.perf_counter()
+        refs = [orc.step(PASS_START + 1 + k) for k in range(ORACLE_FRAMES)]
+        cpu_s = time.perf_counter() - t1
+        dR = dtr = 0.0
+        exact = True
+        for ref, (_, r) in zip(refs, first_pass):
+            dR = max(dR, float(np.abs(np.array(r.R_refined).reshape(3, 3) - ref["R_ref"]).max()))
+            dtr = max(dtr, float(np.abs(np.array(r.t_refined) - ref["t_ref"]).max() / max(1.0, np.linalg.norm(ref["t_ref"]))))
+            exact &= (r.n_tracked, r.n_triangulated, r.n_inliers, r.draws_consumed, r.ransac_iterations, r.n_candidates,
+                      r.n_landmarks) == (ref["n_tracked"], ref["n_tri"], ref["n_inliers"], ref["draws"], ref["iters"],
+                                         ref["n_cand"], ref["n_landmarks"])
+        f = refs[-1]["features"]
+        exact &= bool(np.array_equal(first_state["keypoints"], f.keypoints.astype(np.float64)) and
+                      np.array_equal(first_state["state"], f.state) and
+                      np.array_equal(first_state["candidate_mask"], f.candidate_mask))
+        out["pose_vs_oracle"] = {"frames": ORACLE_FRAMES, "max_abs_dR": dR, "max_rel_dt": dtr,
+                                 "counts_keypoints_states_masks_exact": bool(exact),
+                                 "note": "vs the CPU oracle of the same loop (oracle/csrc/sift.c, match.c, p3p.c + the pinned "
+                                         "bookkeeping classes); parity unpinned vs OpenCV's SIFT / BFMatcher"}
+        out["cpu_baseline"] = {"value": ORACLE_FRAMES / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d frames through the CPU oracle of the loop, single thread, %.1f s" % (ORACLE_FRAMES, cpu_s)}
     print(json.dumps(out), flush=True)
+    pipe.close()
     ctx.close()
 
 

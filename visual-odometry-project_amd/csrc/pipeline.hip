@@ -91,7 +91,7 @@ struct vo_pipeline {
   volatile unsigned* h_seq = nullptr;
   unsigned* m_seq = nullptr;
   unsigned seq = 0;
-  struct flight_t { int prev_idx, next_idx, a, b, fcur, rslot; unsigned seq; long k; };
+  struct flight_t { int prev_idx, next_idx, a, b, fcur, rslot; unsigned seq; long k; unsigned sift_job; };
   flight_t flight[2];
   int n_flight = 0;
   long steps_submitted = 0;
@@ -138,6 +138,8 @@ struct vo_pipeline {
   // that a polling kernel can never keep the kernel it waits for from running.  After anything was enqueued again for
   // one sequence (host path, a continuing RANSAC loop, a rewind) the next submit also waits for the events.
   bool gates = false, gate_resync = false;
+  int sift_chain_pending = 0;        // SIFT mode: flights whose main-stream chain is not enqueued yet (their SIFT launches are
+                                     // being made by the worker; the chain follows at the next submit or at collect)
   flight_t jobs[4];
   int worker_rc = 0;
   char worker_err[256] = {0};
@@ -457,7 +459,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     // the mask costs more than it gives (16 sequences: -5 %).  VO_SIDE_CUS="lo-hi" overrides, "all" switches it off.
     const char* sc = getenv("VO_SIDE_CUS");
     std::string auto_mask;
-    if (!sc && p->S <= 2 && p->detect_limit >= 0.0 && !side) {
+    if (!sc && p->S <= 2 && p->detect_limit >= 0.0 && !side && cfg->tracker_mode == 0) {
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount >= 128) {
         auto_mask = "32-" + std::to_string(prop.multiProcessorCount - 1);
@@ -905,13 +907,27 @@ extern "C" int vo_sift_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int 
                            uint8_t* d_desc_u8, int32_t* d_n);
 
 // detect + describe of the step's new frame on the tracker's stream (it depends on the image only): slot f.b
-static int enqueue_sift(vo_pipeline* p, const vo_pipeline::flight_t& f) {
-  vo_ctx* trk = p->trk;
+// (The scale space of a frame is a chain of ~60 dependent launches, most of them on images too small to fill anything:
+//  consecutive frames alternate between two contexts -- the tracker's and, idle in this mode, the detection's -- each with
+//  its own streams and arena, so that two frames' chains are in flight side by side.  The launches are made by the worker
+//  thread; err_buf: its private error text.)
+static int enqueue_sift(vo_pipeline* p, const vo_pipeline::flight_t& f, char* err_buf = nullptr) {
+  static const bool one_ctx = getenv("VO_SIFT_ONE_CONTEXT") != nullptr;
+  vo_ctx* sc = ((f.k & 1) && !one_ctx) ? p->det : p->trk;
   const vo_pipeline_config& c = p->cfg;
-  const int rc = vo_sift_dev(trk, p->img(0, f.next_idx), c.H, c.W, p->sift_cap, p->d_skp + (size_t)f.b * p->sift_cap * 6, nullptr,
-                             p->d_sdesc + (size_t)f.b * p->sift_cap * 128, p->d_sn + f.b);
-  if (rc != VO_OK) return vo_set_error(p->ctx, rc, "sift: %s", vo_last_error(trk));
-  VO_HIP_TRY(p->ctx, hipEventRecord(p->evPyr[f.b], trk->stream));
+  int rc = VO_OK;
+  if (sc != p->trk && hipStreamWaitEvent(sc->stream, p->evImg[f.next_idx], 0) != hipSuccess) rc = VO_EHIP;   // (the upload)
+  if (rc == VO_OK)
+    rc = vo_sift_dev(sc, p->img(0, f.next_idx), c.H, c.W, p->sift_cap, p->d_skp + (size_t)f.b * p->sift_cap * 6, nullptr,
+                     p->d_sdesc + (size_t)f.b * p->sift_cap * 128, p->d_sn + f.b);
+  if (rc == VO_OK && hipEventRecord(p->evPyr[f.b], sc->stream) != hipSuccess) rc = VO_EHIP;
+  if (rc != VO_OK) {
+    if (err_buf) {
+      snprintf(err_buf, 256, "sift: %s", vo_last_error(sc));
+      return rc;
+    }
+    return vo_set_error(p->ctx, rc, "sift: %s", vo_last_error(sc));
+  }
   return VO_OK;
 }
 
@@ -969,7 +985,8 @@ static void worker_main(vo_pipeline* p) {
     }
     idle = 0;
     const vo_pipeline::flight_t j = p->jobs[seen & 3];
-    const int rc = enqueue_detection(p, j.next_idx, j.b, false, p->worker_err);
+    const int rc = p->cfg.tracker_mode == 1 ? enqueue_sift(p, j, p->worker_err)
+                                            : enqueue_detection(p, j.next_idx, j.b, false, p->worker_err);
     if (rc != VO_OK) p->worker_rc = rc;
     ++seen;
     p->job_done.store(seen, std::memory_order_release);
@@ -1235,6 +1252,30 @@ int vo_pipeline_get_detection(vo_pipeline* p, double* kp_xy) {
   return VO_OK;
 }
 
+}  // extern "C"
+
+// SIFT mode: enqueue the main-stream chains of the flights that do not have theirs yet (oldest first)
+// (in flight order, as far as their SIFT launches have been made -- by this thread, or by the worker: sift_job = the
+//  worker's job count that says so; must_reach: flights up to this index are waited for)
+static int sift_flush_chains(vo_pipeline* p, int must_reach = -1) {
+  while (p->sift_chain_pending > 0) {
+    const int k = p->n_flight - p->sift_chain_pending;
+    const vo_pipeline::flight_t& f = p->flight[k];
+    if (f.sift_job != 0 && (int)(p->job_done.load(std::memory_order_acquire) - f.sift_job) < 0) {
+      if (k > must_reach) break;
+      const unsigned want = f.sift_job;
+      wait_until(50e-6, [&] { return (int)(p->job_done.load(std::memory_order_acquire) - want) >= 0; });
+    }
+    VO_TRY(worker_check(p));
+    VO_TRY(ensure_raws(p, 0));
+    VO_TRY(enqueue_chain_sift(p, f, false, f.seq));
+    --p->sift_chain_pending;
+  }
+  return VO_OK;
+}
+
+extern "C" {
+
 int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   if (!p) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
@@ -1260,11 +1301,33 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   // this thread enqueues the pyramid, the tracker and the main-stream chain.  The tracker waits for the event behind
   // the detection of `prev`: the worker must have recorded it (it was posted a whole step ago).
   if (c.tracker_mode == 1) {
-    VO_TRY(enqueue_sift(p, f));
-    VO_TRY(ensure_raws(p, 0));
-    VO_TRY(enqueue_chain_sift(p, f, false, f.seq));
+    // The frame's ~75 SIFT launches go to the worker thread; this thread first gives the flight submitted before its
+    // main-stream chain (its SIFT launches are made by now), so the two threads' launches overlap across frames.
+    // Two threads make the launches, a frame each: even flights' go to the worker, odd flights' are made here (each
+    // thread on its own SIFT context, so that two frames' chains also run side by side on the GPU).
+    f.sift_job = 0;
+    if (p->threads_budget >= 2 && (f.k & 1) == 0) {
+      const unsigned my = p->job_posted.load(std::memory_order_relaxed);
+      if ((int)(p->job_done.load(std::memory_order_acquire) - my) >= 0) {       // (idle worker: its context's flags are ours)
+        p->trk->prof_on = ctx->prof_on;
+        p->trk->prof_kernel = ctx->prof_kernel;
+        p->trk->prof_every = ctx->prof_every;
+      }
+      f.sift_job = my + 1;
+      p->jobs[my & 3] = f;
+      p->job_posted.store(my + 1, std::memory_order_seq_cst);
+      if (p->worker_asleep.load(std::memory_order_seq_cst)) futex_wake(&p->job_posted);
+    } else {
+      vo_ctx* mine = (f.k & 1) ? p->det : p->trk;          // (budget 1: both contexts are this thread's)
+      mine->prof_on = ctx->prof_on;
+      mine->prof_kernel = ctx->prof_kernel;
+      mine->prof_every = ctx->prof_every;
+      VO_TRY(enqueue_sift(p, f));
+    }
     p->slot_seq[(size_t)f.rslot] = f.seq;
     p->flight[p->n_flight++] = f;
+    ++p->sift_chain_pending;
+    VO_TRY(sift_flush_chains(p));
     ++p->steps_submitted;
     p->slot = f.b;
     p->cur = 1 - f.fcur;
@@ -1572,6 +1635,7 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
   VO_REQUIRE(ctx, p->n_flight > 0, "pipeline_collect: nothing submitted");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const vo_pipeline::flight_t f = p->flight[0];
+  if (p->cfg.tracker_mode == 1) VO_TRY(sift_flush_chains(p, 0));
   {
     const double t_in = now_s();
     for (int q = 0; q < p->S; ++q)
@@ -1588,6 +1652,13 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
     }
     if (out->fault || was_open) {
       p->gate_resync = true;             // (what is enqueued again below is ordered by events, and so is the next submit)
+      if (p->cfg.tracker_mode == 1) {    // (every flight has its chain before any is enqueued again)
+        rc = sift_flush_chains(p, p->n_flight - 1);
+        if (rc != VO_OK) {
+          p->n_flight = 0;
+          return rc;
+        }
+      }
       rc = out->fault ? recover_step(p, f, q, out) : VO_OK;
       // steps submitted behind it saw the fault and did nothing for this sequence: their main-stream chains are
       // enqueued again for it alone (pyramids and detections are done and still in place)

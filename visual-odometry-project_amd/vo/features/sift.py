@@ -6,6 +6,10 @@ from vo.primitives import Features, Frame, Matches
 
 
 class SIFTDetector:
+    # cv2.SIFT_create() keeps every keypoint (nfeatures = 0, sift.py:10); an integer keeps the strongest that many
+    # (BASELINE.json configs[2] caps the detector at 2000)
+    _max_keypoints = None
+
     def __init__(self, frame: Frame, context=None):
         self._ctx = context
         kp, desc = self.detect_and_compute(frame=frame)
@@ -23,7 +27,7 @@ class SIFTDetector:
         if img.ndim == 3:
             b, g, r = (img[..., c].astype(np.int64) for c in range(3))
             img = ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
-        kp, desc = self._context().sift(img)
+        kp, desc = self._context().sift(img, cap=type(self)._max_keypoints)
         return kp[:, :2].astype(np.float64).reshape(-1, 2, 1), desc
 
     def get_sift_matches(self, curr_frame: Frame, new_frame: Frame) -> Matches:
