@@ -276,7 +276,7 @@ def api_leg(ctx):
     return out
 
 
-def cfg3_main(args):
+def cfg3_main(args, tracker="sift"):
     """VO_BENCH_CONFIG=cfg3: BASELINE.json configs[2] -- the same stream with SIFT detect + describe (cap 2000) and
     brute-force L2 2-NN + ratio + uniqueness matching in place of KLT (src/vo/features/tracker.py:60-61, sift.py:23-56),
     as a device-resident loop (vo_pipeline_config.tracker_mode = 1): images in, pose records out; descriptors, pair
@@ -287,19 +287,21 @@ def cfg3_main(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     from vo import _native, driver
+    from vo.features.harris import HarrisCornerDetector
     from vo.features.sift import SIFTDetector
     ctx = _native.Context(0)
     _native.set_default_context(ctx)
     CAP = 2000
-    saved = SIFTDetector._max_keypoints
+    saved = (SIFTDetector._max_keypoints, HarrisCornerDetector._num_keypoints_override)
     SIFTDetector._max_keypoints = CAP
+    HarrisCornerDetector._num_keypoints_override = CAP
     try:
-        state, _, _, _ = driver.bootstrap(ResidentSequence(stream), "sift", ransac_threshold=1.0)
+        state, _, _, _ = driver.bootstrap(ResidentSequence(stream), tracker, ransac_threshold=1.0)
     finally:
-        SIFTDetector._max_keypoints = saved
+        SIFTDetector._max_keypoints, HarrisCornerDetector._num_keypoints_override = saved
     feats = state.curr_frame.features
     pipe = _native.Pipeline(ctx, H, W, N_FRAMES, stream.K, n_keypoints=CAP, hyp=HYP_LAUNCH, p3p_threshold=1.0, outlier_ratio=0.9,
-                            confidence=0.99, max_iterations=HYP, refine_iters=REFINE_ITERS, tracker="sift", sift_cap=CAP)
+                            confidence=0.99, max_iterations=HYP, refine_iters=REFINE_ITERS, tracker=tracker, sift_cap=CAP)
     for i in range(N_FRAMES):
         pipe.set_frame(i, stream.image(i))
     pipe.set_state(PASS_START, feats, state.curr_pose, state.prev_pose, num_features=CAP)
@@ -338,11 +340,16 @@ def cfg3_main(args):
            "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32 (SIFT) / u8 -> i32 (matching) / f64 (pose)", "data": "synthetic",
-           "config": {"workload": "cfg-3: %dx%d synthetic stream, %d frames strictly forward, per frame SIFT detect + describe (%d "
-                                  "strongest), brute-force L2 2-NN + 0.8 ratio + uniqueness against the current Features' "
-                                  "descriptors (v_mfma_i32_32x32x32_i8), Matches regroup from the pair list, P3P-RANSAC %d "
-                                  "iterations + device replay, pose refinement, State bookkeeping, candidate DLT; device-resident "
-                                  "(vo_pipeline tracker_mode = sift), frames resident in HBM" % (W, H, N_FRAMES, CAP, HYP),
+           "config": {"workload": ("cfg-3: %dx%d synthetic stream, %d frames strictly forward, per frame SIFT detect + describe (%d "
+                                   "strongest), brute-force L2 2-NN + 0.8 ratio + uniqueness against the current Features' "
+                                   "descriptors (v_mfma_i32_32x32x32_i8), Matches regroup from the pair list, P3P-RANSAC %d "
+                                   "iterations + device replay, pose refinement, State bookkeeping, candidate DLT; device-resident "
+                                   "(vo_pipeline tracker_mode = sift), frames resident in HBM" if tracker == "sift" else
+                                   "Tracker(mode='harris') on the cfg-2 stream (%dx%d, %d frames strictly forward): per frame Harris "
+                                   "response + exact greedy NMS (%d keypoints), raw 19x19 patches as bytes, brute-force L2 2-NN + 0.85 "
+                                   "ratio + uniqueness against the current Features' patches (v_mfma_i32_32x32x32_i8, 361 values), "
+                                   "Matches regroup from the pair list, P3P-RANSAC %d iterations + device replay, refinement, State "
+                                   "bookkeeping, candidate DLT; device-resident (vo_pipeline tracker_mode = harris)") % (W, H, N_FRAMES, CAP, HYP),
                       "keypoints": CAP, "frames_resident": N_FRAMES, "frame_lookahead": 1,
                       "passes_started_in_timed_region": walker.passes},
            "loop": dict(st, bootstrap_landmarks=int((feats.state == 2).sum())),
@@ -370,7 +377,7 @@ def cfg3_main(args):
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from pipeline_oracle import OracleLoop
-        orc = OracleLoop(stream, CAP, WIN, MAX_LEVEL, refine_iters=REFINE_ITERS, tracker="sift")
+        orc = OracleLoop(stream, CAP, WIN, MAX_LEVEL, refine_iters=REFINE_ITERS, tracker=tracker)
         orc.set_state(PASS_START, feats, state.curr_pose, state.prev_pose)
         t1 = time.perf_counter()
         refs = [orc.step(PASS_START + 1 + k) for k in range(ORACLE_FRAMES)]
@@ -389,8 +396,11 @@ def cfg3_main(args):
                       np.array_equal(first_state["candidate_mask"], f.candidate_mask))
         out["pose_vs_oracle"] = {"frames": ORACLE_FRAMES, "max_abs_dR": dR, "max_rel_dt": dtr,
                                  "counts_keypoints_states_masks_exact": bool(exact),
-                                 "note": "vs the CPU oracle of the same loop (oracle/csrc/sift.c, match.c, p3p.c + the pinned "
-                                         "bookkeeping classes); parity unpinned vs OpenCV's SIFT / BFMatcher"}
+                                 "note": ("vs the CPU oracle of the same loop (oracle/csrc/sift.c, match.c, p3p.c + the pinned "
+                                          "bookkeeping classes); parity unpinned vs OpenCV's SIFT / BFMatcher" if tracker == "sift" else
+                                          "vs the CPU oracle of the same loop (oracle/harris_np.py pinned to the reference, "
+                                          "oracle/csrc/match.c, p3p.c + the pinned bookkeeping classes); parity unpinned vs "
+                                          "OpenCV's BFMatcher")}
         out["cpu_baseline"] = {"value": ORACLE_FRAMES / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "%d frames through the CPU oracle of the loop, single thread, %.1f s" % (ORACLE_FRAMES, cpu_s)}
     print(json.dumps(out), flush=True)
@@ -484,10 +494,10 @@ def main():
     ap.add_argument("--exchange", action="store_true",
                     help="run the all-gather of {pose, landmarks} records even on one GPU (always on for --gpus > 1)")
     args = ap.parse_args()
-    if CONFIG == "cfg3":
+    if CONFIG in ("cfg3", "harris"):
         if args.steps == 2000:
-            args.steps, args.warmup = 60, 5
-        return cfg3_main(args)
+            args.steps, args.warmup = 150, 10
+        return cfg3_main(args, "sift" if CONFIG == "cfg3" else "harris")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

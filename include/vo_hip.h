@@ -382,9 +382,13 @@ typedef struct vo_pipeline_config {
                                     carry, Matches regroup from the pair list with the descriptors following their
                                     keypoints [ref: src/vo/primitives/matches.py:51-58, 134-141], then the same pose
                                     estimation and State bookkeeping.  One sequence per pipeline; the state handed over
-                                    needs its descriptors too (vo_pipeline_set_descriptors).                      */
+                                    needs its descriptors too (vo_pipeline_set_descriptors).
+                                    2: Harris [ref: tracker.py:58-59, src/vo/features/harris.py:50-84, 196-264] -- per
+                                    frame the detector's n_keypoints keypoints (response + greedy NMS, every frame),
+                                    their raw 19x19 patches (descriptor_radius 9) as bytes, 2-NN + 0.85 ratio +
+                                    uniqueness on the matrix cores (361 values padded to 384), then as mode 1.      */
   int32_t sift_cap;              /* keypoints kept per frame in SIFT mode (0 = n_keypoints; <= 4000, <= feature_cap) */
-  double match_ratio;            /* sift.py:49; 0 = 0.8                                                            */
+  double match_ratio;            /* 0 = the reference's: 0.8 in SIFT mode (sift.py:49), 0.85 in Harris mode (harris.py:255) */
 } vo_pipeline_config;
 typedef struct vo_step_result {
   double R[9], t[3];            /* world -> camera pose of `next` (best hypothesis)   */
@@ -450,8 +454,8 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
  * state of the frame it was taken at and queues that frame's pyramid and detection, all asynchronously on the pipeline's
  * streams (nothing in flight; no host synchronisation).  What lives on the reference's estimator object across frames
  * (RANSAC.n_iterations / outlier_ratio [ref: src/vo/algorithms/ransac.py:47-56], the generator) is NOT rewound.      */
-/* SIFT tracker mode: the descriptors (n x 128 float32, whole numbers 0..255) of the features handed over by the last
- * vo_pipeline_set_state, in the same order.                                                                      */
+/* Descriptor tracker modes: the descriptors (n x 128 float32 in SIFT mode, n x 361 in Harris mode; whole numbers
+ * 0..255) of the features handed over by the last vo_pipeline_set_state, in the same order.                      */
 int vo_pipeline_set_descriptors(vo_pipeline* p, const float* desc, int n);
 int vo_pipeline_checkpoint(vo_pipeline* p);
 int vo_pipeline_rewind(vo_pipeline* p);

@@ -83,7 +83,7 @@ class OracleLoop:
         self.state.curr_pose = np.array(curr_pose, np.float64)
         self.state.prev_pose = np.array(prev_pose, np.float64)
         self.state.prev_frame = f
-        if self.tracker_mode == "sift":
+        if self.tracker_mode in ("sift", "harris"):
             return
         # the tracker shell: built around the frame without touching its features
         keep = f.features
@@ -101,6 +101,20 @@ class OracleLoop:
             new.features = Features(kp2[:, :2].astype(np.float64).reshape(-1, 2, 1))
             new.features.descriptors = desc2
             good = native.match_knn2_ratio(st.curr_frame.features.descriptors, desc2, self.match_ratio)[0]
+            if len(good) == 0:
+                good = np.empty((0, 2), dtype=int)
+            matches = Matches(st.curr_frame, new, matches=good)
+            self.n_new, self.n_pairs = len(kp2), len(good)
+        elif self.tracker_mode == "harris":
+            # harris.py:50-84: extractKeypoints + extractDescriptors on the new frame, matchDescriptor (ratio 0.85)
+            from vo.primitives import Features, Matches
+            img = self.stream.image(next_idx)
+            kp2 = harris_np.nms_keypoints_fast(harris_np.harris_scores(img, 9, 0.09), self.cfg["N"], 5)
+            new.features = Features(kp2.astype(np.float64))
+            new.features.descriptors = harris_np.patch_descriptors(img, kp2, 9)
+            d1 = st.curr_frame.features.descriptors.astype(np.float32)
+            d2 = new.features.descriptors.astype(np.float32)
+            good = native.match_knn2_ratio(d1.reshape(len(d1), -1), d2.reshape(len(d2), -1), 0.85)[0]
             if len(good) == 0:
                 good = np.empty((0, 2), dtype=int)
             matches = Matches(st.curr_frame, new, matches=good)
@@ -191,4 +205,12 @@ def initial_sift_features(stream, idx, n_keypoints):
     f.landmarks[:n_tri] = land[:n_tri].reshape(-1, 3, 1)
     f.tracks = np.concatenate([np.full((n_tri, 2, 1), np.nan), kp[n_tri:]])
     f.poses = np.concatenate([np.full((n_tri, 4, 4), np.nan), np.stack([T] * (n - n_tri))])
+    return f, T
+
+
+def initial_harris_features(stream, idx, n_keypoints):
+    """Starting state for the Harris tracker mode: initial_features' keypoints and landmarks with their raw-patch
+    descriptors (harris.py:160-194)."""
+    f, T = initial_features(stream, idx, n_keypoints)
+    f.descriptors = harris_np.patch_descriptors(stream.image(idx), f.keypoints, 9)
     return f, T

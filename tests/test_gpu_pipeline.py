@@ -659,3 +659,39 @@ def test_sift_tracker_mode_matches_oracle_loop(ctx, H, W, N, lookahead):
             assert np.abs(np.array(r.R_refined).reshape(3, 3) - Tcw[:3, :3]).max() < 3e-2
             assert np.abs(np.array(r.t_refined) - Tcw[:3, 3]).max() < 0.5
     pipe.close()
+
+
+@pytest.mark.parametrize("lookahead", [False, True])
+def test_harris_tracker_mode_matches_oracle_loop(ctx, lookahead):
+    """Tracker(mode="harris") (src/vo/features/tracker.py:58-59, harris.py:50-84, 196-264) as a device-resident loop: per
+    frame Harris response + greedy NMS (N keypoints), raw 19x19 patch descriptors as bytes, 2-NN + 0.85 ratio +
+    uniqueness on the matrix cores (361 values per row), Matches regroup from the pair list, then the common pose chain.
+    Against the oracle loop after every frame."""
+    from pipeline_oracle import initial_harris_features
+    from vo import _native, synthetic
+    H, W, N, F = 480, 640, 500, 5
+    stream = synthetic.Stream(F, H, W)
+    feats, T = initial_harris_features(stream, 0, N)
+    pipe = _native.Pipeline(ctx, H, W, F, stream.K, n_keypoints=N, hyp=256, p3p_threshold=1.0, max_iterations=1000,
+                            refine_iters=20, tracker="harris")
+    for i in range(F):
+        pipe.set_frame(i, stream.image(i))
+    pipe.set_state(0, feats, T, T)
+    orc = OracleLoop(stream, N, 15, 2, refine_iters=20, tracker="harris")
+    orc.set_state(0, feats, T, T)
+    pairs = [(k, k + 1) for k in range(F - 1)]
+    if lookahead:
+        refs = [orc.step(b) for _, b in pairs]
+        rs = run_all(pipe, pairs, True)
+        for r, ref in zip(rs, refs):
+            assert (r.n_tracked, r.n_triangulated, r.n_inliers, r.draws_consumed, r.ransac_iterations, r.n_candidates,
+                    r.n_landmarks) == (ref["n_tracked"], ref["n_tri"], ref["n_inliers"], ref["draws"], ref["iters"],
+                                       ref["n_cand"], ref["n_landmarks"])
+        check_step(rs[-1], refs[-1], pipe, orc.rs.rng, land_tol=1e-4)
+    else:
+        for a, b in pairs:
+            ref = orc.step(b)
+            r = pipe.step(a, b)
+            assert r.n_features_in == N and r.n_tracked == N and r.n_triangulated >= 8
+            check_step(r, ref, pipe, orc.rs.rng, land_tol=1e-4)
+    pipe.close()

@@ -1459,6 +1459,26 @@ __global__ __launch_bounds__(NT) void patch_desc_kernel(const uint8_t* __restric
   }
 }
 
+// the same patches as bytes, one row of row_bytes (>= (2r+1)^2, the rest zero) per keypoint: what the device-resident
+// harris tracker mode matches on the matrix cores (the values are pixels: whole numbers 0..255 by construction)
+__global__ __launch_bounds__(128) void patch_desc_u8_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                            const double* __restrict__ kp_xy, int N, int r,
+                                                            uint8_t* __restrict__ desc, int row_bytes) {
+  const int k = blockIdx.x;
+  const int d = 2 * r + 1;
+  const int x = (int)kp_xy[2 * k], y = (int)kp_xy[2 * k + 1];
+  uint8_t* o = desc + (size_t)k * row_bytes;
+  for (int i = threadIdx.x; i < row_bytes; i += 128) {
+    uint8_t v = 0;
+    if (i < d * d) {
+      const int dy = i / d, dx = i - dy * d;
+      const int gy = y - r + dy, gx = x - r + dx;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[(size_t)gy * W + gx];
+    }
+    o[i] = v;
+  }
+}
+
 size_t response_lds_bytes(int p) {
   const resp_geom g = response_geometry(p);
   const int HR = p == 9 ? RY / 2 + p - 1 : g.GH;     // (the compile-time patch holds half the rows of sums at a time)
@@ -1666,6 +1686,18 @@ int vo_patch_descriptors_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, co
     hipLaunchKernelGGL(patch_desc_kernel, dim3(N), dim3(NT), 0, ctx->stream, d_img, H, W, d_kp_xy, N, r, d_desc);
   }
   return vo_check_launch(ctx, "patch_desc_kernel");
+}
+
+int vo_patch_descriptors_u8_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, const double* d_kp_xy, int N, int r,
+                                uint8_t* d_desc, int row_bytes) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, d_img && d_kp_xy && d_desc && N >= 1 && r >= 0 && (2 * r + 1) * (2 * r + 1) <= row_bytes,
+             "patch_descriptors_u8: bad arguments");
+  {
+    vo_prof_scope ps(ctx, VO_K_PATCH_DESC);
+    hipLaunchKernelGGL(patch_desc_u8_kernel, dim3(N), dim3(128), 0, ctx->stream, d_img, H, W, d_kp_xy, N, r, d_desc, row_bytes);
+  }
+  return vo_check_launch(ctx, "patch_desc_u8_kernel");
 }
 
 // ---- host-buffer wrappers ----------------------------------------------------------

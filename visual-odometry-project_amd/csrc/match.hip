@@ -385,9 +385,10 @@ int vo_knn2_dev(vo_ctx* ctx, const float* d_q, int nq, const float* d_t, int nt,
 // counts too (d_nq, d_nt; the launches are sized for cap_q / cap_t).  Pairs (query, train) in query order -> d_pairs
 // (cap_q x 2), their number -> *d_npairs.  Asynchronous on the context's stream; scratch[10..14] of the context.
 int vo_match_u8_dev(vo_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, int cap_q, const uint8_t* d_t, const int32_t* d_nt,
-                    int cap_t, double ratio, int32_t* d_pairs, int32_t* d_npairs) {
+                    int cap_t, double ratio, int32_t* d_pairs, int32_t* d_npairs, int row_bytes) {
   if (!ctx) return VO_EINVAL;
   VO_REQUIRE(ctx, d_q && d_nq && d_t && d_nt && d_pairs && d_npairs && cap_q >= 1 && cap_t >= 1, "match_u8_dev: bad arguments");
+  VO_REQUIRE(ctx, row_bytes == 128 || row_bytes == 384, "match_u8_dev: rows of 128 (SIFT) or 384 (19x19 patches, padded) bytes");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   vo_buf* s = ctx->scratch;
@@ -406,9 +407,14 @@ int vo_match_u8_dev(vo_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, int ca
   VO_HIP_TRY(ctx, hipMemsetAsync(d_npairs, 0, 4, st));
   {
     vo_prof_scope ps(ctx, VO_K_MATCH);
-    hipLaunchKernelGGL(knn2_mfma_kernel<4>, dim3(qblocks, splits), dim3(256), 0, st, d_q, cap_q, d_t, cap_t,
-                       (unsigned long long*)s[13].p, (unsigned*)ctx->match_arrived.p, (int*)s[10].p, (double*)s[11].p,
-                       (const int*)d_nq, (const int*)d_nt);
+    if (row_bytes == 128)
+      hipLaunchKernelGGL(knn2_mfma_kernel<4>, dim3(qblocks, splits), dim3(256), 0, st, d_q, cap_q, d_t, cap_t,
+                         (unsigned long long*)s[13].p, (unsigned*)ctx->match_arrived.p, (int*)s[10].p, (double*)s[11].p,
+                         (const int*)d_nq, (const int*)d_nt);
+    else
+      hipLaunchKernelGGL(knn2_mfma_kernel<12>, dim3(qblocks, splits), dim3(256), 0, st, d_q, cap_q, d_t, cap_t,
+                         (unsigned long long*)s[13].p, (unsigned*)ctx->match_arrived.p, (int*)s[10].p, (double*)s[11].p,
+                         (const int*)d_nq, (const int*)d_nt);
   }
   VO_TRY(vo_check_launch(ctx, "knn2_mfma_kernel"));
   hipLaunchKernelGGL(ratio_unique_kernel, dim3(1), dim3(RU_T), 0, st, (const int*)s[10].p, (const double*)s[11].p, cap_q,

@@ -104,7 +104,10 @@ struct vo_pipeline {
   // keypoints and descriptors are made by the SIFT kernels on the tracker's stream, matched against the descriptors the
   // current Features carry (bytes, regrouped with them: matches.py:51-58, 134-141) on the matrix cores, and regrouped
   // from the explicit pair list -- nothing of it leaves HBM.  One sequence per pipeline in this mode.
+  // Harris tracker mode (tracker_mode = 2; tracker.py:58-59, harris.py:50-84): the same with the detector's N keypoints
+  // (every frame), their 19x19 raw patches as 384-byte rows, ratio 0.85.
   int sift_cap = 0;
+  int desc_row = 128;                // bytes per descriptor row: 128 (SIFT) or 384 (361 patch bytes, padded)
   float* d_skp = nullptr;            // [3][sift_cap * 6]   keypoint rows of the frame in slot s
   uint8_t* d_sdesc = nullptr;        // [3][sift_cap * 128] its descriptors
   int32_t* d_sn = nullptr;           // [3] its keypoint count; [3]: pairs of the step being enqueued
@@ -225,12 +228,14 @@ __global__ __launch_bounds__(256) void sift_kp_f64_kernel(const float* __restric
 
 // ... and the descriptors of the regrouped frame: row dst of the new Features = the new keypoint src_row[dst]'s
 __global__ __launch_bounds__(256) void desc_gather_kernel(const uint8_t* __restrict__ src, const int* __restrict__ src_row,
-                                                          const vo_seq_ctl* __restrict__ ctl, int cap, uint8_t* __restrict__ dst) {
+                                                          const vo_seq_ctl* __restrict__ ctl, int cap, uint8_t* __restrict__ dst,
+                                                          int row_words) {
   if (ctl->fault) return;
   const int w = blockIdx.x * 256 + threadIdx.x;        // one 4-byte word of one row
-  const int row = w >> 5, k = w & 31;
+  const int row = w / row_words, k = w - row * row_words;
   if (row >= min(ctl->n2, cap)) return;
-  reinterpret_cast<unsigned*>(dst)[(size_t)row * 32 + k] = reinterpret_cast<const unsigned*>(src)[(size_t)src_row[row] * 32 + k];
+  reinterpret_cast<unsigned*>(dst)[(size_t)row * row_words + k] =
+      reinterpret_cast<const unsigned*>(src)[(size_t)src_row[row] * row_words + k];
 }
 
 template <typename T>
@@ -402,8 +407,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   VO_REQUIRE(ctx, cfg->K[0] != 0.0 && cfg->K[4] != 0.0, "pipeline: singular intrinsics");
   VO_REQUIRE(ctx, cfg->refine_iters >= 0 && cfg->refine_iters <= 100, "pipeline: refine_iters must be in 0..100");
   VO_REQUIRE(ctx, cfg->sequences >= 0 && cfg->sequences <= 256, "pipeline: sequences must be in 1..256");
-  VO_REQUIRE(ctx, cfg->tracker_mode == 0 || cfg->tracker_mode == 1, "pipeline: tracker_mode must be 0 (klt) or 1 (sift)");
-  VO_REQUIRE(ctx, cfg->tracker_mode == 0 || cfg->sequences <= 1, "pipeline: the sift tracker mode runs one sequence per pipeline");
+  VO_REQUIRE(ctx, cfg->tracker_mode >= 0 && cfg->tracker_mode <= 2, "pipeline: tracker_mode must be 0 (klt), 1 (sift) or 2 (harris)");
+  VO_REQUIRE(ctx, cfg->tracker_mode == 0 || cfg->sequences <= 1, "pipeline: the descriptor tracker modes run one sequence per pipeline");
   const int cap = cfg->feature_cap > 0 ? cfg->feature_cap : 2 * cfg->n_keypoints;
   VO_REQUIRE(ctx, cap >= cfg->n_keypoints && cap <= 32768, "pipeline: feature_cap must be in n_keypoints..32768");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -459,7 +464,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     // the mask costs more than it gives (16 sequences: -5 %).  VO_SIDE_CUS="lo-hi" overrides, "all" switches it off.
     const char* sc = getenv("VO_SIDE_CUS");
     std::string auto_mask;
-    if (!sc && p->S <= 2 && p->detect_limit >= 0.0 && !side && cfg->tracker_mode == 0) {
+    if (!sc && p->S <= 2 && p->detect_limit >= 0.0 && !side && cfg->tracker_mode == 0) {   // (KLT mode only)
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount >= 128) {
         auto_mask = "32-" + std::to_string(prop.multiProcessorCount - 1);
@@ -530,17 +535,22 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_best_mask, Sz * p->words));
   PA(dev_alloc(ctx, &p->d_newkp, (size_t)cap * 2));
   PA(dev_alloc(ctx, &p->d_pairs, (size_t)cap * 2));
-  if (cfg->tracker_mode == 1) {
-    p->sift_cap = cfg->sift_cap > 0 ? cfg->sift_cap : cfg->n_keypoints;
+  if (cfg->tracker_mode != 0) {
+    p->desc_row = cfg->tracker_mode == 2 ? 384 : 128;
+    p->sift_cap = cfg->tracker_mode == 2 ? cfg->n_keypoints : (cfg->sift_cap > 0 ? cfg->sift_cap : cfg->n_keypoints);
     if (rc == VO_OK && (p->sift_cap > cap || p->sift_cap > 4000))
       rc = vo_set_error(ctx, VO_EINVAL, "pipeline: sift_cap %d exceeds the feature capacity %d (or 4000)", p->sift_cap, cap);
     PA(dev_alloc(ctx, &p->d_skp, (size_t)3 * p->sift_cap * 6));
-    PA(dev_alloc(ctx, &p->d_sdesc, (size_t)3 * p->sift_cap * 128));
+    PA(dev_alloc(ctx, &p->d_sdesc, (size_t)3 * p->sift_cap * p->desc_row));
     PA(dev_alloc(ctx, &p->d_sn, 8));
-    PA(dev_alloc(ctx, &p->d_fdesc, (size_t)2 * cap * 128));
+    PA(dev_alloc(ctx, &p->d_fdesc, (size_t)2 * cap * p->desc_row));
     PA(dev_alloc(ctx, &p->d_srcrow, (size_t)cap));
-    if (rc == VO_OK && (hipMemset(p->d_sn, 0, 32) != hipSuccess || hipMemset(p->d_fdesc, 0, (size_t)2 * cap * 128) != hipSuccess))
+    if (rc == VO_OK && (hipMemset(p->d_sn, 0, 32) != hipSuccess || hipMemset(p->d_fdesc, 0, (size_t)2 * cap * p->desc_row) != hipSuccess))
       rc = vo_set_error(ctx, VO_EHIP, "pipeline: hipMemset failed");
+    if (rc == VO_OK && cfg->tracker_mode == 2) {          // (every frame has exactly N detector keypoints)
+      const int32_t nn[3] = {cfg->n_keypoints, cfg->n_keypoints, cfg->n_keypoints};
+      if (hipMemcpy(p->d_sn, nn, 12, hipMemcpyHostToDevice) != hipSuccess) rc = vo_set_error(ctx, VO_EHIP, "pipeline: hipMemcpy failed");
+    }
   }
   // n_iterations as a step function of the outlier ratio (state_device.h, table_lookup): a batch of `hyp`
   // samples cannot finish a rule that needs more than `hyp` iterations, so hyp + 1 thresholds suffice
@@ -931,6 +941,25 @@ static int enqueue_sift(vo_pipeline* p, const vo_pipeline::flight_t& f, char* er
   return VO_OK;
 }
 
+// Harris tracker mode: the new frame's N keypoints (Harris response + greedy NMS, every frame) and their raw patches as
+// bytes, on the detection stream; slot f.b
+static int enqueue_harris_front(vo_pipeline* p, const vo_pipeline::flight_t& f, char* err_buf = nullptr) {
+  const vo_pipeline_config& c = p->cfg;
+  int rc = enqueue_detection(p, f.next_idx, f.b, true, err_buf);
+  if (rc != VO_OK) return rc;
+  rc = vo_patch_descriptors_u8_dev(p->det, p->img(0, f.next_idx), c.H, c.W, p->kp(0, f.b), c.n_keypoints, 9,
+                                   p->d_sdesc + (size_t)f.b * p->sift_cap * p->desc_row, p->desc_row);
+  if (rc == VO_OK && hipEventRecord(p->evPyr[f.b], p->det->stream) != hipSuccess) rc = VO_EHIP;
+  if (rc != VO_OK) {
+    if (err_buf) {
+      snprintf(err_buf, 256, "harris front: %s", vo_last_error(p->det));
+      return rc;
+    }
+    return vo_set_error(p->ctx, rc, "harris front: %s", vo_last_error(p->det));
+  }
+  return VO_OK;
+}
+
 // main-stream chain of a step in SIFT mode: 2-NN + ratio + uniqueness against the current Features' descriptors
 // (sift.py:38-54), Matches regroup from the pair list (matches.py:26-212) with the descriptors following their
 // keypoints, then hypotheses and pose as in the KLT mode
@@ -938,23 +967,30 @@ static int enqueue_chain_sift(vo_pipeline* p, const vo_pipeline::flight_t& f, bo
   vo_ctx* ctx = p->ctx;
   const vo_pipeline_config& c = p->cfg;
   hipStream_t st = ctx->stream;
+  const bool harris = c.tracker_mode == 2;
+  const size_t row = (size_t)p->desc_row;
   const vo_feat A = p->F[f.fcur], B = p->F[1 - f.fcur];
-  const uint8_t* descA = p->d_fdesc + (size_t)f.fcur * p->cap * 128;
-  uint8_t* descB = p->d_fdesc + (size_t)(1 - f.fcur) * p->cap * 128;
-  const uint8_t* sdesc = p->d_sdesc + (size_t)f.b * p->sift_cap * 128;
+  const uint8_t* descA = p->d_fdesc + (size_t)f.fcur * p->cap * row;
+  uint8_t* descB = p->d_fdesc + (size_t)(1 - f.fcur) * p->cap * row;
+  const uint8_t* sdesc = p->d_sdesc + (size_t)f.b * p->sift_cap * row;
   const float* skp = p->d_skp + (size_t)f.b * p->sift_cap * 6;
   int32_t* n_new = p->d_sn + f.b;
   int32_t* n_pairs = p->d_sn + 3;
   VO_HIP_TRY(ctx, hipStreamWaitEvent(st, p->evPyr[f.b], 0));
-  VO_TRY(vo_match_u8_dev(ctx, descA, &p->d_ctl->n, p->cap, sdesc, n_new, p->sift_cap, c.match_ratio > 0.0 ? c.match_ratio : 0.8,
-                         p->d_pairs, n_pairs));
-  hipLaunchKernelGGL(sift_kp_f64_kernel, dim3(vo_cdiv(p->sift_cap, 256)), dim3(256), 0, st, skp, (const int*)n_new, p->sift_cap,
-                     p->d_newkp);
-  VO_TRY(vo_check_launch(ctx, "sift_kp_f64_kernel"));
-  VO_TRY(vo_state_regroup_pairs(ctx, p->d_ctl, A, B, p->d_pairs, p->cap, p->d_newkp, p->sift_cap, p->cap, n_pairs, n_new,
+  const double ratio = c.match_ratio > 0.0 ? c.match_ratio : (harris ? 0.85 : 0.8);        // harris.py:255 / sift.py:49
+  VO_TRY(vo_match_u8_dev(ctx, descA, &p->d_ctl->n, p->cap, sdesc, n_new, p->sift_cap, ratio, p->d_pairs, n_pairs, p->desc_row));
+  const double* new_kp = p->d_newkp;
+  if (harris) {
+    new_kp = p->kp(0, f.b);            // the detector's keypoints are float64 pairs already
+  } else {
+    hipLaunchKernelGGL(sift_kp_f64_kernel, dim3(vo_cdiv(p->sift_cap, 256)), dim3(256), 0, st, skp, (const int*)n_new, p->sift_cap,
+                       p->d_newkp);
+    VO_TRY(vo_check_launch(ctx, "sift_kp_f64_kernel"));
+  }
+  VO_TRY(vo_state_regroup_pairs(ctx, p->d_ctl, A, B, p->d_pairs, p->cap, new_kp, p->sift_cap, p->cap, n_pairs, n_new,
                                 p->d_srcrow));
-  hipLaunchKernelGGL(desc_gather_kernel, dim3(vo_cdiv(p->cap * 32, 256)), dim3(256), 0, st, sdesc, (const int*)p->d_srcrow,
-                     (const vo_seq_ctl*)p->d_ctl, p->cap, descB);
+  hipLaunchKernelGGL(desc_gather_kernel, dim3(vo_cdiv(p->cap * (p->desc_row / 4), 256)), dim3(256), 0, st, sdesc,
+                     (const int*)p->d_srcrow, (const vo_seq_ctl*)p->d_ctl, p->cap, descB, p->desc_row / 4);
   VO_TRY(vo_check_launch(ctx, "desc_gather_kernel"));
   VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], st));
   if (first_half_only) return VO_OK;
@@ -985,8 +1021,9 @@ static void worker_main(vo_pipeline* p) {
     }
     idle = 0;
     const vo_pipeline::flight_t j = p->jobs[seen & 3];
-    const int rc = p->cfg.tracker_mode == 1 ? enqueue_sift(p, j, p->worker_err)
-                                            : enqueue_detection(p, j.next_idx, j.b, false, p->worker_err);
+    const int rc = p->cfg.tracker_mode == 1   ? enqueue_sift(p, j, p->worker_err)
+                   : p->cfg.tracker_mode == 2 ? enqueue_harris_front(p, j, p->worker_err)
+                                              : enqueue_detection(p, j.next_idx, j.b, false, p->worker_err);
     if (rc != VO_OK) p->worker_rc = rc;
     ++seen;
     p->job_done.store(seen, std::memory_order_release);
@@ -1096,25 +1133,27 @@ int vo_pipeline_set_state(vo_pipeline* p, int idx, int n, const double* kp, cons
 int vo_pipeline_set_descriptors(vo_pipeline* p, const float* desc, int n) {
   if (!p) return VO_EINVAL;
   vo_ctx* ctx = p->ctx;
-  VO_REQUIRE(ctx, p->cfg.tracker_mode == 1, "pipeline_set_descriptors: the pipeline is not in sift tracker mode");
+  VO_REQUIRE(ctx, p->cfg.tracker_mode != 0, "pipeline_set_descriptors: the pipeline is not in a descriptor tracker mode");
   VO_REQUIRE(ctx, p->have_state && p->n_flight == 0, "pipeline_set_descriptors: hand the state over first (nothing in flight)");
   VO_REQUIRE(ctx, n >= 0 && n <= p->cap && (n == 0 || desc), "pipeline_set_descriptors: bad arguments");
-  std::vector<uint8_t> b((size_t)n * 128);
-  for (size_t i = 0; i < b.size(); ++i) {
-    const float v = desc[i];
-    VO_REQUIRE(ctx, v >= 0.f && v <= 255.f && v == (float)(int)v, "pipeline_set_descriptors: descriptor values must be whole numbers 0..255");
-    b[i] = (uint8_t)v;
-  }
+  const int D = p->cfg.tracker_mode == 2 ? 361 : 128;     // values per row handed in; rows are padded to desc_row bytes
+  std::vector<uint8_t> b((size_t)n * p->desc_row, 0);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < D; ++k) {
+      const float v = desc[(size_t)i * D + k];
+      VO_REQUIRE(ctx, v >= 0.f && v <= 255.f && v == (float)(int)v, "pipeline_set_descriptors: descriptor values must be whole numbers 0..255");
+      b[(size_t)i * p->desc_row + k] = (uint8_t)v;
+    }
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n > 0)
-    VO_HIP_TRY(ctx, mcpy(ctx->stream, p->d_fdesc + (size_t)p->cur * p->cap * 128, b.data(), b.size(), hipMemcpyHostToDevice));
+    VO_HIP_TRY(ctx, mcpy(ctx->stream, p->d_fdesc + (size_t)p->cur * p->cap * p->desc_row, b.data(), b.size(), hipMemcpyHostToDevice));
   return VO_OK;
 }
 
 // pyramid and detection of the frame the handed-over states belong to, all sequences, synchronously
 static int prime(vo_pipeline* p, bool wait = true) {
   vo_ctx* ctx = p->ctx;
-  if (p->cfg.tracker_mode == 1) {      // SIFT mode: the frame's own descriptors travel with its Features
+  if (p->cfg.tracker_mode != 0) {      // descriptor modes: the frame's own descriptors travel with its Features
     p->primed = true;
     return VO_OK;
   }
@@ -1144,9 +1183,9 @@ extern "C" int vo_pipeline_checkpoint(vo_pipeline* p) {
   VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_feat, (char*)p->feat_mem + (size_t)p->cur * p->feat_block, p->feat_block,
                                  hipMemcpyDeviceToDevice, st));
   VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_ctl, p->d_ctl, (size_t)p->S * sizeof(vo_seq_ctl), hipMemcpyDeviceToDevice, st));
-  if (p->cfg.tracker_mode == 1) {
-    if (!p->d_ckpt_fdesc) VO_TRY(dev_alloc(ctx, &p->d_ckpt_fdesc, (size_t)p->cap * 128));
-    VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_fdesc, p->d_fdesc + (size_t)p->cur * p->cap * 128, (size_t)p->cap * 128,
+  if (p->cfg.tracker_mode != 0) {
+    if (!p->d_ckpt_fdesc) VO_TRY(dev_alloc(ctx, &p->d_ckpt_fdesc, (size_t)p->cap * p->desc_row));
+    VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_ckpt_fdesc, p->d_fdesc + (size_t)p->cur * p->cap * p->desc_row, (size_t)p->cap * p->desc_row,
                                    hipMemcpyDeviceToDevice, st));
   }
   VO_HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1165,9 +1204,9 @@ extern "C" int vo_pipeline_rewind(vo_pipeline* p) {
   // every step has been collected: its chain -- tracker included -- is done, nothing reads the Features any more
   VO_HIP_TRY(ctx, hipMemcpyAsync((char*)p->feat_mem + (size_t)p->cur * p->feat_block, p->d_ckpt_feat, p->feat_block,
                                  hipMemcpyDeviceToDevice, st));
-  if (p->cfg.tracker_mode == 1)
-    VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_fdesc + (size_t)p->cur * p->cap * 128, p->d_ckpt_fdesc, (size_t)p->cap * 128,
-                                   hipMemcpyDeviceToDevice, st));
+  if (p->cfg.tracker_mode != 0)
+    VO_HIP_TRY(ctx, hipMemcpyAsync(p->d_fdesc + (size_t)p->cur * p->cap * p->desc_row, p->d_ckpt_fdesc,
+                                   (size_t)p->cap * p->desc_row, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(ctl_rewind_kernel, dim3(vo_cdiv(p->S, 64)), dim3(64), 0, st, p->d_ctl, p->d_ckpt_ctl, p->S);
   VO_TRY(vo_check_launch(ctx, "ctl_rewind_kernel"));
   // the next step's tracker waits for "the previous step's regroup": that event now stands for the restored state
@@ -1300,18 +1339,21 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   // The detection of `next` (half of the step's launches, needed only by the NEXT step) goes to the worker thread;
   // this thread enqueues the pyramid, the tracker and the main-stream chain.  The tracker waits for the event behind
   // the detection of `prev`: the worker must have recorded it (it was posted a whole step ago).
-  if (c.tracker_mode == 1) {
+  if (c.tracker_mode != 0) {
     // The frame's ~75 SIFT launches go to the worker thread; this thread first gives the flight submitted before its
     // main-stream chain (its SIFT launches are made by now), so the two threads' launches overlap across frames.
     // Two threads make the launches, a frame each: even flights' go to the worker, odd flights' are made here (each
     // thread on its own SIFT context, so that two frames' chains also run side by side on the GPU).
     f.sift_job = 0;
-    if (p->threads_budget >= 2 && (f.k & 1) == 0) {
+    if (p->threads_budget >= 2 && ((f.k & 1) == 0 || c.tracker_mode == 2)) {      // (harris: one detection context, the worker's)
       const unsigned my = p->job_posted.load(std::memory_order_relaxed);
       if ((int)(p->job_done.load(std::memory_order_acquire) - my) >= 0) {       // (idle worker: its context's flags are ours)
         p->trk->prof_on = ctx->prof_on;
         p->trk->prof_kernel = ctx->prof_kernel;
         p->trk->prof_every = ctx->prof_every;
+        p->det->prof_on = ctx->prof_on;
+        p->det->prof_kernel = ctx->prof_kernel;
+        p->det->prof_every = ctx->prof_every;
       }
       f.sift_job = my + 1;
       p->jobs[my & 3] = f;
@@ -1322,7 +1364,14 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
       mine->prof_on = ctx->prof_on;
       mine->prof_kernel = ctx->prof_kernel;
       mine->prof_every = ctx->prof_every;
-      VO_TRY(enqueue_sift(p, f));
+      if (c.tracker_mode == 2) {
+        p->det->prof_on = ctx->prof_on;
+        p->det->prof_kernel = ctx->prof_kernel;
+        p->det->prof_every = ctx->prof_every;
+        VO_TRY(enqueue_harris_front(p, f));
+      } else {
+        VO_TRY(enqueue_sift(p, f));
+      }
     }
     p->slot_seq[(size_t)f.rslot] = f.seq;
     p->flight[p->n_flight++] = f;
@@ -1495,7 +1544,7 @@ static int recover_step(vo_pipeline* p, const vo_pipeline::flight_t& f, int q, v
       const int one = 1;
       VO_HIP_TRY(ctx, mcpy(st, p->d_det_go + (size_t)f.a * p->S + q, &one, 4, hipMemcpyHostToDevice));
     }
-    if (c.tracker_mode == 1) {
+    if (c.tracker_mode != 0) {
       VO_TRY(enqueue_chain_sift(p, f, true, 0u));      // (the frame's keypoints and descriptors are still in their slot)
     } else {
       VO_TRY(enqueue_tracker(p, f, false, q, 1));
@@ -1635,7 +1684,7 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
   VO_REQUIRE(ctx, p->n_flight > 0, "pipeline_collect: nothing submitted");
   VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
   const vo_pipeline::flight_t f = p->flight[0];
-  if (p->cfg.tracker_mode == 1) VO_TRY(sift_flush_chains(p, 0));
+  if (p->cfg.tracker_mode != 0) VO_TRY(sift_flush_chains(p, 0));
   {
     const double t_in = now_s();
     for (int q = 0; q < p->S; ++q)
@@ -1652,7 +1701,7 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
     }
     if (out->fault || was_open) {
       p->gate_resync = true;             // (what is enqueued again below is ordered by events, and so is the next submit)
-      if (p->cfg.tracker_mode == 1) {    // (every flight has its chain before any is enqueued again)
+      if (p->cfg.tracker_mode != 0) {    // (every flight has its chain before any is enqueued again)
         rc = sift_flush_chains(p, p->n_flight - 1);
         if (rc != VO_OK) {
           p->n_flight = 0;
@@ -1666,7 +1715,7 @@ int vo_pipeline_collect_all(vo_pipeline* p, vo_step_result* outs) {
         const unsigned seq = ++p->seq;
         p->slot_seq[(size_t)p->flight[k].rslot * p->S + q] = seq;
         rc = ensure_raws(p, q);
-        if (p->cfg.tracker_mode == 1) {
+        if (p->cfg.tracker_mode != 0) {
           if (rc == VO_OK) rc = enqueue_chain_sift(p, p->flight[k], false, seq);
           continue;
         }

@@ -150,7 +150,11 @@ int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x
 // SIFT tracker mode of the frame pipeline: device-resident detect + describe (sift.hip: extern "C" vo_sift_dev) and
 // matching (match.hip)
 extern "C" int vo_match_u8_dev(vo_ctx* ctx, const uint8_t* d_q, const int32_t* d_nq, int cap_q, const uint8_t* d_t,
-                               const int32_t* d_nt, int cap_t, double ratio, int32_t* d_pairs, int32_t* d_npairs);
+                               const int32_t* d_nt, int cap_t, double ratio, int32_t* d_pairs, int32_t* d_npairs,
+                               int row_bytes = 128);
+// raw (2r+1)^2 patches of the zero-padded image as BYTES, rows padded with zeros to row_bytes (harris.hip)
+extern "C" int vo_patch_descriptors_u8_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, const double* d_kp_xy, int N,
+                                           int r, uint8_t* d_desc, int row_bytes);
 // the next `count` 32-bit outputs of NumPy's PCG64 Generator (ransac_host.hip); advances *rng
 void vo_rng_raw32(vo_pcg64* rng, int count, uint32_t* out);
 // DLT with a device-resident point count (dlt.hip)

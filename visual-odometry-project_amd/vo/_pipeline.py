@@ -29,7 +29,7 @@ class Pipeline:
                  klt_err_threshold=100.0, hyp=1000, p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99,
                  max_iterations=1000, seed=2023, refine_iters=0, feature_cap=0, bearing_threshold=0.0075,
                  redetect_fraction=0.8, debug_fault_every=0, redetect_start_pose="identity", sequences=1,
-                 detect_margin=0.01, debug_never_detect=0, detect_losses=2.5, tracker="klt", sift_cap=0, match_ratio=0.8):
+                 detect_margin=0.01, debug_never_detect=0, detect_losses=2.5, tracker="klt", sift_cap=0, match_ratio=0.0):
         from vo import _native
         self.ctx = ctx
         self.cfg = _native.PipelineConfig()
@@ -51,7 +51,7 @@ class Pipeline:
         c.detect_margin = float(detect_margin)       # < 0: the detector runs on every frame
         c.debug_never_detect = int(debug_never_detect)
         c.detect_losses = float(detect_losses)
-        c.tracker_mode = {"klt": 0, "sift": 1}[tracker]         # src/vo/features/tracker.py:54-63
+        c.tracker_mode = {"klt": 0, "sift": 1, "harris": 2}[tracker]         # src/vo/features/tracker.py:54-63
         c.sift_cap = int(sift_cap)
         c.match_ratio = float(match_ratio)
         self.tracker = tracker
@@ -116,8 +116,8 @@ class Pipeline:
         self.ctx._chk(self.ctx._lib.vo_pipeline_set_state_seq(self._h, int(seq), int(idx), n, _ptr(kp), _ptr(state),
                                                               _ptr(land), _ptr(tracks), _ptr(poses), _ptr(T_wc),
                                                               _ptr(T_cw), _ptr(T_wc_prev), _ptr(T_cw_prev), nf))
-        if self.tracker == "sift":
-            desc = _c(np.asarray(features.descriptors).reshape(n, 128), np.float32)
+        if self.tracker in ("sift", "harris"):
+            desc = _c(np.asarray(features.descriptors).reshape(n, 128 if self.tracker == "sift" else 361), np.float32)
             self.ctx._chk(self.ctx._lib.vo_pipeline_set_descriptors(self._h, _ptr(desc), n))
 
     def checkpoint(self):

@@ -18,6 +18,10 @@ def _gray(image: np.ndarray) -> np.ndarray:
 
 
 class HarrisCornerDetector:
+    # Tracker(frame, mode="harris") constructs the detector with its defaults (tracker.py:43-50: 1000 keypoints); a
+    # caller that wants another count there (BASELINE.json's configurations name 2000) sets this before
+    _num_keypoints_override = None
+
     def __init__(self, frame: Frame = None, patch_size: int = 9, kappa: float = 0.09, num_keypoints: int = 1000,
                  nonmaximum_supression_radius: int = 5, descriptor_radius: int = 9, match_lambda: float = 4.0,
                  context=None):
@@ -25,7 +29,7 @@ class HarrisCornerDetector:
         self._frame2 = frame
         self._patch_size = patch_size
         self._kappa = kappa
-        self._num_keypoints = num_keypoints
+        self._num_keypoints = type(self)._num_keypoints_override or num_keypoints
         self._nonmaximum_supression_radius = nonmaximum_supression_radius
         self._descriptor_radius = descriptor_radius
         self._match_lambda = match_lambda

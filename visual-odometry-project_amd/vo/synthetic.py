@@ -98,14 +98,43 @@ def _render_image(args):
     return render(k, H, W, seed, want_depth=False)[0]
 
 
+def _cache_file(job):
+    import os
+    d = os.environ.get("VO_SYNTH_CACHE")
+    return os.path.join(d, "synth_%dx%d_seed%d_frame%d.npy" % (job[1], job[2], job[3], job[0])) if d else None
+
+
 def render_images(jobs, workers=0):
     """Images of many frames, jobs = [(k, H, W, seed), ...], rendered by `workers` processes (spawned: safe to call
-    from a process that holds a GPU context; 0 = in this process)."""
-    if workers <= 1 or len(jobs) < 4:
-        return [_render_image(j) for j in jobs]
-    import multiprocessing as mp
-    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
-        return pool.map(_render_image, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+    from a process that holds a GPU context; 0 = in this process).  VO_SYNTH_CACHE=<dir>: frames found there are read
+    instead of rendered, rendered ones are left there (tools/run_profiles.sh renders once for its dozen runs -- and keeps
+    worker processes out of the profiler)."""
+    import os
+    out = [None] * len(jobs)
+    todo = []
+    for i, j in enumerate(jobs):
+        f = _cache_file(j)
+        if f and os.path.exists(f):
+            out[i] = np.load(f)
+        else:
+            todo.append(i)
+    if todo:
+        sub = [jobs[i] for i in todo]
+        if workers <= 1 or len(sub) < 4:
+            imgs = [_render_image(j) for j in sub]
+        else:
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(min(workers, len(sub))) as pool:
+                imgs = pool.map(_render_image, sub, chunksize=max(1, len(sub) // (4 * workers)))
+        for i, im in zip(todo, imgs):
+            out[i] = im
+            f = _cache_file(jobs[i])
+            if f:
+                os.makedirs(os.path.dirname(f), exist_ok=True)
+                tmp = f + ".tmp%d.npy" % os.getpid()
+                np.save(tmp, im)
+                os.replace(tmp, f)
+    return out
 
 
 class Stream:
