@@ -57,7 +57,9 @@ HYP_LAUNCH = int(os.environ.get("VO_BENCH_HYP_LAUNCH", str(HYP + HYP // 8 + 24))
 N_FRAMES = 30 if CONFIG == "cfg5" else 100    # cfg-2 100 frames, cfg-5 30 frames
 PASS_START = 2           # the bootstrap uses frames 0 and 2 (main.py:204-209); a pass walks PASS_START -> N_FRAMES - 1
 S_LEG = 16               # sequences per GPU of the in-line throughput leg
-CPU_BASELINE_FRAMES = int(os.environ.get("VO_BENCH_CPU_FRAMES", "32"))
+# frames of the first pass that also go through the CPU oracle of the loop (parity + CPU baseline): the whole pass --
+# its re-detect frames included -- is 97 frames, 12-15 s of one core
+CPU_BASELINE_FRAMES = int(os.environ.get("VO_BENCH_CPU_FRAMES", "97"))
 RENDER_WORKERS = int(os.environ.get("VO_BENCH_RENDER_WORKERS", str(max(1, min(12, (os.cpu_count() or 2) - 2)))))
 REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
 EXCHANGE_EVERY = int(os.environ.get("VO_BENCH_EXCHANGE_EVERY", "16"))   # frames per all-gather of {pose, landmarks} records

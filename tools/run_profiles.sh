@@ -15,28 +15,20 @@ export TMPDIR=/tmp
 export VO_BENCH_PROFILE_TAG=$tag
 # the synthetic frames once, by worker processes outside the profiler (every run below reads them from the cache)
 export VO_SYNTH_CACHE=/tmp/vo_synth_cache
-python3 - <<'PY'
-import os, sys
-sys.path.insert(0, "visual-odometry-project_amd")
-from vo import synthetic
-jobs = [(k, 1241, 1376, seed) for seed in list(range(2023, 2039)) + list(range(3023, 3039)) for k in range(100)]
-jobs += [(k, 2160, 3840, 2023) for k in range(30)]
-synthetic.render_images(jobs, workers=max(1, min(12, (os.cpu_count() or 2) - 2)))
-print("rendered", len(jobs), "frames")
-PY
+timeout -k 10 400 python3 tools/prerender_frames.py >> gpurun_out/prof_progress.log 2>&1
 export VO_BENCH_RENDER_WORKERS=0
 echo "frames cached" >> gpurun_out/prof_progress.log
 cmd="python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-api --no-legs"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $cmd > $out/stats.log 2>&1; echo stats >> gpurun_out/prof_progress.log
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $cmd > $out/stats.log 2>&1; echo stats >> gpurun_out/prof_progress.log
 export VO_BENCH_DETECT_MARGIN=-1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $cmd > $out/fetch.log 2>&1; echo fetch >> gpurun_out/prof_progress.log
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- $cmd > $out/write.log 2>&1; echo write >> gpurun_out/prof_progress.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_all -- $cmd > $out/stats_all.log 2>&1; echo stats_all >> gpurun_out/prof_progress.log
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $cmd > $out/fetch.log 2>&1; echo fetch >> gpurun_out/prof_progress.log
+timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- $cmd > $out/write.log 2>&1; echo write >> gpurun_out/prof_progress.log
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_all -- $cmd > $out/stats_all.log 2>&1; echo stats_all >> gpurun_out/prof_progress.log
 unset VO_BENCH_DETECT_MARGIN
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16 -- $cmd --sequences 16 --steps 150 > $out/stats_s16.log 2>&1; echo stats_s16 >> gpurun_out/prof_progress.log
-VO_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_one -- $cmd > $out/stats_one.log 2>&1; echo stats_one >> gpurun_out/prof_progress.log
-VO_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16_one -- $cmd --sequences 16 --steps 100 > $out/stats_s16_one.log 2>&1; echo stats_s16_one >> gpurun_out/prof_progress.log
-VO_ONE_STREAM=1 VO_BENCH_DETECT_MARGIN=-1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16_one_all -- $cmd --sequences 16 --steps 100 > $out/stats_s16_one_all.log 2>&1; echo stats_s16_one_all >> gpurun_out/prof_progress.log
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16 -- $cmd --sequences 16 --steps 150 > $out/stats_s16.log 2>&1; echo stats_s16 >> gpurun_out/prof_progress.log
+VO_ONE_STREAM=1 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_one -- $cmd > $out/stats_one.log 2>&1; echo stats_one >> gpurun_out/prof_progress.log
+VO_ONE_STREAM=1 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16_one -- $cmd --sequences 16 --steps 100 > $out/stats_s16_one.log 2>&1; echo stats_s16_one >> gpurun_out/prof_progress.log
+VO_ONE_STREAM=1 VO_BENCH_DETECT_MARGIN=-1 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16_one_all -- $cmd --sequences 16 --steps 100 > $out/stats_s16_one_all.log 2>&1; echo stats_s16_one_all >> gpurun_out/prof_progress.log
 cp "$(ls $out/stats_one/*/*kernel_stats.csv | head -1)" $out/${tag}_one_stream_kernel_stats.csv
 cp "$(ls $out/stats_s16_one/*/*kernel_stats.csv | head -1)" $out/${tag}_s16_one_stream_kernel_stats.csv
 cp "$(ls $out/stats_s16_one_all/*/*kernel_stats.csv | head -1)" $out/${tag}_s16_one_stream_detect_every_frame_kernel_stats.csv
@@ -48,13 +40,13 @@ cp "$(ls $out/stats/*/*kernel_stats.csv | head -1)" $out/${tag}_bench_kernel_sta
 cp "$(ls $out/stats_s16/*/*kernel_stats.csv | head -1)" $out/${tag}_s16_kernel_stats.csv
 # the bench line reads the PMC figures it reports as roofline.traffic from profiles/<tag>_pmc_traffic.json
 cp $out/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json
-python3 bench.py > $out/${tag}_bench_line.json 2> $out/bench.err
-python3 bench.py --steps 20 --warmup 5 > $out/${tag}_bench_line_driver_flags.json 2> $out/bench_drv.err
-python3 bench.py --sequences 16 --steps 300 --warmup 30 --no-cpu-baseline --no-api --no-legs > $out/${tag}_s16_bench_line.json 2> $out/bench_s16.err
-VO_BENCH_DETECT_MARGIN=-1 python3 bench.py --no-cpu-baseline --no-api --no-legs > $out/${tag}_detect_every_frame_bench_line.json 2> $out/bench_da.err
-VO_BENCH_CONFIG=cfg3 python3 bench.py > $out/${tag}_cfg3_bench_line.json 2> $out/bench_cfg3.err
-VO_BENCH_CONFIG=harris python3 bench.py > $out/${tag}_harris_bench_line.json 2> $out/bench_harris.err
-VO_BENCH_CONFIG=cfg5 python3 bench.py --steps 300 --warmup 40 --no-cpu-baseline --no-api --no-legs > $out/${tag}_cfg5_bench_line.json 2> $out/bench_cfg5.err
+timeout -k 10 300 python3 bench.py > $out/${tag}_bench_line.json 2> $out/bench.err
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $out/${tag}_bench_line_driver_flags.json 2> $out/bench_drv.err
+timeout -k 10 300 python3 bench.py --sequences 16 --steps 300 --warmup 30 --no-cpu-baseline --no-api --no-legs > $out/${tag}_s16_bench_line.json 2> $out/bench_s16.err
+VO_BENCH_DETECT_MARGIN=-1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-api --no-legs > $out/${tag}_detect_every_frame_bench_line.json 2> $out/bench_da.err
+VO_BENCH_CONFIG=cfg3 timeout -k 10 300 python3 bench.py > $out/${tag}_cfg3_bench_line.json 2> $out/bench_cfg3.err
+VO_BENCH_CONFIG=harris timeout -k 10 300 python3 bench.py > $out/${tag}_harris_bench_line.json 2> $out/bench_harris.err
+VO_BENCH_CONFIG=cfg5 timeout -k 10 300 python3 bench.py --steps 300 --warmup 40 --no-cpu-baseline --no-api --no-legs > $out/${tag}_cfg5_bench_line.json 2> $out/bench_cfg5.err
 for f in $out/${tag}*_bench_line*.json; do echo "$f: $(grep -o '"value": [0-9.]*' $f | head -1)"; done
 # only the condensed files travel back (the raw traces are tens of MB)
 mkdir -p gpurun_out/profiles_$tag
