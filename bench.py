@@ -405,7 +405,7 @@ def cfg3_main(args, tracker="sift"):
                                           "OpenCV's BFMatcher")}
         out["cpu_baseline"] = {"value": ORACLE_FRAMES / cpu_s, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "%d frames through the CPU oracle of the loop, single thread, %.1f s" % (ORACLE_FRAMES, cpu_s)}
-    print(json.dumps(out), flush=True)
+    _Stdout.emit(out)
     pipe.close()
     ctx.close()
 
@@ -420,7 +420,8 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
            "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
            os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.run(cmd).returncode)
+    # (this process's descriptor 1 points at stderr, see _Stdout: the ranks get the real stdout)
+    raise SystemExit(subprocess.run(cmd, stdout=_Stdout.file.fileno() if _Stdout.file else None).returncode)
 
 
 def make_pipeline(ctx, streams, states, S, detect_margin, hyp=None):
@@ -478,7 +479,27 @@ def timed_leg(ctx, pipe, S, warm, steps):
             "ransac_iters_median": st["ransac_iters_median"]}
 
 
+class _Stdout:
+    """The process's real stdout kept aside for the ONE JSON line; file descriptor 1 itself is pointed at stderr, so
+    that what native libraries print (RCCL's version banner at communicator creation) cannot precede or follow the line."""
+    file = None
+
+    @classmethod
+    def isolate(cls):
+        if cls.file is None:
+            sys.stdout.flush()
+            cls.file = os.fdopen(os.dup(1), "w")
+            os.dup2(2, 1)
+
+    @classmethod
+    def emit(cls, obj):
+        f = cls.file or sys.stdout
+        f.write(json.dumps(obj) + "\n")
+        f.flush()
+
+
 def main():
+    _Stdout.isolate()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -799,7 +820,7 @@ def main():
                     p4 = make_pipeline(ctx, leg_streams, leg_states, S_LEG, -1.0)
                     out["sequences_16_detector_every_frame"] = timed_leg(ctx, p4, S_LEG, 30, 2 * (N_FRAMES - 1 - PASS_START))
                     p4.close()
-        print(json.dumps(out), flush=True)
+        _Stdout.emit(out)
     if pipe is not None:
         pipe.close()
     ctx.close()
