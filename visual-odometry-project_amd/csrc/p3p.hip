@@ -457,9 +457,12 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
 //   run beside it), inlier bits leave as one ballot word per wave, counts as popcounts.
 // HG hypotheses per workgroup: 8 for one sequence (125 workgroups at 1000 hypotheses: latency), 16 when a launch holds
 // several sequences (wave 0's 64 lanes all solve, half as many workgroups share the solve's latency: throughput).
-constexpr int HP = 7;      // correspondences per thread and tile (256 * 7 = 1792 = 28 mask words)
+// Correspondences per thread and tile: 7 for HG = 8 (256 * 7 = 1792 = 28 mask words: one tile at every population the
+// frame loop sees), 4 for HG = 16, which with five waves per SIMD asked for (96 registers: the solve spills 11 words,
+// the scoring loop none) puts the 72 x 16 workgroups of a 16-sequence launch on the chip in one round instead of two.
 template <int HG>
-__global__ __launch_bounds__(256) void p3p_hyp_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HG == 16 ? 5 : 4, HG == 16 ? 5 : 4))) void
+p3p_hyp_kernel(const double* __restrict__ Xw, const double* __restrict__ xi,
                                                       const unsigned* __restrict__ raws,
                                                       const unsigned long long* __restrict__ d_rawpos, unsigned raw_mask,
                                                       const int* __restrict__ d_n, unsigned* __restrict__ flag, int Hyp,
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(256) void p3p_hyp_kernel(const double* __restrict__
                                                       uint8_t* __restrict__ valid, int* __restrict__ counts,
                                                       unsigned long long* __restrict__ masks, int words,
                                                       unsigned long long* __restrict__ ts_out, vo_hyp_batch B) {
+  constexpr int HP = HG == 16 ? 4 : 7;
   __shared__ int s_cnt[4][HG];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (blockIdx.y != 0) {               // several sequences per launch: grid.y = sequence
