@@ -1,0 +1,20 @@
+#!/bin/bash
+# extrema kernel with and without extrema (threshold 1e30): is the candidate append what bounds it?
+set -eo pipefail
+out=gpurun_out/sift_thr
+mkdir -p $out
+export TMPDIR=/tmp VO_SYNTH_CACHE=/tmp/vo_synth_cache
+cp tools/dev/libvo_hip_dbg.so visual-odometry-project_amd/vo/lib/libvo_hip.so
+for t in none 1e30; do
+  if [ $t != none ]; then export VO_SIFT_DEBUG_THRESHOLD=$t; fi
+  timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/t_$t -- python3 tools/dev/sift_one.py > $out/log_$t.txt 2>&1
+  python3 - $out/t_$t <<'PY'
+import sys, glob, csv
+fn = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+rows = sorted(csv.DictReader(open(fn)), key=lambda r: int(r["Start_Timestamp"]))
+rows = [r for r in rows if "extrema" in r["Kernel_Name"] or "orient" in r["Kernel_Name"] or "descriptor" in r["Kernel_Name"]]
+for r in rows[-12:]:
+    print("%8.1f us grid %sx%s %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Grid_Size_X"], r["Grid_Size_Y"], r["Kernel_Name"][:50]))
+PY
+  rm -rf $out/t_$t
+done

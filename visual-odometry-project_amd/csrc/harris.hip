@@ -90,7 +90,8 @@ __global__ __launch_bounds__(NT) void harris_response_kernel(const uint8_t* __re
                                                         // take their place (29.3 KB per workgroup, five per CU, not four)
 
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * RX, y0 = blockIdx.y * RY;
+  const unsigned tile = vo_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int x0 = (int)(tile % gridDim.x) * RX, y0 = (int)(tile / gridDim.x) * RY;
   const int ix0 = x0 - pr - 1, iy0 = y0 - pr - 1;   // image coords of s_img[0][0]
 
   // A: image tile + halo (zeros outside the image; such pixels only feed outputs
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(NT) void nms_candidates_kernel(const double* __rest
   __shared__ unsigned s_coarse[256];   // the tile's share of the coarse histogram level
 
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * CX, y0 = blockIdx.y * CY;
-  const unsigned blk = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned blk = vo_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);   // (tile = segment index)
+  const int x0 = (int)(blk % gridDim.x) * CX, y0 = (int)(blk / gridDim.x) * CY;
   if (tid < 3) s_cnt[tid] = 0;
   s_coarse[tid] = 0;
 
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(RT) void nms_round_kernel(const double* __restrict_
   __shared__ unsigned short s_sel[SEG];          // candidates selected in this launch
   __shared__ unsigned short s_pass2[SEG];        // ... after the dense filter
   __shared__ unsigned s_npass, s_npass2, s_nsel, s_prog;
-  const unsigned blk = blockIdx.x;
+  const unsigned blk = vo_xcd_tile(blockIdx.x, gridDim.x);
   const unsigned n = seg_cnt[blk].z;
   const int tid = threadIdx.x;
   if (n == 0 || seg_cnt[blk].w == 0) return;

@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void pyramid3_tiled_kernel(const uint8_t* __re
   __shared__ unsigned s_f[PT_FR * PT_FD];
   __shared__ __attribute__((aligned(4))) uint8_t s_l1[PT_RY * PT_L1P];
   const int tid = threadIdx.x;
-  const int x1a = ((int)blockIdx.x % tiles_x) * PT_X, y1a = ((int)blockIdx.x / tiles_x) * PT_Y;
+  const int tile = (int)vo_xcd_tile(blockIdx.x, gridDim.x);
+  const int x1a = (tile % tiles_x) * PT_X, y1a = (tile / tiles_x) * PT_Y;
   const int gx0 = 2 * x1a - 8, gy0 = 2 * y1a - 6;
   // ---- A: frame patch ----
   {

@@ -90,23 +90,114 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const uint8_t* __restric
   out[(size_t)y * W0 + x] = top * (1.f - fy) + bot * fy;
 }
 
-// Row pass and column pass of one Gaussian in one launch: a 64x32 output tile, its input with `r` pixels of halo and
-// the row-blurred intermediate live in LDS (the image-wide version reads every input 2 (2r + 1) times through the
-// cache hierarchy and round-trips the intermediate through HBM).  Each sum runs in tap order without FMA, as above.
-// R_T > 0: radius known at compile time -- the tap loops unroll, so a sum's LDS reads are all in flight before its
-// first addition (with a runtime trip count every tap waits for its own read: 15-25 us for a single tile).
-constexpr int BT_W = 64, BT_H = 32;
-template <int R_T>
+// Row pass and column pass of one Gaussian in one launch: an output tile, its input with `r` pixels of halo and the
+// row-blurred intermediate live in LDS (the image-wide version reads every input 2 (2r + 1) times through the cache
+// hierarchy and round-trips the intermediate through HBM).  Each sum runs in tap order without FMA, as above.
+//
+// Radius known at compile time (every radius cv2.SIFT_create()'s default sigmas produce): a 32 x 64 tile -- tall, the
+// row pass also runs over the 2r halo rows --, and every work item makes several neighbouring outputs from one set of
+// registers: four along x in the row pass (4 + 2r inputs in 16-byte LDS reads), eight down y in the column pass (8 + 2r
+// reads) -- a sixth of the LDS reads of one output per work item.  Measured: no faster (octave 0: 21 us at r = 5, 42 us
+// at r = 13, i.e. 54 MB at 1.3-2.6 TB/s; the launches of octaves >= 2 are 5-6 us whatever the kernel does).
+constexpr int BT_W = 64, BT_H = 32;      // tile of the run-time-radius kernel
+constexpr int BR_W = 32, BR_H = 64;      // tile of the compile-time-radius kernel
+constexpr int BR_RB = 4, BR_CB = 8;      // outputs per work item: row pass, column pass
+template <int R>
+struct blur_geom {
+  static constexpr int PW = BR_W + 2 * R;            // input columns of a tile
+  static constexpr int PI = (PW + 3) & ~3;           // their pitch in LDS: rows start on 16 bytes
+  static constexpr int RH = BR_H + 2 * R;            // input rows
+  static constexpr int NV = 4 + ((2 * R + 3) & ~3);  // values a row-pass work item reads (whole float4s)
+  static constexpr size_t lds = (size_t)RH * (PI + BR_W) * 4;
+};
+template <int R>
+__global__ __launch_bounds__(256) void blur2d_rb_kernel(const float* __restrict__ src, int H, int W, taps_t k,
+                                                        float* __restrict__ dst) {
+  typedef blur_geom<R> G;
+  extern __shared__ __align__(16) float blur_smem[];
+  float* s_in = blur_smem;                  // RH x PI
+  float* s_mid = blur_smem + G::RH * G::PI; // RH x BR_W
+  const int tid = threadIdx.x;
+  const unsigned tile = vo_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int x0 = (int)(tile % gridDim.x) * BR_W, y0 = (int)(tile / gridDim.x) * BR_H;
+  // the tile with its halo, eight loads per work item in flight at a time
+  {
+    constexpr int total = G::RH * G::PW;
+    const bool inside = x0 - R >= 0 && y0 - R >= 0 && x0 - R + G::PW <= W && y0 - R + G::RH <= H;
+    const float* base_p = src + (ptrdiff_t)(y0 - R) * W + (x0 - R);
+    for (int base = 0; base < total; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(base + u * 256 + tid, total - 1);
+        const int ky = i / G::PW, kx = i - ky * G::PW;
+        v[u] = inside ? base_p[(ptrdiff_t)ky * W + kx] : src[(size_t)refl(y0 - R + ky, H) * W + refl(x0 - R + kx, W)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 256 + tid;
+        const int ky = i / G::PW, kx = i - ky * G::PW;
+        if (i < total) s_in[ky * G::PI + kx] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  // row pass: four neighbouring outputs per work item
+  {
+    constexpr int GR = BR_W / BR_RB;
+    for (int it = tid; it < G::RH * GR; it += 256) {
+      const int ky = it / GR, g = it - ky * GR;
+      const float4* q = reinterpret_cast<const float4*>(s_in + ky * G::PI + BR_RB * g);
+      float v[G::NV];
+#pragma unroll
+      for (int m = 0; m < G::NV / 4; ++m) {
+        const float4 t = q[m];
+        v[4 * m] = t.x;
+        v[4 * m + 1] = t.y;
+        v[4 * m + 2] = t.z;
+        v[4 * m + 3] = t.w;
+      }
+      float o[BR_RB];
+#pragma unroll
+      for (int e = 0; e < BR_RB; ++e) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j <= 2 * R; ++j) a += k.w[j] * v[e + j];
+        o[e] = a;
+      }
+      *reinterpret_cast<float4*>(s_mid + ky * BR_W + BR_RB * g) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  __syncthreads();
+  // column pass: eight outputs down a column per work item (256 work items = 32 columns x 8 strips)
+  {
+    static_assert(BR_W * (BR_H / BR_CB) == 256, "one column strip per work item");
+    const int lx = tid & (BR_W - 1), ys = (tid / BR_W) * BR_CB;
+    const float* q = s_mid + ys * BR_W + lx;
+    float v[BR_CB + 2 * R];
+#pragma unroll
+    for (int j = 0; j < BR_CB + 2 * R; ++j) v[j] = q[j * BR_W];
+    const int x = x0 + lx;
+#pragma unroll
+    for (int e = 0; e < BR_CB; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j <= 2 * R; ++j) a += k.w[j] * v[e + j];
+      const int y = y0 + ys + e;
+      if (x < W && y < H) dst[(size_t)y * W + x] = a;
+    }
+  }
+}
+
+// any radius (run-time trip counts: every tap waits for its own LDS read)
 __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ src, int H, int W, taps_t k,
                                                      float* __restrict__ dst) {
-  extern __shared__ float blur_smem[];
-  const int r = R_T > 0 ? R_T : k.r, PI = BT_W + 2 * r, RH = BT_H + 2 * r;
+  extern __shared__ __align__(16) float blur_smem[];
+  const int r = k.r, PI = BT_W + 2 * r, RH = BT_H + 2 * r;
   float* s_in = blur_smem;                 // RH x PI
   float* s_mid = blur_smem + RH * PI;      // RH x BT_W
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
-  // the tile with its halo: eight loads per work item in flight at a time (one load per trip leaves every trip waiting
-  // for its own round trip: ~20 of them, 8-10 us of a launch that the small octaves are nothing else but)
   {
     const int total = RH * PI;
     for (int base = 0; base < total; base += 256 * 8) {
@@ -128,12 +219,7 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ s
   for (int ky = ty; ky < RH; ky += 4) {
     const float* q = s_in + ky * PI + tx;
     float s = 0.f;
-    if (R_T > 0) {
-#pragma unroll
-      for (int j = 0; j <= 2 * R_T; ++j) s += k.w[j] * q[j];
-    } else {
-      for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j];
-    }
+    for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j];
     s_mid[ky * BT_W + tx] = s;
   }
   __syncthreads();
@@ -143,12 +229,7 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ s
     if (x >= W || y >= H) continue;
     const float* q = s_mid + ly * BT_W + tx;
     float s = 0.f;
-    if (R_T > 0) {
-#pragma unroll
-      for (int j = 0; j <= 2 * R_T; ++j) s += k.w[j] * q[j * BT_W];
-    } else {
-      for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j * BT_W];
-    }
+    for (int j = 0; j <= 2 * r; ++j) s += k.w[j] * q[j * BT_W];
     dst[(size_t)y * W + x] = s;
   }
 }
@@ -178,32 +259,105 @@ struct octs_t {
 // counters of one vo_sift call (device): [0] extrema candidates, [1] keypoints, [2] overflow flag,
 // [3] refined survivors, [4] rows selected for description
 enum { C_CAND = 0, C_KP = 1, C_OVER = 2, C_SURV = 3, C_SEL = 4 };
+// The extrema are appended to EX_SUB lists, not one: a returning atomic on ONE counter completes at ~90 per microsecond
+// chip-wide, and a textured frame makes ~10^4 wave-level reservations per octave -- with one list the append was 80 us of
+// the 100 us an octave-1 launch took.  List j: entries [j * subcap, ...) of the candidate array, its counter C_SUB + 32 j
+// (a 128-byte line of its own) in the counter block; a tile appends to list (tile mod EX_SUB).
+constexpr int EX_SUB = 32, C_SUB = 16, C_WORDS = C_SUB + 32 * EX_SUB;
 
-// 26-neighbour extrema of the three inner DoG layers of one octave in one pass over its six Gaussian layers: the
-// centre differences first (six coalesced loads per pixel), the neighbourhood only where a centre passes the threshold.
+// 26-neighbour extrema of the three inner DoG layers of one octave in one pass over its six Gaussian layers.  A 64 x 16
+// tile per workgroup: the five difference values of the tile and one ring of neighbours go to LDS (six coalesced loads
+// per pixel, all in flight together), the tests then read LDS.  (With the neighbourhood read from memory, 54 dependent
+// loads per centre that passes the threshold and most centres of a textured frame passing, the launch took 270 us on
+// octave 0: 0.6 TB/s for 164 MB.)
+constexpr int EX_W = 64, EX_H = 16, EX_PW = EX_W + 2, EX_PH = EX_H + 2;
 __global__ __launch_bounds__(256) void extrema_kernel(oct_t O, float threshold, int4* __restrict__ cand,
-                                                      unsigned* __restrict__ n_cand, unsigned cap) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (c < BORDER || c >= O.W - BORDER || r < BORDER || r >= O.H - BORDER) return;
-  const size_t p = (size_t)r * O.W + c;
-  float gv[NG];
+                                                      unsigned* __restrict__ sub_cnt, unsigned subcap) {
+  __shared__ float s_d[NG - 1][EX_PH][EX_PW];
+  const int tid = threadIdx.x;
+  const unsigned tile = vo_xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int x0 = (int)(tile % gridDim.x) * EX_W, y0 = (int)(tile / gridDim.x) * EX_H;
+  unsigned* n_cand = sub_cnt + 32u * (tile % (unsigned)EX_SUB);
+  cand += (size_t)(tile % (unsigned)EX_SUB) * subcap;
+  {
+    constexpr int total = EX_PH * EX_PW, PER = (total + 255) / 256;
+    float gv[PER][NG];
 #pragma unroll
-  for (int i = 0; i < NG; ++i) gv[i] = O.g[i][p];
+    for (int u = 0; u < PER; ++u) {
+      const int i = min(tid + u * 256, total - 1);
+      const int ly = i / EX_PW, lx = i - ly * EX_PW;
+      const int gy = min(max(y0 - 1 + ly, 0), O.H - 1), gx = min(max(x0 - 1 + lx, 0), O.W - 1);   // (clamped entries are never a
+      const size_t p = (size_t)gy * O.W + gx;                                                     //  neighbour of a tested centre)
 #pragma unroll
-  for (int layer = 1; layer <= NOL; ++layer) {
-    const float val = gv[layer + 1] - gv[layer];
-    if (!(fabsf(val) > threshold)) continue;
-    const dog_t img = dog_layer(O, layer), prv = dog_layer(O, layer - 1), nxt = dog_layer(O, layer + 1);
-    bool ext = true;
-    for (int dy = -1; dy <= 1; ++dy)
-      for (int dx = -1; dx <= 1; ++dx) {
-        const size_t q = p + dy * O.W + dx;
-        const float vi = img[q], vp = prv[q], vn = nxt[q];
-        if (val > 0 ? (val < vi || val < vp || val < vn) : (val > vi || val > vp || val > vn)) ext = false;
+      for (int l = 0; l < NG; ++l) gv[u][l] = O.g[l][p];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = tid + u * 256;
+      if (i < total) {
+        const int ly = i / EX_PW, lx = i - ly * EX_PW;
+#pragma unroll
+        for (int l = 0; l < NG - 1; ++l) s_d[l][ly][lx] = gv[u][l + 1] - gv[u][l];
       }
-    if (!ext) continue;
-    const unsigned pos = atomicAdd(n_cand, 1u);
-    if (pos < cap) cand[pos] = make_int4(O.o, layer, r, c);
+    }
+  }
+  __syncthreads();
+  // A centre is an extremum when no neighbour lies beyond it: for a positive centre the largest of the 27 values is the
+  // centre itself, for a negative one the smallest.  Largest and smallest separably: over the three layers at every
+  // position, over three columns, over three rows -- a work item owns a strip of four rows of one column, 90 LDS reads
+  // and ~300 operations for its 12 (pixel, layer) tests (the plain 26-neighbour loop: 81 reads and ~200 operations per
+  // test that passes the threshold, most of a textured frame -- the launch was bound by it, 120 us on octave 0).
+  const int lx = tid & 63, ls = (tid >> 6) * (EX_H / 4);
+  static_assert(EX_H / 4 == 4 && NOL == 3 && NG == 6, "strips of four rows, three tested layers out of five differences");
+  float hmx[6][3], hmn[6][3], ctr[4][3];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {                  // region row ls + j = tile row ls + j - 1
+    float M[3][3], N[3][3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      const float d0 = s_d[0][ls + j][lx + cc], d1 = s_d[1][ls + j][lx + cc], d2 = s_d[2][ls + j][lx + cc],
+                  d3 = s_d[3][ls + j][lx + cc], d4 = s_d[4][ls + j][lx + cc];
+      const float m12 = fmaxf(d1, d2), m23 = fmaxf(d2, d3), n12 = fminf(d1, d2), n23 = fminf(d2, d3);
+      M[cc][0] = fmaxf(d0, m12);
+      M[cc][1] = fmaxf(m12, d3);
+      M[cc][2] = fmaxf(m23, d4);
+      N[cc][0] = fminf(d0, n12);
+      N[cc][1] = fminf(n12, d3);
+      N[cc][2] = fminf(n23, d4);
+      if (cc == 1 && j >= 1 && j <= 4) {
+        ctr[j - 1][0] = d1;
+        ctr[j - 1][1] = d2;
+        ctr[j - 1][2] = d3;
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      hmx[j][l] = fmaxf(fmaxf(M[0][l], M[1][l]), M[2][l]);
+      hmn[j][l] = fminf(fminf(N[0][l], N[1][l]), N[2][l]);
+    }
+  }
+  const int c = x0 + lx;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = y0 + ls + k;
+    const bool inner = c >= BORDER && c < O.W - BORDER && r >= BORDER && r < O.H - BORDER;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const float val = ctr[k][l];
+      const float mx = fmaxf(fmaxf(hmx[k][l], hmx[k + 1][l]), hmx[k + 2][l]);
+      const float mn = fminf(fminf(hmn[k][l], hmn[k + 1][l]), hmn[k + 2][l]);
+      const bool ext = inner && fabsf(val) > threshold && (val > 0 ? val >= mx : val <= mn);
+      // one reservation per wave
+      const unsigned long long m = __ballot(ext);
+      if (m != 0ull) {
+        const int leader = __builtin_ctzll(m);
+        unsigned base = 0;
+        if ((tid & 63) == leader) base = atomicAdd(n_cand, (unsigned)__popcll(m));
+        base = __shfl(base, leader);
+        const unsigned pos = base + (unsigned)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+        if (ext && pos < subcap) cand[pos] = make_int4(O.o, l + 1, r, c);
+      }
+    }
   }
 }
 
@@ -254,13 +408,22 @@ struct surv_t {
 // that converge to the same (octave, layer, row, column) produce identical keypoints, which the reference removes
 // after sorting (KeyPointsFilter::removeDuplicatedSorted): only the first to claim the cell in the hash table goes on.
 __global__ __launch_bounds__(256) void refine_kernel(octs_t OS, const int4* __restrict__ cand,
-                                                     const unsigned* __restrict__ n_cand, unsigned cap,
+                                                     const unsigned* __restrict__ sub_cnt, unsigned subcap,
                                                      float contrast_thr, float edge_thr, float sigma,
                                                      unsigned long long* __restrict__ table, unsigned table_mask,
                                                      surv_t* __restrict__ out, unsigned* __restrict__ n_out,
                                                      unsigned cap_out) {
-  const unsigned n = min(*n_cand, cap);
-  for (unsigned k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+  // candidate v of the EX_SUB lists taken one behind the other
+  unsigned first[EX_SUB + 1];
+  first[0] = 0;
+#pragma unroll
+  for (int j = 0; j < EX_SUB; ++j) first[j + 1] = first[j] + min(sub_cnt[32 * j], subcap);
+  const unsigned n = first[EX_SUB];
+  for (unsigned v = blockIdx.x * 256 + threadIdx.x; v < n; v += gridDim.x * 256) {
+    unsigned k = v;
+#pragma unroll
+    for (int j = 1; j < EX_SUB; ++j)
+      if (v >= first[j]) k = (unsigned)j * subcap + (v - first[j]);
     const int4 cd = cand[k];
     const oct_t& O = OS.o[cd.x];
     int layer = cd.y, r = cd.z, c = cd.w;
@@ -385,16 +548,27 @@ constexpr int ORI_RMAX = 17, DESC_RMAX = 39;   // radii cv2's default parameters
 // in pixel raster order; here 64 lanes evaluate 64 consecutive raster positions (gradient, exp, atan2: the
 // expensive part), their (bin, weight) pairs are compacted in raster order into LDS, and lane b adds the pairs of
 // bin b in that order -- every bin sees exactly the sequence of additions of the sequential loop.
-__global__ __launch_bounds__(64) void orient_kernel(octs_t OS, const surv_t* __restrict__ surv,
-                                                    const unsigned* __restrict__ n_surv, unsigned cap_surv,
-                                                    skp_t* __restrict__ out, unsigned* __restrict__ n_out,
-                                                    unsigned cap_out) {
-  __shared__ float s_add[64];
-  __shared__ float s_tmp[36];
-  __shared__ float s_patch[(2 * ORI_RMAX + 3) * (2 * ORI_RMAX + 3)];
-  const int lane = threadIdx.x;
+// Four waves per workgroup, each with its own staging areas; the keypoints a workgroup makes are collected in LDS and
+// appended to the list with ONE reservation (one returning atomic per keypoint on the one counter -- ~10^4 of them --
+// bounds the launch at the counter's ~90 operations per microsecond).
+constexpr int ORI_WAVES = 4, ORI_BUF = 96;
+__global__ __launch_bounds__(64 * ORI_WAVES) void orient_kernel(octs_t OS, const surv_t* __restrict__ surv,
+                                                                const unsigned* __restrict__ n_surv, unsigned cap_surv,
+                                                                skp_t* __restrict__ out, unsigned* __restrict__ n_out,
+                                                                unsigned cap_out) {
+  __shared__ float s_add_w[ORI_WAVES][64];
+  __shared__ float s_tmp_w[ORI_WAVES][36];
+  __shared__ float s_patch_w[ORI_WAVES][(2 * ORI_RMAX + 3) * (2 * ORI_RMAX + 3)];
+  __shared__ skp_t s_buf[ORI_BUF];
+  __shared__ unsigned s_nbuf, s_base;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* s_add = s_add_w[wv];
+  float* s_tmp = s_tmp_w[wv];
+  float* s_patch = s_patch_w[wv];
+  if (threadIdx.x == 0) s_nbuf = 0;
+  __syncthreads();
   const unsigned n = min(*n_surv, cap_surv);
-  for (unsigned k = blockIdx.x; k < n; k += gridDim.x) {
+  for (unsigned k = blockIdx.x * ORI_WAVES + wv; k < n; k += gridDim.x * ORI_WAVES) {
     const surv_t sv = surv[k];
     const oct_t& O = OS.o[sv.kp.oct];
     const int W = O.W, H = O.H, r = sv.r, c = sv.c;
@@ -474,16 +648,27 @@ __global__ __launch_bounds__(64) void orient_kernel(octs_t OS, const surv_t* __r
         bin = bin < 0 ? 36 + bin : (bin >= 36 ? bin - 36 : bin);
         float angle = 360.f - (360.f / 36) * bin;
         if (fabsf(angle - 360.f) < 1.1920929e-07f) angle = 0.f;
-        const unsigned pos = atomicAdd(n_out, 1u);
-        if (pos < cap_out) {
-          skp_t q = sv.kp;
-          q.angle = angle;
-          out[pos] = q;
+        skp_t q = sv.kp;
+        q.angle = angle;
+        const unsigned slot = atomicAdd(&s_nbuf, 1u);
+        if (slot < (unsigned)ORI_BUF) {
+          s_buf[slot] = q;
+        } else {                                       // (the buffer is full: this one goes to the list directly)
+          const unsigned pos = atomicAdd(n_out, 1u);
+          if (pos < cap_out) out[pos] = q;
         }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  const unsigned nb = min(s_nbuf, (unsigned)ORI_BUF);
+  if (threadIdx.x == 0 && nb) s_base = atomicAdd(n_out, nb);
+  __syncthreads();
+  if (threadIdx.x < nb) {
+    const unsigned pos = s_base + threadIdx.x;
+    if (pos < cap_out) out[pos] = s_buf[threadIdx.x];
   }
 }
 
@@ -722,6 +907,8 @@ __global__ __launch_bounds__(DESC_T) void descriptor_kernel(pyr_ptrs P, const sk
           const unsigned long long o0m = ob <= 7 ? m[10 + ob] : 0ull;
           unsigned long long mine = (m[cr] | r1) & (m[5 + cc] | c1) & (o0m | o1);
           const float* vw = s_v + w * 64 * DESC_VP;
+          // (tried: the masks as 32-bit halves with two samples' shares requested before the first addition -- 313 us
+          //  against 265 for the launch: every loop runs as long as its busiest bin, and two loops per wave add up)
           while (mine) {
             const int e = __builtin_ctzll(mine);
             mine &= mine - 1ull;
@@ -776,8 +963,10 @@ __global__ __launch_bounds__(DESC_T) void descriptor_kernel(pyr_ptrs P, const sk
   }
 }
 
-__global__ void overflow_kernel(const unsigned* cnt, unsigned cap_cand, unsigned cap_kp, unsigned* flag) {
-  if (cnt[C_CAND] > cap_cand || cnt[C_SURV] > cap_kp || cnt[C_KP] > cap_kp) *flag = 1u;
+__global__ void overflow_kernel(const unsigned* cnt, unsigned subcap, unsigned cap_kp, unsigned* flag) {
+  bool over = cnt[C_SURV] > cap_kp || cnt[C_KP] > cap_kp;
+  for (int j = 0; j < EX_SUB; ++j) over = over || cnt[C_SUB + 32 * j] > subcap;
+  if (over) *flag = 1u;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -838,8 +1027,7 @@ __device__ __forceinline__ unsigned block_scan4(const unsigned (&f)[4], unsigned
 }
 
 __global__ __launch_bounds__(FIN_T) void sift_finalize_kernel(const float* __restrict__ rows, const unsigned* __restrict__ n_rows,
-                                                              int cap, float* __restrict__ kp_out, float* __restrict__ desc_out,
-                                                              uint8_t* __restrict__ desc_bytes, int* __restrict__ n_out,
+                                                              int cap, unsigned* __restrict__ src_out, int* __restrict__ n_out,
                                                               unsigned* __restrict__ overflow) {
   extern __shared__ __align__(16) unsigned s_fin[];
   unsigned* s_key = s_fin;                       // [FIN_MAX][4]
@@ -952,26 +1140,26 @@ __global__ __launch_bounds__(FIN_T) void sift_finalize_kernel(const float* __res
     for (int k = 0; k < 4; ++k) keep[k] = (above[k] || (tie[k] && tpos[k] < ties)) ? 1u : 0u;
     n_keep = block_scan4(keep, pos, s_wave);
   }
-  // destination -> row, then the copy by everybody
-  __syncthreads();
-  unsigned* s_src = s_key;                        // (the keys are done)
+  // destination -> row; the rows themselves are moved by the launch behind this one (sift_gather_kernel: a workgroup per
+  // row -- as this workgroup's tail the copy of 2000 x 134 values was half of the kernel's 215 us)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const unsigned sidx = 4u * tid + k;
-    if (keep[k]) s_src[pos[k]] = s_row[sidx];
+    if (keep[k]) src_out[pos[k]] = s_row[sidx];
   }
-  __syncthreads();
   if (tid == 0) *n_out = (int)n_keep;
-  for (unsigned e = tid; e < n_keep * 134u; e += FIN_T) {
-    const unsigned d = e / 134u, c = e - d * 134u;
-    const float v = rows[(size_t)s_src[d] * 134 + c];
-    if (c < 6) {
-      kp_out[(size_t)d * 6 + c] = v;
-    } else {
-      if (desc_out) desc_out[(size_t)d * 128 + (c - 6)] = v;
-      if (desc_bytes) desc_bytes[(size_t)d * 128 + (c - 6)] = (uint8_t)v;     // (whole numbers 0..255 by construction)
-    }
-  }
+}
+
+__global__ __launch_bounds__(128) void sift_gather_kernel(const float* __restrict__ rows, const unsigned* __restrict__ src,
+                                                          const int* __restrict__ n_out, float* __restrict__ kp_out,
+                                                          float* __restrict__ desc_out, uint8_t* __restrict__ desc_bytes) {
+  const unsigned d = blockIdx.x, c = threadIdx.x;
+  if ((int)d >= *n_out) return;
+  const float* r = rows + (size_t)src[d] * 134;
+  const float v = r[6 + c];
+  if (desc_out) desc_out[(size_t)d * 128 + c] = v;
+  if (desc_bytes) desc_bytes[(size_t)d * 128 + c] = (uint8_t)v;     // (whole numbers 0..255 by construction)
+  if (c < 6) kp_out[(size_t)d * 6 + c] = r[c];
 }
 
 taps_t make_taps(double sigma) {
@@ -1039,19 +1227,19 @@ static int sift_enqueue(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap
       h /= 2;
     }
   }
-  const unsigned cap_kp = (unsigned)vo_sift_capacity(H, W), cap_cand = 4u * cap_kp;
+  const unsigned cap_kp = (unsigned)vo_sift_capacity(H, W), subcap = cap_kp, cap_cand = (unsigned)EX_SUB * subcap;
   VO_TRY(vo_ensure(ctx, ctx->sift_arena, total * 4));
   unsigned table_len = 1;
   while (table_len < 4u * cap_kp) table_len <<= 1;
   VO_TRY(vo_ensure(ctx, ctx->scratch[0], (size_t)cap_cand * 16));
   VO_TRY(vo_ensure(ctx, ctx->scratch[1], (size_t)cap_kp * sizeof(skp_t)));
-  VO_TRY(vo_ensure(ctx, ctx->scratch[2], 64));
+  VO_TRY(vo_ensure(ctx, ctx->scratch[2], ((size_t)C_WORDS + FIN_MAX) * 4));   // counters, then sift_finalize's row order
   VO_TRY(vo_ensure(ctx, ctx->scratch[3], (size_t)cap_kp * 134 * 4));
   VO_TRY(vo_ensure(ctx, ctx->scratch[4], (size_t)cap_kp * sizeof(surv_t)));
   VO_TRY(vo_ensure(ctx, ctx->scratch[5], (size_t)table_len * 8));
   VO_TRY(vo_ensure(ctx, ctx->scratch[6], (size_t)cap_kp * 4));
   unsigned* d_cnt = (unsigned*)ctx->scratch[2].p;   // counters of this call, see C_CAND ..
-  VO_HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, 64, st));
+  VO_HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, (size_t)C_WORDS * 4, st));
   VO_HIP_TRY(ctx, hipMemsetAsync(ctx->scratch[5].p, 0, (size_t)table_len * 8, st));
 
   float* arena = (float*)ctx->sift_arena.p;
@@ -1087,15 +1275,17 @@ static int sift_enqueue(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap
   }
   auto grid2 = [](int w, int h) { return dim3(vo_cdiv(w, 64), vo_cdiv(h, 4)); };
   auto blur = [&](hipStream_t on, const float* src, int h, int w, const taps_t& t, float* dst) {
-    const size_t lds = (size_t)(BT_H + 2 * t.r) * (2 * BT_W + 2 * t.r) * 4;
-    const dim3 grid(vo_cdiv(w, BT_W), vo_cdiv(h, BT_H));
+    const dim3 grid(vo_cdiv(w, BR_W), vo_cdiv(h, BR_H));
     switch (t.r) {   // the radii of cv2.SIFT_create()'s default sigma
-      case 5: hipLaunchKernelGGL(blur2d_kernel<5>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
-      case 6: hipLaunchKernelGGL(blur2d_kernel<6>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
-      case 8: hipLaunchKernelGGL(blur2d_kernel<8>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
-      case 10: hipLaunchKernelGGL(blur2d_kernel<10>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
-      case 13: hipLaunchKernelGGL(blur2d_kernel<13>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
-      default: hipLaunchKernelGGL(blur2d_kernel<0>, grid, dim3(256), lds, on, src, h, w, t, dst); break;
+      case 5: hipLaunchKernelGGL(blur2d_rb_kernel<5>, grid, dim3(256), blur_geom<5>::lds, on, src, h, w, t, dst); break;
+      case 6: hipLaunchKernelGGL(blur2d_rb_kernel<6>, grid, dim3(256), blur_geom<6>::lds, on, src, h, w, t, dst); break;
+      case 8: hipLaunchKernelGGL(blur2d_rb_kernel<8>, grid, dim3(256), blur_geom<8>::lds, on, src, h, w, t, dst); break;
+      case 10: hipLaunchKernelGGL(blur2d_rb_kernel<10>, grid, dim3(256), blur_geom<10>::lds, on, src, h, w, t, dst); break;
+      case 13: hipLaunchKernelGGL(blur2d_rb_kernel<13>, grid, dim3(256), blur_geom<13>::lds, on, src, h, w, t, dst); break;
+      default:
+        hipLaunchKernelGGL(blur2d_kernel, dim3(vo_cdiv(w, BT_W), vo_cdiv(h, BT_H)), dim3(256),
+                           (size_t)(BT_H + 2 * t.r) * (2 * BT_W + 2 * t.r) * 4, on, src, h, w, t, dst);
+        break;
     }
   };
   // Octave o + 1 starts from layer NOL of octave o: the chain  base -> g1..g3 -> decimate -> g1..g3 -> ...  is the
@@ -1131,8 +1321,8 @@ static int sift_enqueue(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap
       hipStream_t sb = o == 0 ? ctx->aux_stream : ctx->aux_stream2;
       VO_HIP_TRY(ctx, hipStreamWaitEvent(sb, ctx->aux_events[o], 0));
       for (int i = NOL + 1; i < NG; ++i) blur(sb, oct[o].g[i - 1], h, w, taps[i], const_cast<float*>(oct[o].g[i]));
-      hipLaunchKernelGGL(extrema_kernel, grid2(w, h), dim3(256), 0, sb, oct[o], threshold, (int4*)ctx->scratch[0].p,
-                         d_cnt + C_CAND, cap_cand);
+      hipLaunchKernelGGL(extrema_kernel, dim3(vo_cdiv(w, EX_W), vo_cdiv(h, EX_H)), dim3(256), 0, sb, oct[o], threshold, (int4*)ctx->scratch[0].p,
+                         d_cnt + C_SUB, subcap);
     }
     VO_HIP_TRY(ctx, hipEventRecord(ctx->aux_events[MAX_OCT], ctx->aux_stream));
     VO_HIP_TRY(ctx, hipEventRecord(ctx->aux_events[MAX_OCT + 1], ctx->aux_stream2));
@@ -1150,12 +1340,12 @@ static int sift_enqueue(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap
   {
     vo_prof_scope ps(ctx, VO_K_SIFT_DETECT);
     // counts stay on the device: fixed grids, every kernel strides over what the one before it produced
-    hipLaunchKernelGGL(refine_kernel, dim3(1024), dim3(256), 0, st, OS, (const int4*)ctx->scratch[0].p, d_cnt + C_CAND,
-                       cap_cand, contrast_thr, edge_thr, sigma, (unsigned long long*)ctx->scratch[5].p, table_len - 1,
+    hipLaunchKernelGGL(refine_kernel, dim3(1024), dim3(256), 0, st, OS, (const int4*)ctx->scratch[0].p, d_cnt + C_SUB,
+                       subcap, contrast_thr, edge_thr, sigma, (unsigned long long*)ctx->scratch[5].p, table_len - 1,
                        d_surv, d_cnt + C_SURV, cap_kp);
-    hipLaunchKernelGGL(orient_kernel, dim3(8192), dim3(64), 0, st, OS, d_surv, d_cnt + C_SURV, cap_kp, d_kps, d_cnt + C_KP,
+    hipLaunchKernelGGL(orient_kernel, dim3(1024), dim3(64 * ORI_WAVES), 0, st, OS, d_surv, d_cnt + C_SURV, cap_kp, d_kps, d_cnt + C_KP,
                        cap_kp);
-    hipLaunchKernelGGL(overflow_kernel, dim3(1), dim3(1), 0, st, d_cnt, cap_cand, cap_kp, d_cnt + C_OVER);
+    hipLaunchKernelGGL(overflow_kernel, dim3(1), dim3(1), 0, st, d_cnt, subcap, cap_kp, d_cnt + C_OVER);
     hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, st, d_kps, d_cnt + C_KP, cap_kp, (unsigned)cap, d_sel,
                        d_cnt + C_SEL);
   }
@@ -1178,9 +1368,13 @@ static int sift_finalize(vo_ctx* ctx, int cap, float* d_kp, float* d_desc, uint8
     opted[ctx->device] = true;
   }
   unsigned* d_cnt = (unsigned*)ctx->scratch[2].p;
+  unsigned* d_src = d_cnt + C_WORDS;                  // sorted position -> row (FIN_MAX words behind the counters)
   hipLaunchKernelGGL(sift_finalize_kernel, dim3(1), dim3(FIN_T), lds, ctx->stream, (const float*)ctx->scratch[3].p,
-                     d_cnt + C_SEL, cap, d_kp, d_desc, d_desc_u8, d_n, d_cnt + C_OVER);
-  return vo_check_launch(ctx, "sift_finalize_kernel");
+                     d_cnt + C_SEL, cap, d_src, d_n, d_cnt + C_OVER);
+  VO_TRY(vo_check_launch(ctx, "sift_finalize_kernel"));
+  hipLaunchKernelGGL(sift_gather_kernel, dim3(cap > 0 ? cap : FIN_MAX), dim3(128), 0, ctx->stream, (const float*)ctx->scratch[3].p,
+                     (const unsigned*)d_src, (const int*)d_n, d_kp, d_desc, d_desc_u8);
+  return vo_check_launch(ctx, "sift_gather_kernel");
 }
 
 int vo_sift_dev(vo_ctx* ctx, const uint8_t* d_img, int H, int W, int cap, float* d_kp, float* d_desc, uint8_t* d_desc_u8,

@@ -105,6 +105,15 @@ static inline int vo_check_launch(vo_ctx* ctx, const char* what) {
 
 static inline int vo_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Tile order of the image kernels.  Workgroups are dealt to the eight XCDs round-robin by their linear id (ids equal
+// mod 8 share an L2 -- observed, not promised: speed only), so with tile = id neighbouring tiles never share an L2
+// and every halo byte is fetched once per tile that needs it.  This map gives the workgroups of one XCD a contiguous
+// range of the n tiles instead (row-major: whole bands of the image); it is a bijection for any n.
+__device__ __forceinline__ unsigned vo_xcd_tile(unsigned id, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7u, x = id & 7u, j = id >> 3;
+  return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + j;
+}
+
 struct vo_cam2 {      // the two intrinsic matrices of the two-view bootstrap (bootstrap.hip), row-major
   double K1[9], K2[9];
 };
