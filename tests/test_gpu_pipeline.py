@@ -289,6 +289,50 @@ def test_pipeline_at_configuration_size(ctx):
     pipe.close()
 
 
+def test_eight_sequences_at_configuration_size(ctx, tmp_path, monkeypatch):
+    """BASELINE.json configs[3]'s share of one GPU: 8 sequences per launch at 1376x1241 / 2000 keypoints / 1000
+    hypotheses (16-hypothesis workgroups, 64x32 pyramid tiles: the code paths only a launch of several sequences at
+    this size takes), every sequence against the oracle loop on its own frames.  Sequences are windows of two
+    scenes, different starting track counts (two below the re-detect limit), look-ahead on."""
+    from vo import _native, synthetic
+    monkeypatch.setenv("VO_SYNTH_CACHE", str(tmp_path))          # (windows of one scene share their frames)
+    H, W, N, hyp, F, S = 1241, 1376, 2000, 1000, 3, 8
+    streams = [synthetic.Stream(F, H, W, seed=2023 + (q & 1), start=q >> 1) for q in range(S)]
+    fracs = (1.0, 0.9, 0.79, 1.0, 0.95, 0.78, 0.85, 1.0)
+    pipe = _native.Pipeline(ctx, H, W, F, streams[0].K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp,
+                            p3p_threshold=1.0, max_iterations=1000, refine_iters=20, sequences=S)
+    order = streams[0].order(3)
+    pairs = list(zip(order[:-1], order[1:]))
+    refs = []
+    for q in range(S):
+        feats, T = start_state(streams[q], N, fracs[q])
+        for i in range(F):
+            pipe.set_frame(i, streams[q].image(i), seq=q)
+        pipe.set_state(0, feats, T, T, seq=q)
+        orc = OracleLoop(streams[q], N, 15, 2, refine_iters=20)
+        orc.set_state(0, feats, T, T)
+        refs.append([orc.step(b) for _, b in pairs])
+    got = []
+    pipe.submit(*pairs[0])
+    for k in range(len(pairs)):
+        if k + 1 < len(pairs):
+            pipe.submit(*pairs[k + 1])
+        got.append(pipe.collect_all())
+    for q in range(S):
+        for k in range(len(pairs)):
+            r, ref = got[k][q], refs[q][k]
+            assert r.fault == 0, (q, k)
+            assert (r.n_tracked, r.n_triangulated, r.draws_consumed, r.ransac_iterations, r.n_inliers, r.n_candidates,
+                    r.n_landmarks) == (ref["n_tracked"], ref["n_tri"], ref["draws"], ref["iters"], ref["n_inliers"],
+                                       ref["n_cand"], ref["n_landmarks"]), (q, k)
+            assert np.allclose(np.array(r.R).reshape(3, 3), ref["R"], atol=1e-9)
+            assert np.allclose(np.array(r.R_refined).reshape(3, 3), ref["R_ref"], atol=1e-7)
+            assert np.allclose(np.array(r.t_refined), ref["t_ref"], atol=1e-7)
+        check_state(pipe.get_state(seq=q), refs[q][-1]["features"], refs[q][-1]["pose"])
+    assert sum(got[k][q].redetected for k in range(len(pairs)) for q in range(S)) >= 2
+    pipe.close()
+
+
 def test_pipeline_stress_configuration_properties(ctx):
     """BASELINE.json configs[4] (3840x2160, 8000 keypoints, 4-level pyramid, 4000 hypotheses): beyond what the
     oracle finishes in seconds, so checked through properties that do not depend on size -- the greedy NMS rule
