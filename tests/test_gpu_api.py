@@ -69,13 +69,16 @@ def test_good_features_match_oracle(ctx, shape, seed):
     refm = native.good_features(img, mask, 50, 0.05, 5, 5)
     gotm = ctx.good_features(img, mask, 50, 0.05, 5, 5)
     assert np.array_equal(gotm, refm) and np.all(gotm[:, 0] < shape[1] // 2)
+    # a distance whose grid cells hold more candidates than the rounds kernel's cell lists: the one-workgroup walk decides
+    assert np.array_equal(ctx.good_features(img, None, 0, 0.01, 40, 7), native.good_features(img, None, 0, 0.01, 40, 7))
 
 
 @pytest.mark.parametrize("n,quality,min_dist,block", [(2000, 0.01, 8, 7), (500, 0.01, 7.5, 7), (0, 0.02, 12, 5),
                                                       (3000, 0.01, 0, 7), (100000, 0.001, 3, 3)])
 def test_good_features_at_configuration_size(ctx, n, quality, min_dist, block):
     """cv2.goodFeaturesToTrack's ordering and greedy minimum-distance rule run on the device (descending radix sort,
-    one workgroup walking the rule): the same corners in the same order as the oracle's sequential walk, at
+    parallel rounds of the rule over all candidates -- or one workgroup walking it): the same corners in the same order
+    as the oracle's sequential walk, at
     1376x1241, for the bootstrap's 2000 corners, a fractional distance, no corner limit, no distance, and a list
     long enough to need many blocks."""
     img = synthetic_image(1241, 1376, 17, block=9)

@@ -113,28 +113,58 @@ __global__ __launch_bounds__(GT) void corner_candidates_kernel(const float* __re
                                                                const unsigned* __restrict__ max_key, double quality,
                                                                unsigned long long* __restrict__ keys,
                                                                unsigned* __restrict__ count, unsigned cap) {
-  const int x = blockIdx.x * GX + (threadIdx.x & (GX - 1));
-  const int y = blockIdx.y * (GT / GX) + threadIdx.x / GX;
-  if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1) return;
+  // A 64 x 16 tile per workgroup, four rows per work item; the tile's maxima are collected in LDS and appended with ONE
+  // reservation (one returning atomic per maximum -- or per wave -- on the one counter: ~27k / ~16k of them at 1376x1241,
+  // and the launch waited for the counter 97 % of its 94 us).
+  __shared__ unsigned long long s_keys[GX * GY / 4 + 64];        // (3x3 maxima: at most one per 2x2 block, ties aside)
+  __shared__ unsigned s_n, s_base;
   const unsigned mk = *max_key;
   if (mk == 0) return;                                           // empty mask
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
   const float thr = (float)((double)key_float(mk) * quality);
-  const float v = eig[(size_t)y * W + x];
-  if (!(v > thr) || v == 0.f) return;
-  if (mask && !mask[(size_t)y * W + x]) return;
-  float m = 0.f;
+  const int x = blockIdx.x * GX + (threadIdx.x & (GX - 1));
 #pragma unroll
-  for (int j = -1; j <= 1; ++j)
-#pragma unroll
-    for (int i = -1; i <= 1; ++i) {
-      float q = eig[(size_t)(y + j) * W + (x + i)];
-      q = q > thr ? q : 0.f;
-      m = q > m ? q : m;
+  for (int k = 0; k < GY / (GT / GX); ++k) {
+    const int y = blockIdx.y * GY + k * (GT / GX) + threadIdx.x / GX;
+    bool take = x >= 1 && y >= 1 && x < W - 1 && y < H - 1;
+    float v = 0.f;
+    if (take) {
+      v = eig[(size_t)y * W + x];
+      take = v > thr && v != 0.f && (!mask || mask[(size_t)y * W + x]);
     }
-  if (v != m) return;
-  const unsigned pos = atomicAdd(count, 1u);
-  // descending order of the key = descending value, ties: higher address first (positive floats order like their bits)
-  if (pos < cap) keys[pos] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * W + x);
+    if (take) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = -1; j <= 1; ++j)
+#pragma unroll
+        for (int i = -1; i <= 1; ++i) {
+          float q = eig[(size_t)(y + j) * W + (x + i)];
+          q = q > thr ? q : 0.f;
+          m = q > m ? q : m;
+        }
+      take = v == m;
+    }
+    if (take) {
+      // descending order of the key = descending value, ties: higher address first (positive floats order like their bits)
+      const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * W + x);
+      const unsigned slot = atomicAdd(&s_n, 1u);
+      if (slot < (unsigned)(GX * GY / 4 + 64)) {
+        s_keys[slot] = key;
+      } else {                                                   // (a plateau: more maxima than one per 2x2 block)
+        const unsigned pos = atomicAdd(count, 1u);
+        if (pos < cap) keys[pos] = key;
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned n = min(s_n, (unsigned)(GX * GY / 4 + 64));
+  if (threadIdx.x == 0 && n) s_base = atomicAdd(count, n);
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < n; i += GT) {
+    const unsigned pos = s_base + i;
+    if (pos < cap) keys[pos] = s_keys[i];
+  }
 }
 
 // The greedy rule over the sorted candidates, one workgroup.  Cell grid in global memory: per cell a count and up to
@@ -265,6 +295,151 @@ __global__ __launch_bounds__(GF_T) void greedy_distance_kernel(const unsigned lo
   if (t == 0) ctl[2] = (unsigned)n_acc;
 }
 
+// The same rule over all candidates at once, by up to GC_WG workgroups of one launch: a candidate is accepted as soon as
+// every earlier (higher-priority) candidate within minDistance is rejected, rejected as soon as one of them is accepted --
+// the sequential walk decides exactly that, and decisions never change, so a candidate may read any mix of its
+// neighbours' old and new states.  Rounds are separated by a barrier over the launch (all workgroups are resident: at most
+// one per CU); the walk above takes 40 blocks of 14 us for the 20-30 thousand candidates of a 1376x1241 frame, this
+// ~15 rounds of a few microseconds.
+//   prep   every candidate enters the cell grid (cell side = minDistance, as in the walk)
+//   lists  its earlier candidates within minDistance in the 3x3 cells around it (up to GC_NB; more: the cells are
+//          walked again in every round)
+//   rounds until no candidate is undecided
+//   ranks  accepted candidates in priority order; the first max_corners are the corners
+// A cell with more than GC_CCAP candidates, or more candidates than GC_WG workgroups hold, raises ctl[3]: the caller
+// runs the one-workgroup walk instead.
+constexpr int GC_T = 512, GC_WG = 256, GC_NB = 24, GC_CCAP = 32;
+enum { GC_BAR = 4, GC_OPEN = 5 /* .. 8 */, GC_WGCNT = 16 /* .. 16 + GC_WG */, GC_WORDS = 16 + GC_WG };
+
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned& target, unsigned n_wg) {
+  __syncthreads();
+  target += n_wg;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(GC_T) void greedy_distance_rounds_kernel(const unsigned long long* __restrict__ keys, unsigned nc,
+                                                                      int W, int cell, int gw, int gh, double md2,
+                                                                      int max_corners, unsigned* __restrict__ cell_cnt,
+                                                                      unsigned* __restrict__ cell_items,
+                                                                      unsigned* __restrict__ state,
+                                                                      unsigned* __restrict__ nb, float* __restrict__ xy,
+                                                                      unsigned* __restrict__ ctl) {
+  __shared__ unsigned s_open, s_red[GC_T / 64], s_base;
+  const int t = threadIdx.x;
+  const unsigned n_wg = gridDim.x, k = blockIdx.x * GC_T + t;
+  unsigned target = 0;
+  const bool valid = k < nc;
+  int x = 0, y = 0;
+  if (valid) {
+    const unsigned id = (unsigned)(keys[k] & 0xffffffffull);
+    y = (int)(id / (unsigned)W);
+    x = (int)(id - (unsigned)y * (unsigned)W);
+    const unsigned c = (unsigned)(y / cell) * gw + (x / cell);
+    const unsigned slot = atomicAdd(&cell_cnt[c], 1u);
+    if (slot < (unsigned)GC_CCAP) cell_items[c * GC_CCAP + slot] = k;
+    else atomicOr(&ctl[3], 2u);
+    state[k] = GF_UNDECIDED;
+  }
+  grid_barrier(ctl + GC_BAR, target, n_wg);
+  if (__hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // (uniform: read behind the barrier)
+  // earlier candidates within minDistance
+  const int cx = x / cell, cy = y / cell;
+  auto walk = [&](auto&& visit) {
+    for (int yy = max(0, cy - 1); yy <= min(gh - 1, cy + 1); ++yy)
+      for (int xx = max(0, cx - 1); xx <= min(gw - 1, cx + 1); ++xx) {
+        const unsigned c = (unsigned)yy * gw + xx;
+        const unsigned m = min(cell_cnt[c], (unsigned)GC_CCAP);
+        for (unsigned j = 0; j < m; ++j) {
+          const unsigned q = cell_items[c * GC_CCAP + j];
+          if (q >= k) continue;
+          const unsigned idq = (unsigned)(keys[q] & 0xffffffffull);
+          const int qy = (int)(idq / (unsigned)W), qx = (int)(idq - (unsigned)qy * (unsigned)W);
+          const double dx = x - qx, dy = y - qy;
+          if (dx * dx + dy * dy < md2) visit(q);
+        }
+      }
+  };
+  int nnb = 0;
+  if (valid) walk([&](unsigned q) {
+    if (nnb < GC_NB) nb[(size_t)k * GC_NB + nnb] = q;
+    ++nnb;
+  });
+  unsigned st = valid ? (unsigned)GF_UNDECIDED : (unsigned)GF_REJECTED;
+  for (unsigned round = 0;; ++round) {
+    if (t == 0) s_open = 0;
+    __syncthreads();
+    if (st == GF_UNDECIDED) {
+      bool any_acc = false, any_und = false;
+      auto look = [&](unsigned q) {
+        const unsigned sq = __hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        any_acc |= sq == GF_ACCEPTED;
+        any_und |= sq == GF_UNDECIDED;
+      };
+      if (nnb <= GC_NB) {
+        for (int j = 0; j < nnb; ++j) look(nb[(size_t)k * GC_NB + j]);
+      } else {
+        walk(look);
+      }
+      if (any_acc) st = GF_REJECTED;
+      else if (!any_und) st = GF_ACCEPTED;
+      if (st != GF_UNDECIDED) __hip_atomic_store(&state[k], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else s_open = 1;
+    }
+    __syncthreads();
+    unsigned* open = ctl + GC_OPEN + (round & 3u);
+    if (t == 0) {
+      if (s_open) __hip_atomic_store(open, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0)       // the word of two rounds on: its readers all passed the previous barrier
+        __hip_atomic_store(ctl + GC_OPEN + ((round + 2u) & 3u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    grid_barrier(ctl + GC_BAR, target, n_wg);
+    if (__hip_atomic_load(open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;   // (uniform over the launch)
+    if (round > nc) {            // (every round decides the first undecided candidate: never reached)
+      if (t == 0) atomicOr(&ctl[3], 4u);
+      return;
+    }
+  }
+  // ranks: accepted candidates before this one = those of the earlier workgroups + those before it here
+  const unsigned acc = st == GF_ACCEPTED ? 1u : 0u;
+  const unsigned long long bal = __ballot(acc != 0u);
+  const int lane = t & 63, wv = t >> 6;
+  if (lane == 0) s_red[wv] = (unsigned)__popcll(bal);
+  __syncthreads();
+  unsigned before = (unsigned)__popcll(bal & ((1ull << lane) - 1ull)), mine = 0;
+  for (int w = 0; w < GC_T / 64; ++w) {
+    if (w < wv) before += s_red[w];
+    mine += s_red[w];
+  }
+  if (t == 0) __hip_atomic_store(ctl + GC_WGCNT + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  grid_barrier(ctl + GC_BAR, target, n_wg);
+  unsigned part = 0;
+  for (unsigned w = t; w < blockIdx.x; w += GC_T) part += __hip_atomic_load(ctl + GC_WGCNT + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+  __syncthreads();
+  if (lane == 0) s_red[wv] = part;
+  __syncthreads();
+  if (t == 0) {
+    unsigned b = 0;
+    for (int w = 0; w < GC_T / 64; ++w) b += s_red[w];
+    s_base = b;
+  }
+  __syncthreads();
+  const unsigned limit = max_corners > 0 ? (unsigned)max_corners : 0xffffffffu;
+  const unsigned rank = s_base + before;
+  if (acc && rank < limit) {
+    xy[2 * rank] = (float)x;
+    xy[2 * rank + 1] = (float)y;
+  }
+  if (blockIdx.x == n_wg - 1 && t == 0) ctl[2] = min(s_base + mine, limit);
+}
+
 // minDistance < 1: the first max_corners of the sorted list
 __global__ __launch_bounds__(256) void take_sorted_kernel(const unsigned long long* __restrict__ keys, unsigned n, int W,
                                                           float* __restrict__ xy) {
@@ -325,7 +500,7 @@ int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_
                                                 (size_t)cap, 0, 64, st));
   VO_TRY(vo_ensure(ctx, ctx->img, px));
   VO_TRY(vo_ensure(ctx, s[0], px * 4));
-  VO_TRY(vo_ensure(ctx, s[1], 16));
+  VO_TRY(vo_ensure(ctx, s[1], (size_t)GC_WORDS * 4));
   VO_TRY(vo_ensure(ctx, s[2], (size_t)cap * 8));
   VO_TRY(vo_ensure(ctx, s[3], (size_t)cap * 8));
   VO_TRY(vo_ensure(ctx, s[4], sort_tmp + 256));
@@ -335,7 +510,7 @@ int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_
   if (mask) VO_TRY(vo_ensure(ctx, ctx->img2, px));
   VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img.p, img, px, hipMemcpyHostToDevice, st));
   if (mask) VO_HIP_TRY(ctx, hipMemcpyAsync(ctx->img2.p, mask, px, hipMemcpyHostToDevice, st));
-  VO_HIP_TRY(ctx, hipMemsetAsync(s[1].p, 0, 16, st));
+  VO_HIP_TRY(ctx, hipMemsetAsync(s[1].p, 0, (size_t)GC_WORDS * 4, st));
   VO_HIP_TRY(ctx, hipMemsetAsync(s[5].p, 0, cells * 4, st));
   const uint8_t* d_mask = mask ? (const uint8_t*)ctx->img2.p : nullptr;
   unsigned* d_ctl = (unsigned*)s[1].p;                            // [0] max key, [1] candidate count, [2] corners, [3] fault
@@ -345,7 +520,7 @@ int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_
   hipLaunchKernelGGL(min_eig_kernel, dim3(vo_cdiv(W, GX), vo_cdiv(H, GY)), dim3(GT), lds, st, (const uint8_t*)ctx->img.p,
                      H, W, block, (float)(scale * scale), d_mask, (float*)s[0].p, d_ctl);
   VO_TRY(vo_check_launch(ctx, "min_eig_kernel"));
-  hipLaunchKernelGGL(corner_candidates_kernel, dim3(vo_cdiv(W, GX), vo_cdiv(H, GT / GX)), dim3(GT), 0, st,
+  hipLaunchKernelGGL(corner_candidates_kernel, dim3(vo_cdiv(W, GX), vo_cdiv(H, GY)), dim3(GT), 0, st,
                      (const float*)s[0].p, H, W, d_mask, d_ctl, quality, (unsigned long long*)s[2].p, d_ctl + 1, cap);
   VO_TRY(vo_check_launch(ctx, "corner_candidates_kernel"));
   unsigned ctl[4] = {0, 0, 0, 0};
@@ -360,12 +535,33 @@ int vo_good_features(vo_ctx* ctx, const uint8_t* img, int H, int W, const uint8_
   float* d_xy = (float*)s[7].p;
   int n = 0;
   if (min_dist >= 1) {
-    hipLaunchKernelGGL(greedy_distance_kernel, dim3(1), dim3(GF_T), 0, st, d_sorted, nc, W, cell, gw, gh,
-                       min_dist * min_dist, max_corners, (unsigned*)s[5].p, (unsigned*)s[6].p, d_xy, d_ctl);
-    VO_TRY(vo_check_launch(ctx, "greedy_distance_kernel"));
-    VO_HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, 16, hipMemcpyDeviceToHost, st));
-    VO_HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (ctl[3]) return vo_set_error(ctx, VO_ECAPACITY, "good_features: more than %d corners in one grid cell", GRID_SLOTS);
+    static const bool walk_only = getenv("VO_GREEDY_WALK") != nullptr;      // (measurements: the one-workgroup walk)
+    const unsigned n_wg = (nc + GC_T - 1) / GC_T;
+    bool done = false;
+    if (!walk_only && n_wg <= (unsigned)GC_WG) {
+      VO_TRY(vo_ensure(ctx, s[8], cells * GC_CCAP * 4));
+      VO_TRY(vo_ensure(ctx, s[9], (size_t)nc * 4));
+      VO_TRY(vo_ensure(ctx, s[10], (size_t)nc * GC_NB * 4));
+      hipLaunchKernelGGL(greedy_distance_rounds_kernel, dim3(n_wg), dim3(GC_T), 0, st, d_sorted, nc, W, cell, gw, gh,
+                         min_dist * min_dist, max_corners, (unsigned*)s[5].p, (unsigned*)s[8].p, (unsigned*)s[9].p,
+                         (unsigned*)s[10].p, d_xy, d_ctl);
+      VO_TRY(vo_check_launch(ctx, "greedy_distance_rounds_kernel"));
+      VO_HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, 16, hipMemcpyDeviceToHost, st));
+      VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+      done = ctl[3] == 0;
+      if (!done) {                     // a crowded cell: the walk decides (its grid holds accepted corners only)
+        VO_HIP_TRY(ctx, hipMemsetAsync(s[5].p, 0, cells * 4, st));
+        VO_HIP_TRY(ctx, hipMemsetAsync(d_ctl + 2, 0, 8, st));
+      }
+    }
+    if (!done) {
+      hipLaunchKernelGGL(greedy_distance_kernel, dim3(1), dim3(GF_T), 0, st, d_sorted, nc, W, cell, gw, gh,
+                         min_dist * min_dist, max_corners, (unsigned*)s[5].p, (unsigned*)s[6].p, d_xy, d_ctl);
+      VO_TRY(vo_check_launch(ctx, "greedy_distance_kernel"));
+      VO_HIP_TRY(ctx, hipMemcpyAsync(ctl, d_ctl, 16, hipMemcpyDeviceToHost, st));
+      VO_HIP_TRY(ctx, hipStreamSynchronize(st));
+      if (ctl[3]) return vo_set_error(ctx, VO_ECAPACITY, "good_features: more than %d corners in one grid cell", GRID_SLOTS);
+    }
     n = (int)ctl[2];
   } else {
     n = (int)(max_corners > 0 ? std::min<unsigned>(nc, (unsigned)max_corners) : nc);
