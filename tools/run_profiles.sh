@@ -29,6 +29,8 @@ timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s
 VO_ONE_STREAM=1 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_one -- $cmd > $out/stats_one.log 2>&1; echo stats_one >> gpurun_out/prof_progress.log
 VO_ONE_STREAM=1 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16_one -- $cmd --sequences 16 --steps 100 > $out/stats_s16_one.log 2>&1; echo stats_s16_one >> gpurun_out/prof_progress.log
 VO_ONE_STREAM=1 VO_BENCH_DETECT_MARGIN=-1 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_s16_one_all -- $cmd --sequences 16 --steps 100 > $out/stats_s16_one_all.log 2>&1; echo stats_s16_one_all >> gpurun_out/prof_progress.log
+VO_BENCH_CONFIG=cfg3 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_cfg3 -- $cmd --steps 60 --warmup 10 > $out/stats_cfg3.log 2>&1; echo stats_cfg3 >> gpurun_out/prof_progress.log
+cp "$(ls $out/stats_cfg3/*/*kernel_stats.csv | head -1)" $out/${tag}_cfg3_kernel_stats.csv
 cp "$(ls $out/stats_one/*/*kernel_stats.csv | head -1)" $out/${tag}_one_stream_kernel_stats.csv
 cp "$(ls $out/stats_s16_one/*/*kernel_stats.csv | head -1)" $out/${tag}_s16_one_stream_kernel_stats.csv
 cp "$(ls $out/stats_s16_one_all/*/*kernel_stats.csv | head -1)" $out/${tag}_s16_one_stream_detect_every_frame_kernel_stats.csv

@@ -868,7 +868,10 @@ __global__ __launch_bounds__(RT) void nms_round_kernel(const double* __restrict_
   __shared__ unsigned short s_sel[SEG];          // candidates selected in this launch
   __shared__ unsigned short s_pass2[SEG];        // ... after the dense filter
   __shared__ unsigned s_npass, s_npass2, s_nsel, s_prog;
-  const unsigned blk = vo_xcd_tile(blockIdx.x, gridDim.x);
+  // (tile = dispatch order here, not vo_xcd_tile's bands: a tile polls its neighbours' decisions, and with the bands the
+  //  first rows of a band run long before the last rows of the band above them -- at 3840x2160, where the tiles are not
+  //  all resident, those rows gave up undecided and the sorted walk of the leftovers took 3.5 ms)
+  const unsigned blk = blockIdx.x;
   const unsigned n = seg_cnt[blk].z;
   const int tid = threadIdx.x;
   if (n == 0 || seg_cnt[blk].w == 0) return;
