@@ -441,6 +441,79 @@ def make_pipeline(ctx, streams, states, S, detect_margin, hyp=None):
     return pipe
 
 
+def upload_leg(ctx, stream, state):
+    """The headline's loop with the frames coming from HOST memory, one 1.7 MB upload per frame (PCIe-inclusive: never
+    `value`): a pipeline with four frame slots walks the stream once, frame PASS_START -> N_FRAMES - 1, in three ways --
+    (a) frames in pinned memory (vo_host_alloc: where a frame grabber or a decoder would put them), uploaded one step
+    ahead of their use by vo_pipeline_set_frame_pinned (DMA on its own stream, beside the kernels); (b) the same, each
+    frame uploaded only when its own step is submitted; (c) frames in ordinary NumPy arrays through vo_pipeline_set_frame
+    (staging copy on the host, DMA in front of the frame's pyramid on the tracker's stream)."""
+    from vo import _native
+    n = stream.n
+    pinned = [ctx.pinned_empty((H, W)) for _ in range(n)]
+    plain = [np.ascontiguousarray(stream.image(i)) for i in range(n)]
+    for i in range(n):
+        pinned[i][...] = plain[i]
+    out = {}
+    for name, src, ahead in (("pinned_uploaded_one_step_ahead", pinned, 1), ("pinned_uploaded_with_its_step", pinned, 0),
+                             ("pageable_numpy_array", plain, 0)):
+        pipe = _native.Pipeline(ctx, H, W, 4, stream.K, n_keypoints=N_KP, klt_win=WIN, klt_max_level=MAX_LEVEL, hyp=HYP_LAUNCH,
+                                p3p_threshold=1.0, outlier_ratio=0.9, confidence=0.99, max_iterations=HYP,
+                                refine_iters=REFINE_ITERS, redetect_start_pose=REDETECT_POSE, detect_margin=DETECT_MARGIN)
+        rate = None
+        for timed in (False, True):                           # a warm pass, then the timed one from the same state
+            pipe.set_frame(PASS_START % 4, src[PASS_START], pinned=src is pinned)
+            pipe.set_state(PASS_START % 4, state.curr_frame.features, state.curr_pose, state.prev_pose, num_features=N_KP)
+            if ahead:
+                pipe.set_frame((PASS_START + 1) % 4, src[PASS_START + 1], pinned=src is pinned)
+            ctx.sync()
+            recs, pending = [], 0
+            is_pinned = src is pinned
+            t_set = t_sub = t_col = 0.0
+            t0 = time.perf_counter()
+            for k in range(PASS_START, n - 1):                # step k: frame k -> k + 1
+                ta = time.perf_counter()
+                if pending == 2:
+                    recs.append(pipe.collect())
+                    pending -= 1
+                tb = time.perf_counter()
+                if ahead:
+                    if k + 2 < n:
+                        pipe.set_frame((k + 2) % 4, src[k + 2], pinned=is_pinned)
+                else:
+                    pipe.set_frame((k + 1) % 4, src[k + 1], pinned=is_pinned)
+                tc = time.perf_counter()
+                pipe.submit(k % 4, (k + 1) % 4)
+                pending += 1
+                td = time.perf_counter()
+                t_col += tb - ta
+                t_set += tc - tb
+                t_sub += td - tc
+            while pending:
+                recs.append(pipe.collect())
+                pending -= 1
+            dt = time.perf_counter() - t0
+            if timed:
+                rate = (n - 1 - PASS_START) / dt
+                out[name + "_host_path_steps"] = int(sum(r.recovered for r in recs))
+                ts = np.array([[r.ts[j] for j in range(6)] for r in recs], dtype=np.float64) * 1e-2
+                out[name + "_chain_us"] = {"step_period": round(float(np.median(np.diff(ts[:, 1]))), 1),
+                                           "tracker_start_to_regroup_start": round(float(np.median(ts[:, 1] - ts[:, 0])), 1),
+                                           "regroup_to_next_tracker_start": round(float(np.median(ts[1:, 0] - ts[:-1, 1])), 1),
+                                           "regroup_to_record": round(float(np.median(ts[:, 5] - ts[:, 1])), 1),
+                                           "record_to_next_regroup": round(float(np.median(ts[1:, 1] - ts[:-1, 5])), 1),
+                                           "detector_executed": round(float(np.mean([r.detector_executed for r in recs])), 2)
+                                           if hasattr(recs[0], "detector_executed") else None}
+                out[name + "_host_us_per_step"] = {"collect": round(1e6 * t_col / (n - 1 - PASS_START), 1),
+                                                   "set_frame": round(1e6 * t_set / (n - 1 - PASS_START), 1),
+                                                   "submit": round(1e6 * t_sub / (n - 1 - PASS_START), 1)}
+        out[name + "_frames_per_s"] = round(float(rate), 1)
+        pipe.close()
+    out["note"] = ("cfg-2 loop, %d steps of the forward stream, frames uploaded from host memory every step (4 frame slots in HBM); "
+                   "PCIe-inclusive, never `value`" % (n - 1 - PASS_START))
+    return out
+
+
 def loop_stats(records):
     """What the loop did over `records` (StepResults of all sequences of the timed steps)."""
     return {"features_in_median": int(np.median([r.n_features_in for r in records])),
@@ -794,8 +867,6 @@ def main():
             parity, base = oracle_leg(stream, state, [rs[0] for _, rs in first_pass[:CPU_BASELINE_FRAMES]], first_state, ORACLE_FRAMES)
             out["pose_vs_oracle"] = parity
             out["cpu_baseline"] = base
-        if world == 1 and not args.no_api:
-            out["api"] = api_leg(ctx)
         if legs:
             pipe.close()
             pipe = None
@@ -820,6 +891,18 @@ def main():
                     p4 = make_pipeline(ctx, leg_streams, leg_states, S_LEG, -1.0)
                     out["sequences_16_detector_every_frame"] = timed_leg(ctx, p4, S_LEG, 30, 2 * (N_FRAMES - 1 - PASS_START))
                     p4.close()
+        if world == 1 and not args.no_api:
+            # the API legs with every other pipeline closed (a second pipeline's streams share the device's hardware queues
+            # with the first one's: beside the open headline pipeline these legs ran at half their rate)
+            if pipe is not None:
+                pipe.close()
+                pipe = None
+            out["api"] = api_leg(ctx)
+            try:
+                if S == 1:
+                    out["api"]["frames_from_host_memory"] = upload_leg(ctx, stream, state)
+            except Exception as e:                           # the headline must not depend on this leg
+                out["api"]["frames_from_host_memory"] = {"error": repr(e)}
         _Stdout.emit(out)
     if pipe is not None:
         pipe.close()

@@ -507,6 +507,16 @@ int64_t vo_pipeline_ransac_bound(vo_pipeline* p, double outlier_ratio);
  * generator state (each then advances by its own draws).                                        */
 int vo_pipeline_sequences(vo_pipeline* p);
 int vo_pipeline_set_frame_seq(vo_pipeline* p, int seq, int idx, const uint8_t* img);
+/* The same from PINNED host memory (vo_host_alloc; a frame grabber's or a decoder's output buffer): no staging copy on the
+ * host, and the DMA runs on a stream of its own beside the pipeline's kernels instead of in front of the frame's pyramid --
+ * a frame uploaded while the previous step is still in flight costs the step nothing.  The buffer must not change until
+ * the upload is over: vo_pipeline_frame_uploaded(idx, wait) -- 1 when it is (wait != 0: blocks until then), 0 when not --
+ * or the collect of a step that read the slot.  Replaces the image hand-over of the reference's per-frame loop
+ * (src/main.py:248-251: frame.image goes into Tracker.track as a host array).                                         */
+int vo_pipeline_set_frame_pinned(vo_pipeline* p, int seq, int idx, const uint8_t* pinned_img);
+int vo_pipeline_frame_uploaded(vo_pipeline* p, int idx, int wait);
+int vo_host_alloc(vo_ctx* ctx, size_t bytes, void** out);
+int vo_host_free(vo_ctx* ctx, void* p);          /* ctx may be NULL */
 int vo_pipeline_set_state_seq(vo_pipeline* p, int seq, int idx, int n, const double* kp, const uint8_t* state,
                               const double* landmarks, const double* tracks, const double* poses,
                               const double* T_wc, const double* T_cw, const double* T_wc_prev,

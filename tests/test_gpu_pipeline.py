@@ -333,6 +333,54 @@ def test_eight_sequences_at_configuration_size(ctx, tmp_path, monkeypatch):
     pipe.close()
 
 
+def test_frames_from_pinned_memory_uploaded_a_step_ahead(ctx):
+    """vo_pipeline_set_frame_pinned: frames handed over in pinned memory (vo_host_alloc) and uploaded one step ahead of
+    their use, on the upload stream, give the records and the state of the same steps fed through vo_pipeline_set_frame."""
+    from vo import _native, synthetic
+    H, W, N, hyp, F = 240, 320, 300, 256, 6
+    stream = synthetic.Stream(F, H, W)
+    feats, T = start_state(stream, N, 0.85)
+    ref = make_pipe(ctx, stream, N, hyp)
+    ref.set_state(0, feats, T, T)
+    pairs = [(i, i + 1) for i in range(F - 1)]
+    want = run_all(ref, pairs, lookahead=True)
+    st_ref = ref.get_state()
+    ref.close()
+
+    pinned = [ctx.pinned_empty((H, W)) for _ in range(F)]
+    for i in range(F):
+        pinned[i][...] = stream.image(i)
+    assert ctx.is_pinned(pinned[0]) and not ctx.is_pinned(np.zeros((H, W), np.uint8))
+    pipe = _native.Pipeline(ctx, H, W, 4, stream.K, n_keypoints=N, klt_win=15, klt_max_level=2, hyp=hyp, p3p_threshold=1.0,
+                            max_iterations=1000, refine_iters=20)
+    pipe.set_frame(0, pinned[0])                    # (pinned: decided by where the array lies)
+    pipe.set_state(0, feats, T, T)
+    pipe.set_frame(1, pinned[1])
+    got, pending = [], 0
+    for k in range(F - 1):                          # step k: frame k -> k + 1, slots k % 4 -> (k + 1) % 4
+        if pending == 2:
+            got.append(pipe.collect())
+            pending -= 1
+        if k + 2 < F:
+            pipe.set_frame((k + 2) % 4, pinned[k + 2], pinned=True)       # the frame of the NEXT step, while this one runs
+        pipe.submit(k % 4, (k + 1) % 4)
+        pending += 1
+    while pending:
+        got.append(pipe.collect())
+        pending -= 1
+    assert pipe.frame_uploaded((F - 1) % 4, wait=True)
+    for a, b in zip(got, want):
+        assert fields(a) == fields(b)
+    st = pipe.get_state()
+    for key in ("keypoints", "state", "candidate_mask", "landmarks", "tracks", "poses", "curr_pose"):
+        assert np.array_equal(st[key], st_ref[key], equal_nan=True), key
+    pipe.submit(1, 0)                               # (slot 1 holds frame 5, slot 0 frame 4)
+    with pytest.raises(_native.VoError):            # a slot of a step in flight is refused, as for set_frame
+        pipe.set_frame(0, pinned[2], pinned=True)
+    pipe.collect()
+    pipe.close()
+
+
 def test_pipeline_stress_configuration_properties(ctx):
     """BASELINE.json configs[4] (3840x2160, 8000 keypoints, 4-level pyramid, 4000 hypotheses): beyond what the
     oracle finishes in seconds, so checked through properties that do not depend on size -- the greedy NMS rule

@@ -61,6 +61,10 @@ struct vo_pipeline {
   // frame upload: pinned staging per (sequence, frame slot), allocated on first use; evImg[idx]: slot idx is in HBM
   std::vector<uint8_t*> h_img;
   std::vector<hipEvent_t> evImg;
+  // vo_pipeline_set_frame_pinned: DMA straight from the caller's pinned buffer on a stream of its own (beside the kernels,
+  // not in front of the pyramid); side[idx]: slot idx was last filled that way -- the tracker's stream waits for evImg too
+  hipStream_t up_stream = nullptr;
+  std::vector<char> side;
   int slot = 0, det_flip = 0, prev_frame = -1;
   // Features double buffer: a step reads F[cur] (frame k-1) and writes F[1 - cur] (frame k)
   vo_feat F[2];
@@ -382,6 +386,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (q) (void)hipHostFree(q);
   for (uint8_t* q : p->h_img)
     if (q) (void)hipHostFree(q);
+  if (p->up_stream) (void)hipStreamDestroy(p->up_stream);
   for (hipEvent_t e : p->evImg)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : {p->evPyr[0], p->evPyr[1], p->evPyr[2], p->evDet[0], p->evDet[1], p->evDet[2], p->evRaw, p->evA, p->evB,
@@ -596,6 +601,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   }
   p->h_img.assign(Sz * cfg->n_frames, nullptr);
   p->evImg.assign((size_t)cfg->n_frames, nullptr);
+  p->side.assign((size_t)cfg->n_frames, 0);
   for (hipEvent_t& e : p->evImg)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   if (rc != VO_OK) {
@@ -662,6 +668,58 @@ int vo_pipeline_set_frame_seq(vo_pipeline* p, int seq, int idx, const uint8_t* i
   memcpy(stage, img, p->px);
   VO_HIP_TRY(ctx, hipMemcpyAsync(p->img(seq, idx), stage, p->px, hipMemcpyHostToDevice, p->trk->stream));
   VO_HIP_TRY(ctx, hipEventRecord(p->evImg[idx], p->trk->stream));
+  p->side[(size_t)idx] = 0;
+  return VO_OK;
+}
+
+// The same from a buffer the caller holds in pinned memory (vo_host_alloc): no staging copy, and the DMA runs on a
+// stream of its own.  The buffer must stay as it is until the upload is over: vo_pipeline_frame_uploaded(idx), or the
+// collect of a step that read the slot.
+int vo_pipeline_set_frame_pinned(vo_pipeline* p, int seq, int idx, const uint8_t* pinned_img) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, seq >= 0 && seq < p->S && idx >= 0 && idx < p->cfg.n_frames && pinned_img, "pipeline_set_frame_pinned: bad arguments");
+  for (int k = 0; k < p->n_flight; ++k)
+    VO_REQUIRE(ctx, p->flight[k].prev_idx != idx && p->flight[k].next_idx != idx,
+               "pipeline_set_frame_pinned: slot %d belongs to a step in flight", idx);
+  VO_REQUIRE(ctx, !(p->have_state && p->primed && idx == p->prev_frame),
+             "pipeline_set_frame_pinned: slot %d holds the frame the next step starts from", idx);
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!p->up_stream) VO_HIP_TRY(ctx, hipStreamCreateWithFlags(&p->up_stream, hipStreamNonBlocking));
+  // (a slot the tracker's stream filled last: that copy is in front of everything that read the slot; a step that read it
+  //  has been collected -- the check above --, so nothing on the GPU still reads what this copy overwrites)
+  if (!p->side[(size_t)idx]) VO_HIP_TRY(ctx, hipStreamWaitEvent(p->up_stream, p->evImg[idx], 0));   // (a copy vo_pipeline_set_frame queued)
+  VO_HIP_TRY(ctx, hipMemcpyAsync(p->img(seq, idx), pinned_img, p->px, hipMemcpyHostToDevice, p->up_stream));
+  VO_HIP_TRY(ctx, hipEventRecord(p->evImg[idx], p->up_stream));
+  p->side[(size_t)idx] = 1;
+  return VO_OK;
+}
+
+int vo_pipeline_frame_uploaded(vo_pipeline* p, int idx, int wait) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, idx >= 0 && idx < p->cfg.n_frames, "pipeline_frame_uploaded: bad slot");
+  if (wait) {
+    VO_HIP_TRY(ctx, hipEventSynchronize(p->evImg[idx]));
+    return 1;
+  }
+  return hipEventQuery(p->evImg[idx]) == hipSuccess ? 1 : 0;
+}
+
+int vo_host_alloc(vo_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx) return VO_EINVAL;
+  VO_REQUIRE(ctx, out && bytes > 0, "host_alloc: bad arguments");
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return vo_set_error(ctx, VO_ENOMEM, "hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+  }
+  return VO_OK;
+}
+
+int vo_host_free(vo_ctx* ctx, void* q) {      // (ctx may be null: a buffer can outlive the context it was made with)
+  if (q && hipHostFree(q) != hipSuccess) return ctx ? vo_set_error(ctx, VO_EHIP, "hipHostFree failed") : VO_EHIP;
   return VO_OK;
 }
 
@@ -730,6 +788,8 @@ static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force, char*
 }
 
 static int enqueue_pyramid(vo_pipeline* p, int frame, int s) {
+  if (p->side[(size_t)frame] && hipStreamWaitEvent(p->trk->stream, p->evImg[frame], 0) != hipSuccess)   // (vo_pipeline_set_frame_pinned)
+    return vo_set_error(p->ctx, VO_EHIP, "pyramid: hipStreamWaitEvent failed");
   const vo_pipeline_config& c = p->cfg;
   const int rc = vo_pyramid_build_batch_dev(p->trk, p->img(0, frame), p->img_stride(), p->S, c.H, c.W, p->n_levels,
                                             p->pyr(0, s), p->pyr_stride());
@@ -926,7 +986,7 @@ static int enqueue_sift(vo_pipeline* p, const vo_pipeline::flight_t& f, char* er
   vo_ctx* sc = ((f.k & 1) && !one_ctx) ? p->det : p->trk;
   const vo_pipeline_config& c = p->cfg;
   int rc = VO_OK;
-  if (sc != p->trk && hipStreamWaitEvent(sc->stream, p->evImg[f.next_idx], 0) != hipSuccess) rc = VO_EHIP;   // (the upload)
+  if ((sc != p->trk || p->side[(size_t)f.next_idx]) && hipStreamWaitEvent(sc->stream, p->evImg[f.next_idx], 0) != hipSuccess) rc = VO_EHIP;   // (the upload)
   if (rc == VO_OK)
     rc = vo_sift_dev(sc, p->img(0, f.next_idx), c.H, c.W, p->sift_cap, p->d_skp + (size_t)f.b * p->sift_cap * 6, nullptr,
                      p->d_sdesc + (size_t)f.b * p->sift_cap * 128, p->d_sn + f.b);

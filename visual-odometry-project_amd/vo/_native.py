@@ -174,6 +174,10 @@ _SIGS = {
     "vo_pipeline_ransac_bound": (C.c_int64, [_vp, _d]),
     "vo_pipeline_sequences": (_i, [_vp]),
     "vo_pipeline_set_frame_seq": (_i, [_vp, _i, _i, _vp]),
+    "vo_pipeline_set_frame_pinned": (_i, [_vp, _i, _i, _vp]),
+    "vo_pipeline_frame_uploaded": (_i, [_vp, _i, _i]),
+    "vo_host_alloc": (_i, [_vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vo_host_free": (_i, [_vp, _vp]),
     "vo_pipeline_set_state_seq": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "vo_pipeline_get_state_seq": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vo_pipeline_get_rng_seq": (_i, [_vp, _i, _vp]),
@@ -225,6 +229,7 @@ class Context:
         self._h = h
         self.device = device
         self._pipelines = weakref.WeakSet()      # pipelines built on this context: closed before it is
+        self._pinned_ranges = []                 # live pinned_empty allocations: (first byte, one past the last, owner)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -354,6 +359,29 @@ class Context:
         self._chk(self._lib.vo_match_knn2_ratio(self._h, _ptr(q), q.shape[0], _ptr(t), t.shape[0],
                                                 max(q.shape[1], 1), float(ratio), _ptr(pairs), C.byref(n)))
         return pairs[: n.value].astype(np.int64)
+
+    def pinned_empty(self, shape, dtype=np.uint8):
+        """A NumPy array in pinned host memory (vo_host_alloc): what Pipeline.set_frame(..., pinned=True) uploads from
+        without a staging copy.  The memory lives as long as the array (and every view of it) does."""
+        shape = tuple(int(v) for v in np.atleast_1d(shape))
+        dt = np.dtype(dtype)
+        nbytes = max(int(np.prod(shape)) * dt.itemsize, 1)
+        q = C.c_void_p()
+        self._chk(self._lib.vo_host_alloc(self._h, nbytes, C.byref(q)))
+        buf = (C.c_uint8 * nbytes).from_address(q.value)
+        arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        lib, addr = self._lib, q.value
+        weakref.finalize(buf, lambda: lib.vo_host_free(None, C.c_void_p(addr)))     # (the context may be gone by then)
+        arr.flags.writeable = True
+        self._pinned_ranges.append((addr, addr + nbytes, weakref.ref(buf)))
+        return arr
+
+    def is_pinned(self, arr):
+        """True when arr's bytes lie inside a live pinned_empty allocation of this context."""
+        a = arr.__array_interface__["data"][0]
+        b = a + arr.nbytes
+        self._pinned_ranges = [r for r in self._pinned_ranges if r[2]() is not None]
+        return any(lo <= a and b <= hi for lo, hi, _ in self._pinned_ranges)
 
     def good_features(self, img, mask=None, max_corners=500, quality=0.01, min_distance=8, block_size=7):
         img = _c(img, np.uint8)

@@ -66,6 +66,7 @@ class Pipeline:
         h = C.c_void_p()
         ctx._chk(ctx._lib.vo_pipeline_create(ctx._h, C.byref(c), C.byref(h)))
         self._h = h
+        self._pinned_src = {}
         ctx._pipelines.add(self)
         self.cap = ctx._lib.vo_pipeline_feature_cap(self._h)
         self.seed(np.random.default_rng(seed))
@@ -82,10 +83,25 @@ class Pipeline:
             pass
 
     # ---- inputs ----
-    def set_frame(self, idx, img, seq=0):
+    def set_frame(self, idx, img, seq=0, pinned=None):
+        """Frame slot idx <- img.  pinned: img lies in Context.pinned_empty memory and is uploaded from there (no staging
+        copy, DMA beside the kernels; img must stay unchanged until frame_uploaded(idx) or the collect of a step that
+        read the slot); None: decided by where img lies."""
         img = _c(img, np.uint8)
         assert img.shape == (self.cfg.H, self.cfg.W)
-        self.ctx._chk(self.ctx._lib.vo_pipeline_set_frame_seq(self._h, int(seq), int(idx), _ptr(img)))
+        if pinned is None:
+            pinned = self.ctx.is_pinned(img)
+        if pinned:
+            self._pinned_src[(int(seq), int(idx))] = img          # (kept alive while the DMA may read it)
+            self.ctx._chk(self.ctx._lib.vo_pipeline_set_frame_pinned(self._h, int(seq), int(idx), _ptr(img)))
+        else:
+            self.ctx._chk(self.ctx._lib.vo_pipeline_set_frame_seq(self._h, int(seq), int(idx), _ptr(img)))
+
+    def frame_uploaded(self, idx, wait=False):
+        rc = self.ctx._lib.vo_pipeline_frame_uploaded(self._h, int(idx), 1 if wait else 0)
+        if rc < 0:
+            self.ctx._chk(rc)
+        return bool(rc)
 
     def seed(self, generator):
         """The estimator's generator (RANSAC.rng, src/vo/algorithms/ransac.py:52)."""
