@@ -867,9 +867,22 @@ def main():
             parity, base = oracle_leg(stream, state, [rs[0] for _, rs in first_pass[:CPU_BASELINE_FRAMES]], first_state, ORACLE_FRAMES)
             out["pose_vs_oracle"] = parity
             out["cpu_baseline"] = base
+        if world == 1 and not args.no_api:
+            # the API legs with every other pipeline closed (a second pipeline's streams share the device's hardware queues
+            # with the first one's: beside the open headline pipeline these legs ran at half their rate)
+            if pipe is not None:
+                pipe.close()
+                pipe = None
+            out["api"] = api_leg(ctx)
+            try:
+                if S == 1:
+                    out["api"]["frames_from_host_memory"] = upload_leg(ctx, stream, state)
+            except Exception as e:                           # the headline must not depend on this leg
+                out["api"]["frames_from_host_memory"] = {"error": repr(e)}
         if legs:
-            pipe.close()
-            pipe = None
+            if pipe is not None:
+                pipe.close()
+                pipe = None
             if DETECT_MARGIN >= 0:
                 # the same loop with the detector executed on EVERY frame (what rounds 1 and early 2 timed), in the same line
                 p2 = make_pipeline(ctx, streams, states, S, -1.0)
@@ -891,18 +904,6 @@ def main():
                     p4 = make_pipeline(ctx, leg_streams, leg_states, S_LEG, -1.0)
                     out["sequences_16_detector_every_frame"] = timed_leg(ctx, p4, S_LEG, 30, 2 * (N_FRAMES - 1 - PASS_START))
                     p4.close()
-        if world == 1 and not args.no_api:
-            # the API legs with every other pipeline closed (a second pipeline's streams share the device's hardware queues
-            # with the first one's: beside the open headline pipeline these legs ran at half their rate)
-            if pipe is not None:
-                pipe.close()
-                pipe = None
-            out["api"] = api_leg(ctx)
-            try:
-                if S == 1:
-                    out["api"]["frames_from_host_memory"] = upload_leg(ctx, stream, state)
-            except Exception as e:                           # the headline must not depend on this leg
-                out["api"]["frames_from_host_memory"] = {"error": repr(e)}
         _Stdout.emit(out)
     if pipe is not None:
         pipe.close()

@@ -142,7 +142,8 @@ def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int =
     img = _gray(frame.image)
     H, W = img.shape
     K = np.asarray(sequence.get_camera().intrinsic_matrix, np.float64)
-    pipe = _native.Pipeline(ctx, H, W, 3, K, n_keypoints=n_keypoints, klt_win=klt_win, klt_max_level=klt_max_level,
+    SLOTS = 4
+    pipe = _native.Pipeline(ctx, H, W, SLOTS, K, n_keypoints=n_keypoints, klt_win=klt_win, klt_max_level=klt_max_level,
                             hyp=hyp, p3p_threshold=1.25 ** 2, outlier_ratio=0.9, confidence=0.9999, max_iterations=10000,
                             refine_iters=20, bearing_threshold=state._bearing_threshold,
                             redetect_start_pose=redetect_start_pose)
@@ -151,23 +152,46 @@ def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int =
     trajectory = [np.eye(4), state.get_pose()]
     n_landmarks = [len(frame.features.triangulated_inliers_landmarks)]
     seconds, results = [], []
-    slot = 0
-    # one frame of look-ahead, as a camera delivers them: frame k+1 is uploaded and submitted before the pose of
-    # frame k is read back
-    pending = 0
-    for k, new_frame in enumerate(sequence):
-        if max_frames is not None and k >= max_frames:
-            break
+    # Frames go through a ring of pinned buffers (the grey conversion writes into them) and are uploaded on the
+    # pipeline's upload stream ONE STEP AHEAD of their use (vo_pipeline_set_frame_pinned): while step k -> k+1 runs,
+    # frame k+2 -- read ahead from the sequence, as a file or dataset reader can -- crosses PCIe beside it.  One frame
+    # of look-ahead on the results as before: the pose of frame k is read back after frame k+1 has been submitted.
+    ring = [ctx.pinned_empty((H, W)) for _ in range(SLOTS)]
+    frames = iter(sequence)
+    taken = 0
+
+    def take():
+        nonlocal taken
+        if max_frames is not None and taken >= max_frames:
+            return None
+        f = next(frames, None)
+        if f is not None:
+            taken += 1
+        return f
+
+    def put(s, f):
+        ring[s][...] = _gray(f.image)
+        pipe.set_frame(s, ring[s], pinned=True)
+
+    slot, pending = 0, 0
+    ahead = take()
+    if ahead is not None:
+        put(1, ahead)
+    while ahead is not None:
         t0 = time.perf_counter()
-        nxt = (slot + 1) % 3
+        nxt = (slot + 1) % SLOTS
         if pending == 2:
             results.append(pipe.collect())
             pending -= 1
-        pipe.set_frame(nxt, _gray(new_frame.image))
+        t1 = time.perf_counter()
+        ahead = take()                                   # the frame of the NEXT step: its slot was read last by a collected step
+        t2 = time.perf_counter()                         # (reading / decoding / rendering the frame is the sequence's time, not the loop's)
+        if ahead is not None:
+            put((slot + 2) % SLOTS, ahead)
         pipe.submit(slot, nxt)
         pending += 1
         slot = nxt
-        seconds.append(time.perf_counter() - t0)
+        seconds.append(time.perf_counter() - t0 - (t2 - t1))
     while pending:
         results.append(pipe.collect())
         pending -= 1
