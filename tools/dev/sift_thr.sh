@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs tools/dev/libvo_hip_dbg.so: libvo_hip.so built from a copy of csrc/ in which sift_enqueue takes its extrema
+# threshold from getenv("VO_SIFT_DEBUG_THRESHOLD") when set (a one-line patch; the variant library is not kept)
 # extrema kernel with and without extrema (threshold 1e30): is the candidate append what bounds it?
 set -eo pipefail
 out=gpurun_out/sift_thr

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs tools/dev/libvo_hip_noxcd.so: libvo_hip.so built from a copy of csrc/ in which vo_xcd_tile returns its id
+# (harris.o and klt.o rebuilt, the other objects reused; the variant library is not kept)
 # A/B of the XCD-aware tile order (development measurement): the built library against tools/dev/libvo_hip_noxcd.so
 set -eo pipefail
 out=gpurun_out/xcd_ab
