@@ -247,15 +247,23 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
   };
   unsigned long long c_all = 0ull, c_before = 0ull;
   int my_key = 3;
-#pragma unroll 4
-  for (int base = 0; base < n_in; base += 256) {
-    const int j = base + tid;
-    const int key = key_of(j);
-    if (base == start) my_key = key;
-    if (key < 3) {
-      const unsigned long long one = 1ull << (21 * key);
-      c_all += one;
-      if (base < start) c_before += one;
+  // (sixteen items' flags per work item requested together: the forward stream hands 2600-4600 items to this kernel,
+  //  and four at a time were three to five dependent round trips -- on the main chain AND in front of the tracker)
+  constexpr int RG_U = 16;
+  for (int base0 = 0; base0 < n_in; base0 += 256 * RG_U) {
+    int keys[RG_U];
+#pragma unroll
+    for (int u = 0; u < RG_U; ++u) keys[u] = key_of(base0 + u * 256 + tid);
+#pragma unroll
+    for (int u = 0; u < RG_U; ++u) {
+      const int base = base0 + u * 256;
+      const int key = keys[u];                    // (3 beyond n_in)
+      if (base == start) my_key = key;
+      if (key < 3) {
+        const unsigned long long one = 1ull << (21 * key);
+        c_all += one;
+        if (base < start) c_before += one;
+      }
     }
   }
 #pragma unroll
