@@ -211,6 +211,8 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
                                                  const float* __restrict__ err, float err_thr, vo_append ap, int cap,
                                                  unsigned long long (&s_red)[2][4], int (&s_wcnt)[3][4]) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int RG_U = 16;
+  const int start = blockIdx.x * 256;
   const int entry_fault = ctl->fault;
   int fault = entry_fault;
   const int n = ctl->n;
@@ -232,8 +234,33 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
     return;
   }
   const int n_in = n + (redetect ? ap.n_det : 0);
-  const int start = blockIdx.x * 256;
   if (start >= n_in && blockIdx.x != 0) return;
+  // The flags of the first 16 x 256 items and this work item's own feature are requested together, ahead of the counting:
+  // this kernel sits on the main chain AND in front of the tracker, and each dependent round trip here (there were up to
+  // six: flags four items at a time, then the own feature behind the counts) is ~2 us of both cycles.  (Requesting them even
+  // before the control block is read, at indices clamped by the capacity, measured no faster.)
+  const int capm = max(n_in - 1, 0), pitm = max(n - 1, 0);
+  int r_s8[RG_U], r_st[RG_U];
+  float r_e[RG_U];
+#pragma unroll
+  for (int u = 0; u < RG_U; ++u) {
+    const int j = u * 256 + tid;
+    r_s8[u] = status[min(j, capm)];
+    r_e[u] = err[min(j, capm)];
+    r_st[u] = A.state[min(j, pitm)];
+  }
+  const int jo = start + tid, jq = min(jo, pitm), jx = min(jo, capm);
+  double o_land[3], o_track[2], o_kp[2], o_pose[12];
+  const float o_nx = next_xy[2 * jx], o_ny = next_xy[2 * jx + 1];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o_land[k] = A.land[3 * jq + k];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    o_track[k] = A.track[2 * jq + k];
+    o_kp[k] = A.kp64[2 * jq + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) o_pose[k] = A.pose[(size_t)k * A.pitch + jq];
   auto key_of = [&](int j) -> int {      // 0 triangulated, 1 matched, 2 newly matched, 3 dropped
     // (unconditional loads at clamped indices, no short-circuit: the three requests of an item, and those of the
     //  following items, go out together instead of one dependent round trip after the other)
@@ -249,11 +276,19 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
   int my_key = 3;
   // (sixteen items' flags per work item requested together: the forward stream hands 2600-4600 items to this kernel,
   //  and four at a time were three to five dependent round trips -- on the main chain AND in front of the tracker)
-  constexpr int RG_U = 16;
   for (int base0 = 0; base0 < n_in; base0 += 256 * RG_U) {
     int keys[RG_U];
 #pragma unroll
-    for (int u = 0; u < RG_U; ++u) keys[u] = key_of(base0 + u * 256 + tid);
+    for (int u = 0; u < RG_U; ++u) {
+      const int j = base0 + u * 256 + tid;
+      if (base0 == 0) {                        // (from the values requested at the top)
+        const int keep = (int)(j < n_in) & (int)(r_s8[u] != 0) & (int)(r_e[u] < err_thr);
+        const int st = j < n ? r_st[u] : 0;
+        keys[u] = keep ? (st == 2 ? 0 : (st == 1 ? 1 : 2)) : 3;
+      } else {
+        keys[u] = key_of(j);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < RG_U; ++u) {
       const int base = base0 + u * 256;
@@ -292,9 +327,30 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
     int dst = (int)((before >> (21 * my_key)) & 0x1fffff) + rank;
     for (int w = 0; w < wv; ++w) dst += s_wcnt[my_key][w];
     dst += my_key == 0 ? 0 : (my_key == 1 ? T0 : T0 + T1);
-    const double x = (double)next_xy[2 * j], y = (double)next_xy[2 * j + 1];
+    const double x = (double)o_nx, y = (double)o_ny;
     if (j < n) {
-      write_group(A, B, my_key, j, dst, x, y);
+      // (write_group, from the registers filled above)
+      const double nan = dnan();
+      B.kp[2 * dst] = (float)x;
+      B.kp[2 * dst + 1] = (float)y;
+      B.kp64[2 * dst] = x;
+      B.kp64[2 * dst + 1] = y;
+      B.cand[dst] = 0;
+      if (my_key == 0) {       // triangulated: the landmark travels, the track data is over (matches.py:146-201)
+        B.state[dst] = 2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) B.land[3 * dst + k] = o_land[k];
+        B.track[2 * dst] = B.track[2 * dst + 1] = nan;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + dst] = nan;
+      } else {
+        B.state[dst] = 1;
+        B.land[3 * dst] = B.land[3 * dst + 1] = B.land[3 * dst + 2] = nan;
+        B.track[2 * dst] = my_key == 1 ? o_track[0] : o_kp[0];     // matched before: the track goes on; newly matched: it
+        B.track[2 * dst + 1] = my_key == 1 ? o_track[1] : o_kp[1]; // starts at frame 1's keypoint
+#pragma unroll
+        for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + dst] = o_pose[k];
+      }
     } else {
       // a keypoint the detector found on the old frame, tracked: "newly matched" (matches.py:62-110)
       const int d = j - n;
