@@ -311,13 +311,23 @@ __global__ __launch_bounds__(GF_T) void greedy_distance_kernel(const unsigned lo
 constexpr int GC_T = 512, GC_WG = 256, GC_NB = 24, GC_CCAP = 32;
 enum { GC_BAR = 4, GC_OPEN = 5 /* .. 8 */, GC_WGCNT = 16 /* .. 16 + GC_WG */, GC_WORDS = 16 + GC_WG };
 
-__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned& target, unsigned n_wg) {
+// (a wait is bounded: a workgroup that has not been joined within ~0.2 s of device clock -- workgroups that are not all
+//  resident, which the launch's size rules out -- raises *fault and goes on; every workgroup of the launch then runs out of
+//  its waits the same way, and the caller, seeing the flag, runs the one-workgroup walk)
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned& target, unsigned n_wg, unsigned* fault) {
   __syncthreads();
   target += n_wg;
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 20000000ull) {
+        atomicOr(fault, 8u);
+        break;
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(GC_T) void greedy_distance_rounds_kernel(const unsi
     else atomicOr(&ctl[3], 2u);
     state[k] = GF_UNDECIDED;
   }
-  grid_barrier(ctl + GC_BAR, target, n_wg);
+  grid_barrier(ctl + GC_BAR, target, n_wg, ctl + 3);
   if (__hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // (uniform: read behind the barrier)
   // earlier candidates within minDistance
   const int cx = x / cell, cy = y / cell;
@@ -398,7 +408,8 @@ __global__ __launch_bounds__(GC_T) void greedy_distance_rounds_kernel(const unsi
       if (blockIdx.x == 0)       // the word of two rounds on: its readers all passed the previous barrier
         __hip_atomic_store(ctl + GC_OPEN + ((round + 2u) & 3u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    grid_barrier(ctl + GC_BAR, target, n_wg);
+    grid_barrier(ctl + GC_BAR, target, n_wg, ctl + 3);
+    if (__hip_atomic_load(&ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // (a barrier gave up)
     if (__hip_atomic_load(open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;   // (uniform over the launch)
     if (round > nc) {            // (every round decides the first undecided candidate: never reached)
       if (t == 0) atomicOr(&ctl[3], 4u);
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(GC_T) void greedy_distance_rounds_kernel(const unsi
     mine += s_red[w];
   }
   if (t == 0) __hip_atomic_store(ctl + GC_WGCNT + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  grid_barrier(ctl + GC_BAR, target, n_wg);
+  grid_barrier(ctl + GC_BAR, target, n_wg, ctl + 3);
   unsigned part = 0;
   for (unsigned w = t; w < blockIdx.x; w += GC_T) part += __hip_atomic_load(ctl + GC_WGCNT + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
