@@ -64,6 +64,7 @@ RENDER_WORKERS = int(os.environ.get("VO_BENCH_RENDER_WORKERS", str(max(1, min(12
 REFINE_ITERS = int(os.environ.get("VO_BENCH_REFINE", "20"))   # Gauss-Newton steps allowed to the pose refinement (0: off)
 EXCHANGE_EVERY = int(os.environ.get("VO_BENCH_EXCHANGE_EVERY", "16"))   # frames per all-gather of {pose, landmarks} records
 REDETECT_POSE = os.environ.get("VO_BENCH_REDETECT_POSE", "current")   # see vo_pipeline_config.redetect_start_pose
+PREPARE_AHEAD = os.environ.get("VO_BENCH_PREPARE", "1") != "0"      # vo_pipeline_prepare: the next frame's pyramid one step ahead
 DETECT_MARGIN = float(os.environ.get("VO_BENCH_DETECT_MARGIN", "0.01"))   # see vo_pipeline_config.detect_margin (< 0: every frame)
 PROF_EVERY = 4           # HIP-event pairs around every 4th launch of the dominant kernel in the timed region
 HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -166,6 +167,8 @@ class Walker:
                     self.cur = PASS_START
                     self.passes += 1
                 pipe.submit(self.cur, self.cur + 1)
+                if PREPARE_AHEAD and self.cur + 2 < self.n_frames:
+                    pipe.prepare(self.cur + 2)                 # the coming step's pyramid, behind this step's tracker
                 flight.append(self.cur + 1)
                 self.cur += 1
                 submitted += 1
@@ -484,6 +487,8 @@ def upload_leg(ctx, stream, state):
                     pipe.set_frame((k + 1) % 4, src[k + 1], pinned=is_pinned)
                 tc = time.perf_counter()
                 pipe.submit(k % 4, (k + 1) % 4)
+                if PREPARE_AHEAD and ahead and k + 2 < n:
+                    pipe.prepare((k + 2) % 4)
                 pending += 1
                 td = time.perf_counter()
                 t_col += tb - ta

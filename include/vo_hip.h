@@ -515,6 +515,11 @@ int vo_pipeline_set_frame_seq(vo_pipeline* p, int seq, int idx, const uint8_t* i
  * (src/main.py:248-251: frame.image goes into Tracker.track as a host array).                                         */
 int vo_pipeline_set_frame_pinned(vo_pipeline* p, int seq, int idx, const uint8_t* pinned_img);
 int vo_pipeline_frame_uploaded(vo_pipeline* p, int idx, int wait);
+/* Hint: frame slot idx will be the `next_idx` of the coming vo_pipeline_submit.  Its pyramid (klt.py:233-249 builds it
+ * inside cv2.calcOpticalFlowPyrLK, per call) is built now, behind the tracker of the step submitted last, so the coming
+ * step's tracker does not start behind a pyramid that its own, later, submit enqueues.  Results do not depend on the hint;
+ * a wrong one costs one wasted pyramid.  KLT tracker mode; a no-op otherwise and before the first step.                 */
+int vo_pipeline_prepare(vo_pipeline* p, int idx);
 int vo_host_alloc(vo_ctx* ctx, size_t bytes, void** out);
 int vo_host_free(vo_ctx* ctx, void* p);          /* ctx may be NULL */
 int vo_pipeline_set_state_seq(vo_pipeline* p, int seq, int idx, int n, const double* kp, const uint8_t* state,

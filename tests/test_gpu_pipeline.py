@@ -381,6 +381,47 @@ def test_frames_from_pinned_memory_uploaded_a_step_ahead(ctx):
     pipe.close()
 
 
+def test_prepare_hint_changes_nothing_but_the_schedule(ctx):
+    """vo_pipeline_prepare: the coming frame's pyramid built a step ahead.  Right hints, wrong hints (another frame: the
+    pyramid is built again by the submit) and hints around forced faults (every fourth step through the host path) give
+    the records and the state of the run without hints."""
+    from vo import synthetic
+    H, W, N, hyp, F = 240, 320, 300, 256, 6
+    stream = synthetic.Stream(F, H, W)
+    feats, T = start_state(stream, N, 0.85)
+    order = stream.order(11)
+    pairs = list(zip(order[:-1], order[1:]))
+
+    def run(hint, fault_every=0):
+        pipe = make_pipe(ctx, stream, N, hyp, debug_fault_every=fault_every)
+        pipe.set_state(0, feats, T, T)
+        pipe.prepare(pairs[0][1])                  # (before the first step: a no-op)
+        out = []
+        pipe.submit(*pairs[0])
+        for k in range(len(pairs)):
+            if k + 1 < len(pairs):
+                if hint == "right":
+                    pipe.prepare(pairs[k + 1][1])
+                elif hint == "wrong":
+                    pipe.prepare((pairs[k + 1][1] + 2) % F)
+                elif hint == "mixed" and k % 3:
+                    pipe.prepare(pairs[k + 1][1] if k % 2 else pairs[k + 1][0])
+                pipe.submit(*pairs[k + 1])
+            out.append(pipe.collect())
+        st = pipe.get_state()
+        pipe.close()
+        return out, st
+
+    for fe in (0, 4):
+        ref, st_ref = run(None, fe)
+        for hint in ("right", "wrong", "mixed"):
+            got, st = run(hint, fe)
+            for a, b in zip(got, ref):
+                assert fields(a) == fields(b), (hint, fe)
+            for key in ("keypoints", "state", "candidate_mask", "landmarks", "tracks", "poses", "curr_pose"):
+                assert np.array_equal(st[key], st_ref[key], equal_nan=True), (hint, fe, key)
+
+
 def test_pipeline_stress_configuration_properties(ctx):
     """BASELINE.json configs[4] (3840x2160, 8000 keypoints, 4-level pyramid, 4000 hypotheses): beyond what the
     oracle finishes in seconds, so checked through properties that do not depend on size -- the greedy NMS rule

@@ -1299,21 +1299,30 @@ int vo_klt_track_ndev(vo_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_prev_
     const float me = (float)min_eig;
     const dim3 kgrid(vo_cdiv(N, KLT_WAVES), S), kblock(64 * KLT_WAVES);
     switch (win) {
-      case 15:
-        hipLaunchKernelGGL((klt_track16_kernel<15, 16>), dim3(vo_cdiv(N, 4), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B, max_iter,
-                           eps * eps, me, d_next_xy, d_status, d_err);
+      case 15: {
+        // 16 lanes per keypoint (four per wave).  VO_KLT_LPK=32: two per wave, the upper half of each group idle in the row
+        // loops, the 18 rows of the template block in one pass instead of two -- measured slower (round 3: step 87.6 ->
+        // 91.3 us at one sequence, the kernel 199 -> 351 us at 16), kept as the measurement's knob.
+        static const int lpk_env = getenv("VO_KLT_LPK") ? atoi(getenv("VO_KLT_LPK")) : 0;
+        if (lpk_env == 32)
+          vo_launch_stop(ctx, klt_track16_kernel<15, 32>, dim3(vo_cdiv(N, 2), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B,
+                         max_iter, eps * eps, me, d_next_xy, d_status, d_err);
+        else
+          vo_launch_stop(ctx, klt_track16_kernel<15, 16>, dim3(vo_cdiv(N, 4), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B,
+                         max_iter, eps * eps, me, d_next_xy, d_status, d_err);
         break;
+      }
       case 17:   // the reference's default window (klt.py:29)
-        hipLaunchKernelGGL((klt_track16_kernel<17, 32>), dim3(vo_cdiv(N, 2), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B, max_iter,
-                           eps * eps, me, d_next_xy, d_status, d_err);
+        vo_launch_stop(ctx, klt_track16_kernel<17, 32>, dim3(vo_cdiv(N, 2), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B,
+                       max_iter, eps * eps, me, d_next_xy, d_status, d_err);
         break;
       case 21:
-        hipLaunchKernelGGL((klt_track16_kernel<21, 32>), dim3(vo_cdiv(N, 2), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B, max_iter,
-                           eps * eps, me, d_next_xy, d_status, d_err);
+        vo_launch_stop(ctx, klt_track16_kernel<21, 32>, dim3(vo_cdiv(N, 2), S), dim3(64), 0, st, P, d_prev_xy, N, d_n, src, B,
+                       max_iter, eps * eps, me, d_next_xy, d_status, d_err);
         break;
       default:
-        hipLaunchKernelGGL(klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, d_n, src, B, win, max_iter, eps * eps,
-                           me, d_next_xy, d_status, d_err, lds_wave);
+        vo_launch_stop(ctx, klt_track_kernel<0>, kgrid, kblock, lds, st, P, d_prev_xy, N, d_n, src, B, win, max_iter, eps * eps,
+                       me, d_next_xy, d_status, d_err, lds_wave);
     }
   }
   return vo_check_launch(ctx, "klt_track_kernel");

@@ -455,7 +455,9 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double* __restrict_
 //   the population is read from memory once per workgroup (Hyp / HG times in all, not Hyp times: the one-workgroup-
 //   per-hypothesis kernel streams ~70 MB through L2 at cfg-2 and slows down 3x when the tracker and the detector
 //   run beside it), inlier bits leave as one ballot word per wave, counts as popcounts.
-// HG hypotheses per workgroup: 8 for one sequence (125 workgroups at 1000 hypotheses: latency), 16 when a launch holds
+// HG hypotheses per workgroup: 4 for one sequence (250 workgroups at 1000 hypotheses, one per compute unit; 8 per workgroup left
+// 131 of the 256 units idle: 22.4 -> 20.0 us, the rest is the solve's own dependent chain -- 2 per workgroup: 19.8), 8 for a few
+// sequences, 16 when a launch holds
 // several sequences (wave 0's 64 lanes all solve, half as many workgroups share the solve's latency: throughput).
 // Correspondences per thread and tile: 7 for HG = 8 (256 * 7 = 1792 = 28 mask words: one tile at every population the
 // frame loop sees), 4 for HG = 16, which with five waves per SIMD asked for (96 registers: the solve spills 11 words,
@@ -635,9 +637,19 @@ int vo_p3p_hypotheses_ring_dev(vo_ctx* ctx, const double* d_X, const double* d_x
   const double lim = sum_sq_limit(thr_sq);   // (lim: see reproj_sum_sq)
   {
     vo_prof_scope ps(ctx, VO_K_P3P_SOLVE);
-    static const int forced = getenv("VO_HYP_GROUP") ? atoi(getenv("VO_HYP_GROUP")) : 0;   // measurements: 8 / 16
+    static const int forced = getenv("VO_HYP_GROUP") ? atoi(getenv("VO_HYP_GROUP")) : 0;   // measurements: 2 / 4 / 8 / 16
     if (forced == 16 || (forced != 8 && S >= 8))
       hipLaunchKernelGGL(p3p_hyp_kernel<16>, dim3(vo_cdiv(Hyp, 16), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
+                         (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], lim, d_R,
+                         d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts,
+                         B);
+    else if (forced == 4 || (forced == 0 && S == 1))
+      hipLaunchKernelGGL(p3p_hyp_kernel<4>, dim3(vo_cdiv(Hyp, 4), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
+                         (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], lim, d_R,
+                         d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts,
+                         B);
+    else if (forced == 2)
+      hipLaunchKernelGGL(p3p_hyp_kernel<2>, dim3(vo_cdiv(Hyp, 2), S), dim3(256), 0, ctx->stream, d_X, d_x, d_raws,
                          (const unsigned long long*)d_rawpos, raw_mask, d_n, d_flag, Hyp, K[0], K[4], K[2], K[5], lim, d_R,
                          d_t, d_valid, d_counts, (unsigned long long*)d_masks, vo_cdiv(n_cap, 64), (unsigned long long*)d_ts,
                          B);

@@ -65,6 +65,9 @@ struct vo_pipeline {
   // not in front of the pyramid); side[idx]: slot idx was last filled that way -- the tracker's stream waits for evImg too
   hipStream_t up_stream = nullptr;
   std::vector<char> side;
+  // vo_pipeline_prepare: the pyramid of frame slot prepared_idx sits in pyramid slot prepared_slot, built behind the
+  // previous tracker -- the next submit whose `next` is that frame does not build it again (-1: none)
+  int prepared_idx = -1, prepared_slot = -1;
   int slot = 0, det_flip = 0, prev_frame = -1;
   // Features double buffer: a step reads F[cur] (frame k-1) and writes F[1 - cur] (frame k)
   vo_feat F[2];
@@ -75,7 +78,7 @@ struct vo_pipeline {
   uint8_t* d_status = nullptr;
   double *d_R = nullptr, *d_t = nullptr;       // [S][hyp * 9], [S][hyp * 3]
   uint8_t* d_valid = nullptr;
-  int32_t *d_counts = nullptr, *d_samples = nullptr;
+  int32_t *d_counts = nullptr, *d_samples = nullptr, *d_pend = nullptr;   // d_pend: [S][cap], state_walk_landmarks_kernel's scratch
   uint64_t *d_masks = nullptr, *d_best_mask = nullptr;
   double* d_table = nullptr;
   std::vector<double> table;
@@ -145,6 +148,7 @@ struct vo_pipeline {
   // that a polling kernel can never keep the kernel it waits for from running.  After anything was enqueued again for
   // one sequence (host path, a continuing RANSAC loop, a rewind) the next submit also waits for the events.
   bool gates = false, gate_resync = false;
+  bool ext_events = true;            // see enqueue_tracker
   int sift_chain_pending = 0;        // SIFT mode: flights whose main-stream chain is not enqueued yet (their SIFT launches are
                                      // being made by the worker; the chain follows at the next submit or at collect)
   flight_t jobs[4];
@@ -358,6 +362,8 @@ void sync_prof(vo_pipeline* p) {
 
 static void worker_main(vo_pipeline* p);
 
+static int enqueue_pyramid(vo_pipeline* p, int frame, int s);
+
 extern "C" {
 
 int vo_klt_num_levels(int H, int W, int win, int max_level);
@@ -378,7 +384,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
   void* dev[] = {p->d_det_go, p->d_img, p->d_pyr, p->d_kp, p->d_scores[0], p->d_scores[1], p->feat_mem, p->d_ctl, p->d_next, p->d_err,
                  p->d_status, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_samples, p->d_masks, p->d_best_mask, p->d_table,
                  p->d_raws, p->d_newkp, p->d_pairs, p->d_ckpt_feat, p->d_ckpt_ctl, p->d_skp, p->d_sdesc, p->d_sn, p->d_fdesc,
-                 p->d_srcrow, p->d_ckpt_fdesc};
+                 p->d_srcrow, p->d_ckpt_fdesc, p->d_pend};
   for (void* q : dev)
     if (q) (void)hipFree(q);
   void* pin[] = {p->h_stage, p->h_res, (void*)p->h_seq};
@@ -485,6 +491,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
       // those are an invalidate / a write-back of the XCD's L2: with ~1000 tracker workgroups per frame the hypothesis and
       // pose kernels running beside them lose their cached population over and over (hypotheses -> pose 23 -> 40 us,
       // pose 34 -> 45, step 103 -> 133 us).  The gates would need the gated data to bypass L2 altogether.
+      p->ext_events = !(getenv("VO_EXT_EVENTS") && getenv("VO_EXT_EVENTS")[0] == '0');
       p->gates = sc != nullptr && p->S <= 2 && !side && (w == 15 || w == 17 || w == 21) && g && g[0] == '1';
     }
     const char* saved_c = getenv("VO_STREAM_CUS");
@@ -538,6 +545,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   PA(dev_alloc(ctx, &p->d_samples, (size_t)Hyp * 4));
   PA(dev_alloc(ctx, &p->d_masks, Sz * Hyp * p->words));
   PA(dev_alloc(ctx, &p->d_best_mask, Sz * p->words));
+  PA(dev_alloc(ctx, &p->d_pend, Sz * cap));
   PA(dev_alloc(ctx, &p->d_newkp, (size_t)cap * 2));
   PA(dev_alloc(ctx, &p->d_pairs, (size_t)cap * 2));
   if (cfg->tracker_mode != 0) {
@@ -669,6 +677,7 @@ int vo_pipeline_set_frame_seq(vo_pipeline* p, int seq, int idx, const uint8_t* i
   VO_HIP_TRY(ctx, hipMemcpyAsync(p->img(seq, idx), stage, p->px, hipMemcpyHostToDevice, p->trk->stream));
   VO_HIP_TRY(ctx, hipEventRecord(p->evImg[idx], p->trk->stream));
   p->side[(size_t)idx] = 0;
+  if (p->prepared_idx == idx) p->prepared_idx = p->prepared_slot = -1;
   return VO_OK;
 }
 
@@ -692,6 +701,7 @@ int vo_pipeline_set_frame_pinned(vo_pipeline* p, int seq, int idx, const uint8_t
   VO_HIP_TRY(ctx, hipMemcpyAsync(p->img(seq, idx), pinned_img, p->px, hipMemcpyHostToDevice, p->up_stream));
   VO_HIP_TRY(ctx, hipEventRecord(p->evImg[idx], p->up_stream));
   p->side[(size_t)idx] = 1;
+  if (p->prepared_idx == idx) p->prepared_idx = p->prepared_slot = -1;
   return VO_OK;
 }
 
@@ -704,6 +714,25 @@ int vo_pipeline_frame_uploaded(vo_pipeline* p, int idx, int wait) {
     return 1;
   }
   return hipEventQuery(p->evImg[idx]) == hipSuccess ? 1 : 0;
+}
+
+// The pyramid of a frame that a coming step will track INTO, built now, behind the tracker of the step submitted last (on
+// the tracker's stream): the next vo_pipeline_submit whose `next_idx` is this slot finds it ready.  Without the hint a
+// step's pyramid is enqueued by its own submit -- which the host makes when it has collected the step before the previous
+// one -- and the tracker, which needs nothing else that late, starts behind it: 31 us after the previous regroup instead
+// of ~15.  (KLT tracker mode; a no-op in the others.  A hint that turns out wrong costs one wasted pyramid.)
+int vo_pipeline_prepare(vo_pipeline* p, int idx) {
+  if (!p) return VO_EINVAL;
+  vo_ctx* ctx = p->ctx;
+  VO_REQUIRE(ctx, idx >= 0 && idx < p->cfg.n_frames, "pipeline_prepare: bad frame slot");
+  if (p->cfg.tracker_mode != 0 || !p->primed || !p->have_state) return VO_OK;
+  VO_HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int s = (p->slot + 1) % 3;                    // the pyramid slot the next submit gives its `next` frame
+  // (that slot held the `prev` pyramid of the step before the one submitted last: its tracker is earlier on this stream)
+  VO_TRY(enqueue_pyramid(p, idx, s));
+  p->prepared_idx = idx;
+  p->prepared_slot = s;
+  return VO_OK;
 }
 
 int vo_host_alloc(vo_ctx* ctx, size_t bytes, void** out) {
@@ -788,6 +817,7 @@ static int enqueue_detection(vo_pipeline* p, int frame, int s, bool force, char*
 }
 
 static int enqueue_pyramid(vo_pipeline* p, int frame, int s) {
+  if (s == p->prepared_slot) p->prepared_idx = p->prepared_slot = -1;      // (whatever vo_pipeline_prepare left there goes)
   if (p->side[(size_t)frame] && hipStreamWaitEvent(p->trk->stream, p->evImg[frame], 0) != hipSuccess)   // (vo_pipeline_set_frame_pinned)
     return vo_set_error(p->ctx, VO_EHIP, "pyramid: hipStreamWaitEvent failed");
   const vo_pipeline_config& c = p->cfg;
@@ -890,6 +920,11 @@ static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool 
   kb.out = (size_t)p->cap;
   kb.ctl = sizeof(vo_seq_ctl);
   kb.det = p->det_stride();
+  // The tracker's and the regroup's events are the kernels' own completion signals (vo_ctx::next_stop), not markers behind
+  // them: a marker between the regroup and the hypothesis kernel cost the main chain 3.7 us, the tracker started 3.4 us
+  // later behind it (step 85.8 -> 84.2 us).  VO_EXT_EVENTS=0: hipEventRecord.
+  const bool ext_events = p->ext_events;
+  if (ext_events) p->trk->next_stop = p->evKlt[f.k & 1];
   {
     const size_t q = (size_t)q0;
     const int rc = vo_klt_track_ndev(p->trk, p->img(q0, f.prev_idx), p->pyr(q0, f.a), p->img(q0, f.next_idx), p->pyr(q0, f.b),
@@ -898,7 +933,12 @@ static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool 
                                      p->d_err + q * p->cap, &src, &kb);
     if (rc != VO_OK) return vo_set_error(ctx, rc, "tracker: %s", vo_last_error(p->trk));
   }
-  VO_HIP_TRY(ctx, hipEventRecord(p->evKlt[f.k & 1], ts));
+  if (p->trk->next_stop) {             // (the launch did not take the event)
+    p->trk->next_stop = nullptr;
+    VO_HIP_TRY(ctx, hipEventRecord(p->evKlt[f.k & 1], ts));
+  } else if (!ext_events) {
+    VO_HIP_TRY(ctx, hipEventRecord(p->evKlt[f.k & 1], ts));
+  }
   return VO_OK;
 }
 
@@ -924,9 +964,11 @@ static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fi
   ap.pose_mode = c.redetect_start_pose;
   ap.debug_fault_every = debug_fault_every > 0 ? debug_fault_every : 0;
   ap.det_go = p->d_det_go + (size_t)f.a * p->S + q0;
+  const bool ext_events = p->ext_events;
+  if (ext_events) ctx->next_stop = p->evRegroup[f.k & 1];
   VO_TRY(vo_state_regroup_klt(ctx, ctl, A, B, p->d_next + q * p->cap * 2, p->d_status + q * p->cap, p->d_err + q * p->cap,
                               (float)c.klt_err_threshold, ap, p->cap, Sn));
-  VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], ctx->stream));
+  if (!ext_events) VO_HIP_TRY(ctx, hipEventRecord(p->evRegroup[f.k & 1], ctx->stream));
   if (first_half_only) return VO_OK;
   return enqueue_pose_half(p, f, q0, Sn, seq);
 }
@@ -963,9 +1005,25 @@ static int enqueue_pose_half(vo_pipeline* p, const vo_pipeline::flight_t& f, int
   // against 18 for the launch, its boundary included; step period 152 -> 121 us.)
   static const bool split_tail = getenv("VO_FUSED_TAIL") == nullptr;
   if (split_tail) {
+    // The feature walk (reset_outliers, bearing-angle candidates: fp64 arithmetic of every feature) was the last third of the
+    // pose kernel, on its ONE compute unit: 10 us.  VO_SPLIT_WALK=1: a launch of its own, cap / 256 workgroups, between the pose
+    // kernel and the landmark stage (step period 93.4 -> 87.8 us); default (2): walk and landmark stage in ONE launch
+    // (state_walk_landmarks_kernel), one boundary less; 0: the walk inside the pose kernel.
+    static const int walk_mode = getenv("VO_SPLIT_WALK") ? atoi(getenv("VO_SPLIT_WALK")) : 2;
     job.tail = 0;
+    job.walk = walk_mode ? 0 : 1;
     VO_TRY(vo_frame_pose(ctx, job, Sn));
-    VO_TRY(vo_state_landmarks(ctx, ctl, B, p->cam, c.refine_iters > 0 ? 1 : 0, p->cap, job.res, job.seq_word, seq, Sn));
+    const uint64_t* bm = p->d_best_mask + (size_t)q0 * p->words;
+    const int rec_refined = c.refine_iters > 0 ? 1 : 0;
+    if (walk_mode == 2) {
+      VO_TRY(vo_state_walk_landmarks(ctx, ctl, B, bm, p->words, p->cam, c.bearing_threshold, rec_refined, p->cap,
+                                     p->d_pend + q * p->cap, job.res, job.seq_word, seq, Sn));
+      return VO_OK;
+    }
+    if (walk_mode == 1)
+      VO_TRY(vo_state_candidates(ctx, ctl, B, bm, p->cam, c.bearing_threshold, 1 /* ctl->refined: what the pose kernel's walk uses */,
+                                 p->cap, Sn, p->words));
+    VO_TRY(vo_state_landmarks(ctx, ctl, B, p->cam, rec_refined, p->cap, job.res, job.seq_word, seq, Sn));
     return VO_OK;
   }
   VO_TRY(vo_frame_pose(ctx, job, Sn));
@@ -1219,6 +1277,7 @@ static int prime(vo_pipeline* p, bool wait = true) {
   }
   VO_TRY(worker_idle(p));
   sync_prof(p);
+  p->prepared_idx = p->prepared_slot = -1;           // (a hand-over or a rewind: the slots start over)
   VO_TRY(enqueue_pyramid(p, p->prev_frame, p->slot));
   VO_TRY(enqueue_detection(p, p->prev_frame, p->slot, true));
   if (wait) {        // (not needed for order: the tracker sits behind the pyramid on its stream and waits for evDet)
@@ -1472,7 +1531,9 @@ int vo_pipeline_submit(vo_pipeline* p, int prev_idx, int next_idx) {
   double tn = now_s();
   p->dbg_part[0] += tn - tq;
   tq = tn;
-  VO_TRY(enqueue_tracker(p, f, true, 0, p->S, p->gates));
+  const bool have_pyr = p->prepared_idx == next_idx && p->prepared_slot == f.b;
+  p->prepared_idx = p->prepared_slot = -1;
+  VO_TRY(enqueue_tracker(p, f, !have_pyr, 0, p->S, p->gates));
   tn = now_s();
   p->dbg_part[1] += tn - tq;
   tq = tn;

@@ -469,6 +469,13 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
       if (job.stamps) ctl->ts[7] = wall_clock64();
     }
   }
+  if (!job.walk) {          // the walk's own launch goes on from here: its counters start at 0
+    if (tid == 0) {
+      ctl->n_cand = 0;
+      ctl->n_pend = 0;
+    }
+    return;
+  }
   // ---- the new pose, both ways (update_with_world_pose, state.py:38-50), then every feature ----
   double Tcw[12], Twc[12];
 #pragma unroll

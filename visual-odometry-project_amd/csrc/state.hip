@@ -433,7 +433,13 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
 // use_refined: 1 the refinement's pose, 0 the accepted hypothesis, -1 the pose the host put into ctl->T_in_*.
 __global__ __launch_bounds__(256) void state_candidates_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat B,
                                                                const unsigned long long* __restrict__ best_mask,
-                                                               vo_cam cam, double bearing_thr, int use_refined) {
+                                                               vo_cam cam, double bearing_thr, int use_refined, int words) {
+  if (blockIdx.y != 0) {               // several sequences per launch: grid.y = sequence
+    const size_t q = blockIdx.y;
+    ctl += q;
+    B = vo_feat_seq(B, q);
+    best_mask += q * (size_t)words;
+  }
   if (ctl->fault) return;
   const int tid = threadIdx.x;
   const int n2 = ctl->n2, n_tri = ctl->n_tri;
@@ -567,14 +573,171 @@ __global__ __launch_bounds__(256) void state_landmarks_kernel(vo_seq_ctl* __rest
   write_step_record(ctl, tid, use_refined, n2, n_cand, n_dropped, n_land, atomicAdd(&ctl->ts[4], 0ull), res, seq_word, seq);
 }
 
+
+// The walk (main.py:261-268) and the landmark stage (main.py:279-286) of one frame in ONE launch -- the frame loop's form;
+// state_candidates_kernel + state_landmarks_kernel stay for vo_pipeline_bookkeeping and the host path.  A feature's walk, its
+// triangulation and its cheirality test use nothing of any other feature, with one exception: _check_landmarks runs only
+// when the FRAME has a candidate (state.py:90-107 is called from the `if candidates` branch, main.py:279).  A workgroup
+// that holds a candidate knows that; one that does not (the features come grouped, the triangulated ones first: the first
+// workgroups never hold one) leaves the features it would drop in `pend`, and the workgroup that arrives last -- it knows
+// the frame's count -- drops them.  The same workgroup commits the pose (every other one has read the previous pose by
+// then), closes the step and writes its record.  One launch and one kernel boundary (5-7 us) less on the step's dependent chain.
+__global__ __launch_bounds__(256) void state_walk_landmarks_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat B,
+                                                                   const unsigned long long* __restrict__ best_mask, int words,
+                                                                   vo_cam cam, double bearing_thr, int use_refined,
+                                                                   int* __restrict__ pend, vo_step_result* __restrict__ res,
+                                                                   unsigned* __restrict__ seq_word, unsigned seq, int rec_fence) {
+  __shared__ int s_cnt[3];             // dropped, landmarks, candidates of this workgroup
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  if (blockIdx.y != 0) {               // several sequences per launch: grid.y = sequence
+    const size_t q = blockIdx.y;
+    ctl += q;
+    pend += q * (size_t)B.pitch;
+    B = vo_feat_seq(B, q);
+    best_mask += q * (size_t)words;
+    if (res) {
+      res += q;
+      seq_word += q;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) ctl->ts[4] = wall_clock64();
+  const int fault = ctl->fault;
+  if (fault) {
+    if (res && blockIdx.x == 0 && tid == 0) write_fault_record(ctl, fault, res, seq_word, seq);
+    return;
+  }
+  const int n2 = ctl->n2, n_tri = ctl->n_tri;
+  if (tid < 3) s_cnt[tid] = 0;
+  // world -> camera as the pose kernel left it, camera -> world = its inverse (update_with_world_pose, state.py:38-50);
+  // Tp: the pose that is still the current one -- the previous one once this frame's is committed
+  double Tcw[12], Twc[12], Tp[12];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Tcw[4 * r] = ctl->refined[3 * r];
+    Tcw[4 * r + 1] = ctl->refined[3 * r + 1];
+    Tcw[4 * r + 2] = ctl->refined[3 * r + 2];
+    Tcw[4 * r + 3] = ctl->refined[9 + r];
+  }
+  rigid_inverse_3x4(Tcw, Twc);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Tp[k] = ctl->T_cw[k];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + tid;
+  int cand = 0, st = 0;
+  double X[3] = {0.0, 0.0, 0.0};
+  if (i < n2) {
+    X[0] = B.land[3 * i];
+    X[1] = B.land[3 * i + 1];
+    X[2] = B.land[3 * i + 2];
+    cand = candidate_feature(B, i, n_tri, best_mask, cam, Twc, bearing_thr, &st);
+    if (cand) {
+      // proj1 = K inv(pose_start)[:3], proj2 = K inv(current_pose)[:3] (triangulation.py:53-57)
+      double Ts[12], Ti[12], C1[12], C2[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) Ts[q] = B.pose[(size_t)q * B.pitch + i];
+      rigid_inverse_3x4(Ts, Ti);
+      k_times(cam.K, Ti, C1);
+      k_times(cam.K, Tcw, C2);
+      vo_dlt::triangulate_point(C1, B.track[2 * i], B.track[2 * i + 1], C2, B.kp64[2 * i], B.kp64[2 * i + 1], X);
+      B.land[3 * i] = X[0];
+      B.land[3 * i + 1] = X[1];
+      B.land[3 * i + 2] = X[2];
+      st = 2;
+      B.state[i] = 2;
+    }
+  }
+  {
+    const unsigned long long cm = __ballot(cand != 0);
+    if ((tid & 63) == 0 && cm) atomicAdd(&s_cnt[2], __popcll(cm));
+  }
+  __syncthreads();
+  const int local_cand = s_cnt[2];
+  // behind a camera (NaN landmarks compare false): the track restarts here -- _check_landmarks, state.py:90-107
+  auto drop = [&](int f) {
+    const double nan = dnan();
+    B.land[3 * f] = B.land[3 * f + 1] = B.land[3 * f + 2] = nan;
+    B.state[f] = 0;
+    B.track[2 * f] = B.kp64[2 * f];
+    B.track[2 * f + 1] = B.kp64[2 * f + 1];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + f] = Twc[k];
+  };
+  int dropped = 0;
+  if (i < n2) {
+    const double zc = Tcw[8] * X[0] + Tcw[9] * X[1] + Tcw[10] * X[2] + Tcw[11];
+    const double zp = Tp[8] * X[0] + Tp[9] * X[1] + Tp[10] * X[2] + Tp[11];
+    if (zc < 0.0 || zp < 0.0) {
+      if (local_cand > 0) {
+        drop(i);
+        st = 0;
+        dropped = 1;
+      } else {
+        pend[atomicAdd(&ctl->n_pend, 1)] = i;      // (still counted as what it is; the closing workgroup corrects the counts)
+      }
+    }
+  }
+  {
+    const int d = __popcll(__ballot(dropped != 0)), l = __popcll(__ballot(i < n2 && st == 2));
+    if ((tid & 63) == 0) {
+      if (d) atomicAdd(&s_cnt[0], d);
+      if (l) atomicAdd(&s_cnt[1], l);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (s_cnt[0]) atomicAdd(&ctl->n_dropped, s_cnt[0]);
+    if (s_cnt[1]) atomicAdd(&ctl->n_land, s_cnt[1]);
+    if (local_cand) atomicAdd(&ctl->n_cand, local_cand);
+    __threadfence();
+    s_last = atomicAdd(&ctl->done, 1) == (int)gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last workgroup: every other one's counts, features and pending verdicts are in ----
+  __threadfence();
+  const int n_cand = atomicAdd(&ctl->n_cand, 0), n_pend = atomicAdd(&ctl->n_pend, 0);
+  int n_dropped = atomicAdd(&ctl->n_dropped, 0), n_land = atomicAdd(&ctl->n_land, 0);
+  if (n_cand > 0 && n_pend > 0) {
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    for (int k = tid; k < n_pend; k += 256) {
+      const int f = pend[k];
+      if (B.state[f] == 2) atomicAdd(&s_cnt[1], 1);
+      drop(f);
+      atomicAdd(&s_cnt[0], 1);
+    }
+    __syncthreads();
+    n_dropped += s_cnt[0];
+    n_land -= s_cnt[1];
+  }
+  if (tid < 12) {
+    double ncw = 0.0, nwc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      ncw = tid == k ? Tcw[k] : ncw;
+      nwc = tid == k ? Twc[k] : nwc;
+    }
+    commit_pose(ctl, tid, ncw, nwc);
+  }
+  if (tid == 0) {
+    ctl->n = n2;                       // the new frame is the current one from here on
+    ctl->step += 1;
+  }
+  if (!res) return;
+  __syncthreads();                     // (the record reads the committed pose)
+  write_step_record(ctl, tid, use_refined, n2, n_cand, n_dropped, n_land, atomicAdd(&ctl->ts[4], 0ull), res, seq_word, seq,
+                    rec_fence != 0);
+}
+
 }  // namespace
 
 int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, const float* d_next_xy,
                          const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap, int S) {
   {
     vo_prof_scope ps(ctx, VO_K_STATE_REGROUP);
-    hipLaunchKernelGGL(state_regroup_klt_kernel, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, A, B, d_next_xy,
-                       d_status, d_err, err_thr, ap, cap);
+    vo_launch_stop(ctx, state_regroup_klt_kernel, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, A, B, d_next_xy,
+                   d_status, d_err, err_thr, ap, cap);
   }
   return vo_check_launch(ctx, "state_regroup_klt_kernel");
 }
@@ -593,13 +756,28 @@ int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, c
 }
 
 int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
-                        double bearing_thr, int use_refined, int cap) {
+                        double bearing_thr, int use_refined, int cap, int S, int words) {
   {
     vo_prof_scope ps(ctx, VO_K_STATE_CANDIDATES);
-    hipLaunchKernelGGL(state_candidates_kernel, dim3(vo_cdiv(cap, 256)), dim3(256), 0, ctx->stream, ctl, B,
-                       (const unsigned long long*)d_best_mask, cam, bearing_thr, use_refined);
+    hipLaunchKernelGGL(state_candidates_kernel, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, B,
+                       (const unsigned long long*)d_best_mask, cam, bearing_thr, use_refined, words);
   }
   return vo_check_launch(ctx, "state_candidates_kernel");
+}
+
+int vo_state_walk_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, int words, vo_cam cam,
+                            double bearing_thr, int use_refined, int cap, int32_t* d_pend, vo_step_result* m_result,
+                            unsigned* m_seq, unsigned seq, int S) {
+  VO_REQUIRE(ctx, d_pend != nullptr && cap <= B.pitch, "state_walk_landmarks: bad arguments");
+  {
+    vo_prof_scope ps(ctx, VO_K_STATE_LANDMARKS);
+    // VO_RECORD_FENCE=1: system-scope fences between the record's lines and its closing words (see write_step_record)
+    static const int rec_fence = getenv("VO_RECORD_FENCE") ? atoi(getenv("VO_RECORD_FENCE")) : 0;
+    hipLaunchKernelGGL(state_walk_landmarks_kernel, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, B,
+                       (const unsigned long long*)d_best_mask, words, cam, bearing_thr, use_refined, (int*)d_pend, m_result,
+                       m_seq, seq, rec_fence);
+  }
+  return vo_check_launch(ctx, "state_walk_landmarks_kernel");
 }
 
 int vo_state_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, vo_cam cam, int use_refined, int cap,

@@ -199,10 +199,11 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
 // main.py:261-268 for feature i of the new frame, given the new pose both ways (Tcw world -> camera, Twc its
 // inverse):  outliers[triangulate_inliers] = ~inliers; set_pose_for_new_tracks (features.py:224-237);
 // reset_outliers (state.py:162-172); compute_candidates (state.py:135-160, 174-219: bearing angle between the rays
-// through the track's first and last keypoint >= threshold, among state == 1).  Returns the candidate flag.
+// through the track's first and last keypoint >= threshold, among state == 1).  Returns the candidate flag; st_out: the
+// feature's state code as this leaves it.
 __device__ __forceinline__ int candidate_feature(const vo_feat& B, int i, int n_tri,
                                                  const unsigned long long* __restrict__ best_mask, const vo_cam& cam,
-                                                 const double* Twc, double bearing_thr) {
+                                                 const double* Twc, double bearing_thr, int* st_out = nullptr) {
   int st = B.state[i];
   const int st0 = st;
   const double u = B.kp64[2 * i], v = B.kp64[2 * i + 1];
@@ -240,6 +241,7 @@ __device__ __forceinline__ int candidate_feature(const vo_feat& B, int i, int n_
     cand = ang >= bearing_thr ? 1 : 0;                      // (NaN compares false, as in NumPy)
   }
   B.cand[i] = (uint8_t)cand;
+  if (st_out) *st_out = reset ? 0 : st;
   return cand;
 }
 
@@ -305,7 +307,7 @@ __device__ __forceinline__ void write_fault_record(const vo_seq_ctl* __restrict_
 __device__ __forceinline__ void write_step_record(vo_seq_ctl* __restrict__ ctl, int tid, int use_refined, int n2, int n_cand,
                                                   int n_dropped, int n_land, unsigned long long ts4,
                                                   vo_step_result* __restrict__ res, unsigned* __restrict__ seq_word,
-                                                  unsigned seq) {
+                                                  unsigned seq, bool fences = true) {
   __shared__ __align__(8) unsigned s_rec[REC_DW];
   vo_step_result* r = reinterpret_cast<vo_step_result*>(s_rec);
   if (tid < REC_DW) s_rec[tid] = 0u;
@@ -358,10 +360,14 @@ __device__ __forceinline__ void write_step_record(vo_seq_ctl* __restrict__ ctl, 
     dst[tid] = v0;
     if (second) dst[tid + 64] = v1;
     if (tid == 0) dst[REC_DW - 2] = seq ^ x;
-    __threadfence_system();
+    // fences = false: no system-scope fence between the lines, the closing words and the sequence word.  The host accepts a
+    // copy only when both check words fit (the lines arrive in no order WITH the fences too, see above), so the fences add
+    // nothing to what it can rely on -- and each is a write-back of the L2 plus a round trip to host memory at the end of
+    // the step's dependent chain.
+    if (fences) __threadfence_system();
     if (tid == 0) {
       dst[REC_DW - 1] = seq + y;
-      __threadfence_system();
+      if (fences) __threadfence_system();
       *seq_word = seq;
     }
   }

@@ -1,6 +1,7 @@
 // Internal (C++) declarations shared by the HIP translation units of libvo_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -32,6 +33,10 @@ struct vo_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   char err[512] = {0};
+  // When set, the next launch that supports it (state_regroup_klt, klt_track16) is made with hipExtLaunchKernelGGL and this
+  // event as its stop event: the event IS the kernel's completion signal, no marker packet behind the kernel (a marker
+  // costs the queue ~4 us before the next dispatch, and a waiting queue one more hop).  Cleared by that launch.
+  hipEvent_t next_stop = nullptr;
 
   // profiling
   bool prof_on = false;
@@ -63,6 +68,17 @@ struct vo_ctx {
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
 };
+
+// a launch that takes vo_ctx::next_stop as its stop event when one is set (and clears it)
+template <class K, class... A>
+inline void vo_launch_stop(vo_ctx* ctx, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+  if (ctx->next_stop) {
+    hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds, st, nullptr, ctx->next_stop, 0, args...);
+    ctx->next_stop = nullptr;
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  }
+}
 
 int vo_set_error(vo_ctx* ctx, int code, const char* fmt, ...);
 int vo_ensure(vo_ctx* ctx, vo_buf& b, size_t bytes);

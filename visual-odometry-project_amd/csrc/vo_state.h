@@ -79,6 +79,8 @@ struct vo_seq_ctl {
   int32_t best_idx, best_count, consumed, hyp_valid;
   int64_t n_done;
   int32_t n_cand, n_dropped, n_land, done;   // counters the bookkeeping kernels add to (zeroed by the replay kernel)
+  int32_t n_pend, pad_pend;                  // state_walk_landmarks_kernel: features whose cheirality verdict waits for the frame's
+                                             // candidate count (zeroed by the pose kernel)
   double best_pose[12];    // R (9, row-major) then t (3) of the accepted hypothesis
   double refined[16];      // refine_pose_kernel's output: R, t, accepted steps, cost (+ tag)
   // 3x4 row-major, world->camera and camera->world: State.curr_pose / State.prev_pose (state.py:9-15), and a
@@ -138,6 +140,8 @@ struct vo_pose_job {
   unsigned* seq_word;
   unsigned seq;
   int stamps;           // debug: device-clock stamps after the replay and after the refinement (record ts[6], ts[7])
+  int walk = 1;         // 0: the kernel stops behind the refinement; vo_state_candidates (a workgroup per 256 features) walks
+                        // the features, commits the pose and counts the candidates instead of this kernel's one workgroup
   int debug_fault_every; // test hook: every n-th step the replay raises VO_FAULT_FORCED where its loop ends (a fault from the
                         // POSE kernel, after the step's regroup has run and -- over several batches -- after the loop's
                         // state has moved: what a draw NumPy might have rejected does, about once in 10^3 steps)
@@ -156,10 +160,16 @@ int vo_state_regroup_pairs(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, c
                            const double* d_new_kp, int n2_in, int cap, const int32_t* d_M = nullptr,
                            const int32_t* d_n2 = nullptr, int32_t* d_src_row = nullptr);
 // main.py:261-268 + state.py:17-50, 135-219: pose, outliers, bearing-angle candidates
+// S > 1: sequence q uses block q of every array (mask rows of `words` 64-bit words)
 int vo_state_candidates(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, vo_cam cam,
-                        double bearing_thr, int use_refined, int cap);
+                        double bearing_thr, int use_refined, int cap, int S = 1, int words = 0);
 // main.py:279-286 + triangulation.py:38-86 + state.py:69-107: candidate triangulation, landmark insertion,
 // cheirality check, step bookkeeping and the result record
+// vo_state_candidates and vo_state_landmarks in ONE launch (the frame loop's form): a feature's walk, its triangulation and its
+// cheirality test need nothing of another feature but the frame's candidate count being > 0.  d_pend: S x cap int32 of scratch.
+int vo_state_walk_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, const uint64_t* d_best_mask, int words, vo_cam cam,
+                            double bearing_thr, int use_refined, int cap, int32_t* d_pend, vo_step_result* m_result,
+                            unsigned* m_seq, unsigned seq, int S);
 int vo_state_landmarks(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat B, vo_cam cam, int use_refined, int cap,
                        vo_step_result* m_result, unsigned* m_seq, unsigned seq, int S = 1);
 // n_iterations for an outlier ratio through the threshold table (host copy of the device lookup; tests)

@@ -176,6 +176,7 @@ _SIGS = {
     "vo_pipeline_set_frame_seq": (_i, [_vp, _i, _i, _vp]),
     "vo_pipeline_set_frame_pinned": (_i, [_vp, _i, _i, _vp]),
     "vo_pipeline_frame_uploaded": (_i, [_vp, _i, _i]),
+    "vo_pipeline_prepare": (_i, [_vp, _i]),
     "vo_host_alloc": (_i, [_vp, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vo_host_free": (_i, [_vp, _vp]),
     "vo_pipeline_set_state_seq": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),

@@ -97,6 +97,11 @@ class Pipeline:
         else:
             self.ctx._chk(self.ctx._lib.vo_pipeline_set_frame_seq(self._h, int(seq), int(idx), _ptr(img)))
 
+    def prepare(self, idx):
+        """Hint: frame slot idx is the `next` of the coming submit -- its pyramid is built now, off that step's critical
+        path (vo_pipeline_prepare).  Results do not depend on it."""
+        self.ctx._chk(self.ctx._lib.vo_pipeline_prepare(self._h, int(idx)))
+
     def frame_uploaded(self, idx, wait=False):
         rc = self.ctx._lib.vo_pipeline_frame_uploaded(self._h, int(idx), 1 if wait else 0)
         if rc < 0:

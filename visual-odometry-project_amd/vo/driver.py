@@ -189,6 +189,8 @@ def run_on_device(sequence: Sequence, max_frames: int = None, n_keypoints: int =
         if ahead is not None:
             put((slot + 2) % SLOTS, ahead)
         pipe.submit(slot, nxt)
+        if ahead is not None:
+            pipe.prepare((slot + 2) % SLOTS)            # its pyramid too, behind this step's tracker
         pending += 1
         slot = nxt
         seconds.append(time.perf_counter() - t0 - (t2 - t1))
