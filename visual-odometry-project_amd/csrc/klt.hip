@@ -867,8 +867,9 @@ __device__ __forceinline__ void klt_track16_body(pyr_t P, const float* __restric
   if (d_n) N = min(N, *d_n);                           // keypoint count read on the device (frame pipeline)
   int n_own = N;                                       // points 0 .. n_own-1 are prev_xy's, the rest the detector's
   if (src.ts && blockIdx.x == 0 && threadIdx.x == 0) *src.ts = wall_clock64();
+  const bool byp = src.gate_mode == 2 && src.gate_wait != nullptr;   // the regroup's outputs / this kernel's: agent-scope accesses
   if (src.n) {
-    n_own = *src.n;
+    n_own = byp ? vo_ld_agent(src.n) : *src.n;
     const bool redetect = (double)n_own < (double)*src.num_features * src.frac && (!src.det_go || *src.det_go != 0);
     N = min(N, n_own + (redetect ? src.n_det : 0));
   }
@@ -881,8 +882,17 @@ __device__ __forceinline__ void klt_track16_body(pyr_t P, const float* __restric
 
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
-  const float p0x = i < n_own ? prev_xy[2 * i] : (float)src.det_kp[2 * (i - n_own)];
-  const float p0y = i < n_own ? prev_xy[2 * i + 1] : (float)src.det_kp[2 * (i - n_own) + 1];
+  float p0x, p0y;
+  if (i >= n_own) {
+    p0x = (float)src.det_kp[2 * (i - n_own)];
+    p0y = (float)src.det_kp[2 * (i - n_own) + 1];
+  } else if (byp) {
+    p0x = vo_ld_agent(&prev_xy[2 * i]);
+    p0y = vo_ld_agent(&prev_xy[2 * i + 1]);
+  } else {
+    p0x = prev_xy[2 * i];
+    p0y = prev_xy[2 * i + 1];
+  }
   bool ok = true;
   float e_out = 0.f;
   float nx = 0.f, ny = 0.f;
@@ -1098,10 +1108,17 @@ __device__ __forceinline__ void klt_track16_body(pyr_t P, const float* __restric
     }
   }
   if (r == 0) {
-    next_xy[2 * i] = nx;
-    next_xy[2 * i + 1] = ny;
-    status[i] = ok ? 1 : 0;
-    err[i] = e_out;
+    if (byp) {
+      vo_st_agent(&next_xy[2 * i], nx);
+      vo_st_agent(&next_xy[2 * i + 1], ny);
+      vo_st_agent(&status[i], (uint8_t)(ok ? 1 : 0));
+      vo_st_agent(&err[i], e_out);
+    } else {
+      next_xy[2 * i] = nx;
+      next_xy[2 * i + 1] = ny;
+      status[i] = ok ? 1 : 0;
+      err[i] = e_out;
+    }
   }
 }
 
@@ -1115,15 +1132,17 @@ __global__ __launch_bounds__(64) void klt_track16_kernel(pyr_t P, const float* _
   const size_t coff = (size_t)blockIdx.y * B.ctl;
   if (src.gate_wait && src.gate_want) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(src.gate_wait) + coff);
-    if (!vo_gate_wait(w, src.gate_want) && threadIdx.x == 0 && src.gate_fault)
+    if (!vo_gate_wait(w, src.gate_want, src.gate_mode != 2) && threadIdx.x == 0 && src.gate_fault)
       atomicOr(reinterpret_cast<int*>(reinterpret_cast<char*>(src.gate_fault) + coff), (int)VO_FAULT_GATE_BIT);
   }
   klt_track16_body<WIN, LPK>(P, prev_xy, N, d_n, src, B, max_iter, eps2, min_eig_thr, next_xy, status, err);
   if (src.gate_set) {
-    __threadfence();
+    if (src.gate_mode == 2) vo_stores_done();          // (one wave per workgroup)
+    else __threadfence();
     if (threadIdx.x == 0)
       vo_gate_arrive(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(src.gate_cnt) + coff), gridDim.x,
-                     reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(src.gate_set) + coff), src.gate_set_to);
+                     reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(src.gate_set) + coff), src.gate_set_to,
+                     src.gate_mode != 2);
   }
 }
 

@@ -148,6 +148,7 @@ struct vo_pipeline {
   // that a polling kernel can never keep the kernel it waits for from running.  After anything was enqueued again for
   // one sequence (host path, a continuing RANSAC loop, a rewind) the next submit also waits for the events.
   bool gates = false, gate_resync = false;
+  int gate_mode = 1;                 // vo_internal.h, vo_gate_wait
   bool ext_events = true;            // see enqueue_tracker
   int sift_chain_pending = 0;        // SIFT mode: flights whose main-stream chain is not enqueued yet (their SIFT launches are
                                      // being made by the worker; the chain follows at the next submit or at collect)
@@ -492,7 +493,8 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
       // pose kernels running beside them lose their cached population over and over (hypotheses -> pose 23 -> 40 us,
       // pose 34 -> 45, step 103 -> 133 us).  The gates would need the gated data to bypass L2 altogether.
       p->ext_events = !(getenv("VO_EXT_EVENTS") && getenv("VO_EXT_EVENTS")[0] == '0');
-      p->gates = sc != nullptr && p->S <= 2 && !side && (w == 15 || w == 17 || w == 21) && g && g[0] == '1';
+      p->gates = sc != nullptr && p->S <= 2 && !side && (w == 15 || w == 17 || w == 21) && g && (g[0] == '1' || g[0] == '2');
+      p->gate_mode = g && g[0] == '2' ? 2 : 1;
     }
     const char* saved_c = getenv("VO_STREAM_CUS");
     std::string keep_c = saved_c ? saved_c : "";
@@ -912,6 +914,7 @@ static int enqueue_tracker(vo_pipeline* p, const vo_pipeline::flight_t& f, bool 
     src.gate_cnt = &ctl->gate_klt_cnt;
     src.gate_set_to = (uint32_t)f.k + 1u;
     src.gate_fault = &ctl->fault;
+    src.gate_mode = p->gate_mode;
   }
   vo_klt_batch kb;
   kb.S = Sn;
@@ -957,6 +960,7 @@ static int enqueue_chain(vo_pipeline* p, const vo_pipeline::flight_t& f, bool fi
   vo_append ap;
   ap.gate_klt_want = gated ? (uint32_t)f.k + 1u : 0u;
   ap.gate_regroup_set = gated ? (uint32_t)f.k + 1u : 0u;
+  ap.gate_mode = p->gate_mode;
   ap.det_kp = p->kp(q0, f.a);
   ap.det_stride = p->det_stride();
   ap.n_det = c.n_keypoints;

@@ -389,6 +389,9 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   __shared__ int s_state, s_cand[RF_T / 64];
   __shared__ int s_list[TAIL_LIST];
   __shared__ int s_nc, s_tail[2];
+  constexpr int MASK_LDS = 256;        // mask words the replay hands over in LDS (16384 correspondences)
+  __shared__ unsigned long long s_mask[MASK_LDS];
+  __shared__ int s_mask_ok;
   if (blockIdx.x != 0) {               // several sequences per launch: one workgroup per sequence
     const size_t q = blockIdx.x;
     job.ctl += q;
@@ -406,6 +409,8 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   }
   vo_seq_ctl* ctl = job.ctl;
   if (threadIdx.x == 0) ctl->ts[3] = wall_clock64();
+  replay_head head;                    // (requested with the fault word below: one round trip for both)
+  if (job.do_replay && (threadIdx.x >> 6) == 0) head = replay_prefetch(ctl);
   {
     // a fault of an earlier step (sticky) or of this step's regroup, which leaves "few landmarks" in its own word
     const int entry_fault = ctl->fault | (job.do_replay ? ctl->few : 0);
@@ -433,9 +438,14 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   rf_point cache[RF_PT];
 #pragma unroll
   for (int k = 0; k < RF_PT; ++k) cache[k] = load_point(X, x, cap, nullptr, nullptr, k * RF_T + tid);
-  if (tid == 0) s_state = 0;
+  if (tid == 0) {
+    s_state = 0;
+    s_mask_ok = 0;
+  }
   __syncthreads();
-  if (job.do_replay && wv == 0) replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table, first, true, job.debug_fault_every);
+  if (job.do_replay && wv == 0)
+    replay_wave(ctl, job.rp, lane, lds_table ? s_table : job.rp.table, first, true, job.debug_fault_every, &head, s_pose, s_mask,
+                MASK_LDS, &s_mask_ok);
   __syncthreads();
   if (tid == 0 && job.stamps) ctl->ts[5] = wall_clock64();
   if (ctl->fault) {                             // (raised by the replay: the host finishes this step)
@@ -447,13 +457,17 @@ __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   }
   const int N = min(ctl->n_p3p, cap);
   const unsigned long long* mask_bits = job.rp.best_mask;
+  // the replay left the accepted pose and its mask row in LDS (s_pose, s_mask) -- the host path (do_replay = 0) in memory
+  const bool from_lds = job.do_replay && s_mask_ok != 0;
 #pragma unroll
   for (int k = 0; k < RF_PT; ++k) {
     const int i = k * RF_T + tid;
-    cache[k].on = i < N && ((mask_bits[min(i, cap - 1) >> 6] >> (i & 63)) & 1ull) != 0;
+    const int w = min(i, cap - 1) >> 6;
+    const unsigned long long word = from_lds ? s_mask[min(w, MASK_LDS - 1)] : mask_bits[w];
+    cache[k].on = i < N && ((word >> (i & 63)) & 1ull) != 0;
   }
   if (tid < 12) {
-    const double v = ctl->best_pose[tid];
+    const double v = job.do_replay ? s_pose[tid] : ctl->best_pose[tid];
     s_pose[tid] = v;
     s_try[tid] = v;
   }

@@ -206,12 +206,19 @@ __global__ __launch_bounds__(RG_T) void state_regroup_kernel(vo_seq_ctl* __restr
 
 
 // (the body of state_regroup_klt_kernel: it returns early on several paths, the kernel's gates sit around it)
+template <bool BYP>
 __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, vo_feat A, vo_feat B,
                                                  const float* __restrict__ next_xy, const uint8_t* __restrict__ status,
                                                  const float* __restrict__ err, float err_thr, vo_append ap, int cap,
                                                  unsigned long long (&s_red)[2][4], int (&s_wcnt)[3][4]) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int RG_U = 16;
+  // gate form 2 (vo_internal.h): the tracker's outputs are read, the positions and the count the next tracker reads are written
+  // with agent-scope accesses
+  constexpr bool byp = BYP;    // (a template parameter: as a run-time flag it cost the ungated kernel 1.7 us -- its sixteen-at-a-time
+                               //  loads no longer went out together)
+  auto ld_status = [&](int j) -> int { return byp ? (int)vo_ld_agent(&status[j]) : (int)status[j]; };
+  auto ld_err = [&](int j) -> float { return byp ? vo_ld_agent(&err[j]) : err[j]; };
   const int start = blockIdx.x * 256;
   const int entry_fault = ctl->fault;
   int fault = entry_fault;
@@ -245,13 +252,14 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
 #pragma unroll
   for (int u = 0; u < RG_U; ++u) {
     const int j = u * 256 + tid;
-    r_s8[u] = status[min(j, capm)];
-    r_e[u] = err[min(j, capm)];
+    r_s8[u] = ld_status(min(j, capm));
+    r_e[u] = ld_err(min(j, capm));
     r_st[u] = A.state[min(j, pitm)];
   }
   const int jo = start + tid, jq = min(jo, pitm), jx = min(jo, capm);
   double o_land[3], o_track[2], o_kp[2], o_pose[12];
-  const float o_nx = next_xy[2 * jx], o_ny = next_xy[2 * jx + 1];
+  const float o_nx = byp ? vo_ld_agent(&next_xy[2 * jx]) : next_xy[2 * jx];
+  const float o_ny = byp ? vo_ld_agent(&next_xy[2 * jx + 1]) : next_xy[2 * jx + 1];
 #pragma unroll
   for (int k = 0; k < 3; ++k) o_land[k] = A.land[3 * jq + k];
 #pragma unroll
@@ -265,8 +273,8 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
     // (unconditional loads at clamped indices, no short-circuit: the three requests of an item, and those of the
     //  following items, go out together instead of one dependent round trip after the other)
     const int jc = min(j, n_in - 1), js = min(j, max(n - 1, 0));
-    const int s8 = status[jc];
-    const float e = err[jc];
+    const int s8 = ld_status(jc);
+    const float e = ld_err(jc);
     const int st_raw = A.state[js];
     const int keep = (int)(j < n_in) & (int)(s8 != 0) & (int)(e < err_thr);
     const int st = j < n ? st_raw : 0;
@@ -331,8 +339,13 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
     if (j < n) {
       // (write_group, from the registers filled above)
       const double nan = dnan();
-      B.kp[2 * dst] = (float)x;
-      B.kp[2 * dst + 1] = (float)y;
+      if (byp) {
+        vo_st_agent(&B.kp[2 * dst], (float)x);
+        vo_st_agent(&B.kp[2 * dst + 1], (float)y);
+      } else {
+        B.kp[2 * dst] = (float)x;
+        B.kp[2 * dst + 1] = (float)y;
+      }
       B.kp64[2 * dst] = x;
       B.kp64[2 * dst + 1] = y;
       B.cand[dst] = 0;
@@ -354,8 +367,13 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
     } else {
       // a keypoint the detector found on the old frame, tracked: "newly matched" (matches.py:62-110)
       const int d = j - n;
-      B.kp[2 * dst] = (float)x;
-      B.kp[2 * dst + 1] = (float)y;
+      if (byp) {
+        vo_st_agent(&B.kp[2 * dst], (float)x);
+        vo_st_agent(&B.kp[2 * dst + 1], (float)y);
+      } else {
+        B.kp[2 * dst] = (float)x;
+        B.kp[2 * dst + 1] = (float)y;
+      }
       B.kp64[2 * dst] = x;
       B.kp64[2 * dst + 1] = y;
       B.cand[dst] = 0;
@@ -372,7 +390,8 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
     ctl->n_in = n_in;
     ctl->redetected = redetect ? 1 : 0;
     ctl->det_ran = ap.det_go ? ap.det_go[blockIdx.y] : 1;
-    ctl->n2 = T0 + T1 + T2;
+    if (byp) vo_st_agent(&ctl->n2, T0 + T1 + T2);
+    else ctl->n2 = T0 + T1 + T2;
     ctl->n_tri = T0;
     ctl->n_mat = T1;
     ctl->n_new = T2;
@@ -391,6 +410,7 @@ __device__ __forceinline__ void regroup_klt_body(vo_seq_ctl* __restrict__ ctl, v
 // copy: when fewer than frac * _num_features features are left, items n .. n + n_det - 1 ARE the detector's
 // keypoints of the old frame (state 0, landmark NaN, track start = the keypoint, start pose np.eye(4)) -- the
 // tracker kernel read its points the same way (vo_klt_source).
+template <bool BYP>
 __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __restrict__ ctl, vo_feat A, vo_feat B,
                                                                 const float* __restrict__ next_xy,
                                                                 const uint8_t* __restrict__ status,
@@ -411,18 +431,23 @@ __global__ __launch_bounds__(256) void state_regroup_klt_kernel(vo_seq_ctl* __re
   }
   // device-side gate: this flight's tracker has published its end (instead of a stream event; vo_seq_ctl)
   if (ap.gate_klt_want) {
-    if (!vo_gate_wait(&ctl->gate_klt, ap.gate_klt_want) && tid == 0) atomicOr(&ctl->fault, (int)VO_FAULT_GATE);
+    if (!vo_gate_wait(&ctl->gate_klt, ap.gate_klt_want, ap.gate_mode != 2) && tid == 0) atomicOr(&ctl->fault, (int)VO_FAULT_GATE);
     __syncthreads();
   }
   if (blockIdx.x == 0 && tid == 0) {
     ctl->ts[1] = wall_clock64();
     ctl->ts[6] = ctl->ts[0];          // this step's tracker start (the next step's tracker overwrites ts[0] meanwhile)
   }
-  regroup_klt_body(ctl, A, B, next_xy, status, err, err_thr, ap, cap, s_red, s_wcnt);
+  regroup_klt_body<BYP>(ctl, A, B, next_xy, status, err, err_thr, ap, cap, s_red, s_wcnt);
   if (ap.gate_regroup_set) {          // every workgroup arrives, whatever it did: the last one opens the tracker's gate
-    __syncthreads();
-    __threadfence();
-    if (tid == 0) vo_gate_arrive(&ctl->gate_regroup_cnt, gridDim.x, &ctl->gate_regroup, ap.gate_regroup_set);
+    if (ap.gate_mode == 2) {
+      vo_stores_done();
+      __syncthreads();
+    } else {
+      __syncthreads();
+      __threadfence();
+    }
+    if (tid == 0) vo_gate_arrive(&ctl->gate_regroup_cnt, gridDim.x, &ctl->gate_regroup, ap.gate_regroup_set, ap.gate_mode != 2);
   }
 }
 
@@ -627,19 +652,58 @@ __global__ __launch_bounds__(256) void state_walk_landmarks_kernel(vo_seq_ctl* _
   int cand = 0, st = 0;
   double X[3] = {0.0, 0.0, 0.0};
   if (i < n2) {
+    // Everything the feature's walk, triangulation and test read, requested together: ONE round trip.  (candidate_feature
+    // followed by the triangulation as state_landmarks_kernel has it reads the start pose twice, the second time behind the
+    // walk's stores: two more dependent round trips on the step's chain.)
+    const int st0 = B.state[i];
+    const double u = B.kp64[2 * i], v = B.kp64[2 * i + 1];
+    double Ts[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) Ts[q] = B.pose[(size_t)q * B.pitch + i];
+    const double ta = B.track[2 * i], tb = B.track[2 * i + 1];
     X[0] = B.land[3 * i];
     X[1] = B.land[3 * i + 1];
     X[2] = B.land[3 * i + 2];
-    cand = candidate_feature(B, i, n_tri, best_mask, cam, Twc, bearing_thr, &st);
+    const bool p3p_out = i < n_tri && !((best_mask[i >> 6] >> (i & 63)) & 1ull);
+    // ---- candidate_feature (state_device.h), from the registers: main.py:261-268 ----
+    st = st0;
+    bool reset = st0 == 0;
+    if (p3p_out) {                     // P3P outlier (main.py:261-262)
+      st = 0;
+      reset = true;
+    }
+    if (reset) {
+      if (st0 != 0) {
+        B.track[2 * i] = u;
+        B.track[2 * i + 1] = v;
+        B.state[i] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) B.pose[(size_t)k * B.pitch + i] = Twc[k];
+      st = 0;
+    } else if (st == 1) {
+      const double* Ki = cam.Kinv;
+      const double n1x = Ki[0] * ta + Ki[1] * tb + Ki[2], n1y = Ki[3] * ta + Ki[4] * tb + Ki[5],
+                   n1z = Ki[6] * ta + Ki[7] * tb + Ki[8];
+      const double n2x = Ki[0] * u + Ki[1] * v + Ki[2], n2y = Ki[3] * u + Ki[4] * v + Ki[5],
+                   n2z = Ki[6] * u + Ki[7] * v + Ki[8];
+      const double r1x = Ts[0] * n1x + Ts[1] * n1y + Ts[2] * n1z, r1y = Ts[4] * n1x + Ts[5] * n1y + Ts[6] * n1z,
+                   r1z = Ts[8] * n1x + Ts[9] * n1y + Ts[10] * n1z;
+      const double r2x = Twc[0] * n2x + Twc[1] * n2y + Twc[2] * n2z, r2y = Twc[4] * n2x + Twc[5] * n2y + Twc[6] * n2z,
+                   r2z = Twc[8] * n2x + Twc[9] * n2y + Twc[10] * n2z;
+      const double dot = r1x * r2x + r1y * r2y + r1z * r2z;
+      const double l1 = sqrt(r1x * r1x + r1y * r1y + r1z * r1z), l2 = sqrt(r2x * r2x + r2y * r2y + r2z * r2z);
+      const double ang = acos(dot / (l1 * l2));
+      cand = ang >= bearing_thr ? 1 : 0;                      // (NaN compares false, as in NumPy)
+    }
+    B.cand[i] = (uint8_t)cand;
     if (cand) {
       // proj1 = K inv(pose_start)[:3], proj2 = K inv(current_pose)[:3] (triangulation.py:53-57)
-      double Ts[12], Ti[12], C1[12], C2[12];
-#pragma unroll
-      for (int q = 0; q < 12; ++q) Ts[q] = B.pose[(size_t)q * B.pitch + i];
+      double Ti[12], C1[12], C2[12];
       rigid_inverse_3x4(Ts, Ti);
       k_times(cam.K, Ti, C1);
       k_times(cam.K, Tcw, C2);
-      vo_dlt::triangulate_point(C1, B.track[2 * i], B.track[2 * i + 1], C2, B.kp64[2 * i], B.kp64[2 * i + 1], X);
+      vo_dlt::triangulate_point(C1, ta, tb, C2, u, v, X);
       B.land[3 * i] = X[0];
       B.land[3 * i + 1] = X[1];
       B.land[3 * i + 2] = X[2];
@@ -736,8 +800,12 @@ int vo_state_regroup_klt(vo_ctx* ctx, vo_seq_ctl* ctl, vo_feat A, vo_feat B, con
                          const uint8_t* d_status, const float* d_err, float err_thr, vo_append ap, int cap, int S) {
   {
     vo_prof_scope ps(ctx, VO_K_STATE_REGROUP);
-    vo_launch_stop(ctx, state_regroup_klt_kernel, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, A, B, d_next_xy,
-                   d_status, d_err, err_thr, ap, cap);
+    if (ap.gate_mode == 2 && ap.gate_klt_want != 0u)
+      vo_launch_stop(ctx, state_regroup_klt_kernel<true>, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, A, B,
+                     d_next_xy, d_status, d_err, err_thr, ap, cap);
+    else
+      vo_launch_stop(ctx, state_regroup_klt_kernel<false>, dim3(vo_cdiv(cap, 256), S), dim3(256), 0, ctx->stream, ctl, A, B,
+                     d_next_xy, d_status, d_err, err_thr, ap, cap);
   }
   return vo_check_launch(ctx, "state_regroup_klt_kernel");
 }

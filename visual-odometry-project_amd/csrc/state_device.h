@@ -80,26 +80,53 @@ __device__ __forceinline__ void replay_fetch(const replay_args& a, int lane, int
   }
 }
 
+// the control-block fields the replay starts from, requested together (by the pose kernel in front of its first barrier:
+// read inside replay_wave they were one more dependent round trip at the head of the step's longest kernel)
+struct replay_head {
+  int n_p3p, cont, consumed, best_idx, best_count, hyp_valid, step;
+  long long n_iterations, n_done;
+  double outlier_ratio;
+};
+__device__ __forceinline__ replay_head replay_prefetch(const vo_seq_ctl* __restrict__ ctl) {
+  replay_head h;
+  h.n_p3p = ctl->n_p3p;
+  h.cont = ctl->cont;
+  h.consumed = ctl->consumed;
+  h.best_idx = ctl->best_idx;
+  h.best_count = ctl->best_count;
+  h.hyp_valid = ctl->hyp_valid;
+  h.step = ctl->step;
+  h.n_iterations = ctl->n_iterations;
+  h.n_done = ctl->n_done;
+  h.outlier_ratio = ctl->outlier_ratio;
+  return h;
+}
+
 // ch: working storage; fetched0: it already holds the chunk of sbase = 0 (the pose kernel requests it in front of its
 // staging of the table and the coordinates, so that the replay does not start with a memory round trip of its own)
+// s_best (12 doubles) / s_mask (s_mask_words words), optional, LDS: the accepted pose and its mask row are left there as well
+// (the refinement behind the caller's barrier starts from them without a trip through memory); *s_mask_ok = 1 when s_mask holds the row
 __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const replay_args& a, int lane,
-                                            const double* tb, replay_chunk& ch, bool fetched0, int debug_fault_every = 0) {
+                                            const double* tb, replay_chunk& ch, bool fetched0, int debug_fault_every = 0,
+                                            const replay_head* head = nullptr, double* s_best = nullptr,
+                                            unsigned long long* s_mask = nullptr, int s_mask_words = 0, int* s_mask_ok = nullptr) {
   if (lane == 0) {            // counters the bookkeeping kernels of this step add to
     ctl->n_cand = 0;
     ctl->n_dropped = 0;
     ctl->n_land = 0;
     ctl->done = 0;
   }
+  const replay_head hd = head ? *head : replay_prefetch(ctl);
   const int hyp = a.hyp;
-  const int N = ctl->n_p3p;
-  long long n_it = ctl->n_iterations;
-  double orat = ctl->outlier_ratio;
+  const int N = hd.n_p3p;
+  long long n_it = hd.n_iterations;
+  double orat = hd.outlier_ratio;
   // cont > 0: the loop has walked `cont` batches of `hyp` samples already (VO_FAULT_CONTINUE) and goes on where it stopped
-  const int cont = ctl->cont;
-  const int consumed_before = cont ? ctl->consumed : 0;
-  const int best_idx_before = cont ? ctl->best_idx : -1;
-  long long n = cont ? ctl->n_done : 0;
-  int best = cont ? ctl->best_count : -1, best_idx = -1, consumed = -1, hyp_valid = cont ? ctl->hyp_valid : 0;
+  const int cont = hd.cont;
+  const int consumed_before = cont ? hd.consumed : 0;
+  const int best_idx_before = cont ? hd.best_idx : -1;
+  long long n = cont ? hd.n_done : 0;
+  int best = cont ? hd.best_count : -1, best_idx = -1, consumed = -1, hyp_valid = cont ? hd.hyp_valid : 0;
   if (!cont && lane == 0) {
     ctl->n_iterations0 = n_it;
     ctl->outlier_ratio0 = orat;
@@ -164,7 +191,7 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
     else more = true;
   }
   if (risky_seen) fault |= VO_FAULT_RISKY_DRAW;
-  if (debug_fault_every > 0 && !more && (ctl->step % debug_fault_every) == debug_fault_every - 1) fault |= VO_FAULT_FORCED;
+  if (debug_fault_every > 0 && !more && (hd.step % debug_fault_every) == debug_fault_every - 1) fault |= VO_FAULT_FORCED;
   // a bound beyond the table (an unbounded max_iterations and a ratio whose bound the table does not hold): the host's loop
   if (!fault && more && n_it == 0x7fffffffffffffffll) fault |= VO_FAULT_UNFINISHED;
   if (!fault && !more && best_idx < 0 && best_idx_before < 0) fault |= VO_FAULT_UNFINISHED;   // (no hypothesis had a solution)
@@ -175,12 +202,26 @@ __device__ __forceinline__ void replay_wave(vo_seq_ctl* __restrict__ ctl, const 
     }
     return;
   }
+  const int wn = (N + 63) >> 6;
+  const bool lds_mask = s_mask != nullptr && wn <= s_mask_words;
   if (best_idx >= 0) {                            // the best so far lives in this batch: its pose and mask row
-    if (lane < 9) ctl->best_pose[lane] = a.R[9 * best_idx + lane];
-    if (lane < 3) ctl->best_pose[9 + lane] = a.t[3 * best_idx + lane];
-    const int wn = (N + 63) >> 6;
-    for (int w = lane; w < wn; w += 64) a.best_mask[w] = a.masks[(size_t)best_idx * a.words + w];
+    double pv = 0.0;
+    if (lane < 12) {
+      pv = lane < 9 ? a.R[9 * best_idx + lane] : a.t[3 * best_idx + (lane - 9)];
+      ctl->best_pose[lane] = pv;
+      if (s_best) s_best[lane] = pv;
+    }
+    for (int w = lane; w < wn; w += 64) {
+      const unsigned long long m = a.masks[(size_t)best_idx * a.words + w];
+      a.best_mask[w] = m;
+      if (lds_mask) s_mask[w] = m;
+    }
+  } else if (!more) {                             // (it was found by an earlier batch of this step: from the control block)
+    if (s_best && lane < 12) s_best[lane] = ctl->best_pose[lane];
+    if (lds_mask)
+      for (int w = lane; w < wn; w += 64) s_mask[w] = a.best_mask[w];
   }
+  if (s_mask_ok && lane == 0) *s_mask_ok = lds_mask ? 1 : 0;
   if (lane == 0) {
     if (more) consumed = hyp;
     ctl->n_iterations = n_it;

@@ -136,26 +136,51 @@ struct vo_cam2 {      // the two intrinsic matrices of the two-view bootstrap (b
 
 // ---- device-side gates between kernels of different streams (vo_seq_ctl's gate words; pipeline.hip) ----
 constexpr int VO_FAULT_GATE_BIT = 128;      // = VO_FAULT_GATE (vo_state.h)
-// poll `word` until it reaches `want` (agent scope, acquire); false after ~2 s of device clock
-__device__ __forceinline__ bool vo_gate_wait(const uint32_t* word, uint32_t want) {
+// Two forms (gate_mode).  1: the data handed over are ordinary loads and stores, the waiting side makes an acquire fence at
+// agent scope when its word is there, the arriving side a release fence before it arrives -- on this part an invalidate /
+// a write-back of the XCD's L2, per workgroup (measured: the kernels running beside the tracker's ~1000 workgroups lose
+// their cached population over and over, step 103 -> 133 us).  2: no fences at all -- the handed-over arrays themselves are
+// written and read with agent-scope accesses (vo_st_agent / vo_ld_agent: sc1, coherent across the XCDs' L2s one access at
+// a time), the arriving side only waits for its own stores to be acknowledged (s_waitcnt) before it counts itself in.
+template <class T>
+__device__ __forceinline__ T vo_ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ void vo_st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// poll `word` until it reaches `want` (agent scope; acquire: form 1); false after ~2 s of device clock
+__device__ __forceinline__ bool vo_gate_wait(const uint32_t* word, uint32_t want, bool acquire = true) {
   const unsigned long long t0 = wall_clock64();
   // (relaxed polls, ONE acquire when the word is there: an acquire at agent scope invalidates the L2 of this XCD)
   while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
     __builtin_amdgcn_s_sleep(8);
     if (wall_clock64() - t0 > 200000000ull) return false;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // (the compiler keeps what follows behind the poll)
   return true;
 }
 
-// one arrival per workgroup (call from ONE work item after the workgroup's stores and a __threadfence()); the last of
-// `total` publishes `epoch` and resets the counter
-__device__ __forceinline__ void vo_gate_arrive(uint32_t* cnt, uint32_t total, uint32_t* word, uint32_t epoch) {
-  const uint32_t prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-  if (prev + 1u == total) {
-    __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+// one arrival per workgroup (call from ONE work item after the workgroup's stores and a __threadfence() -- form 2: after
+// vo_stores_done() in every wave and a barrier); the last of `total` publishes `epoch` and resets the counter
+__device__ __forceinline__ void vo_gate_arrive(uint32_t* cnt, uint32_t total, uint32_t* word, uint32_t epoch, bool fenced = true) {
+  if (fenced) {
+    const uint32_t prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == total) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(word, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    const uint32_t prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == total) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+}
+// form 2: this wave's stores have been acknowledged (vmcnt / lgkmcnt / expcnt all 0), nothing moves across for the compiler
+__device__ __forceinline__ void vo_stores_done() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
 // ---- internal entry points shared between translation units (not part of the C ABI) ----
@@ -208,6 +233,7 @@ struct vo_klt_source {
   uint32_t* gate_cnt = nullptr;
   uint32_t gate_set_to = 0;
   int32_t* gate_fault = nullptr;      // receives VO_FAULT_GATE when the wait times out
+  int gate_mode = 1;                  // 1 fences, 2 agent-scope accesses to the handed-over arrays (see vo_gate_wait)
 };
 // several sequences per launch (grid.y = sequence): element strides from one sequence's block to the next
 struct vo_klt_batch {

@@ -107,6 +107,7 @@ struct vo_append {
   const int* det_go;        // per sequence: 1 = the detector ran on the frame det_kp belongs to (NULL: it always does)
   uint32_t gate_klt_want;   // != 0: wait until ctl->gate_klt reaches it (the tracker of this flight is done) ...
   uint32_t gate_regroup_set; // ... and publish ctl->gate_regroup = this when every workgroup has written
+  int gate_mode;            // 1 fences, 2 agent-scope accesses to the handed-over arrays (vo_internal.h, vo_gate_wait)
 };
 
 struct vo_replay_args {
