@@ -127,6 +127,39 @@ def test_pipeline_matches_oracle_loop(ctx, H, W, N, hyp, frac, redetect, pose_fa
     pipe.close()
 
 
+def test_landmarks_behind_the_camera_are_dropped_whichever_workgroup_holds_them(ctx):
+    """_check_landmarks (state.py:90-107) runs only on a frame that has candidates, for ALL landmarks.  The loop's walk +
+    landmark kernel learns the frame's candidate count only when its last workgroup arrives: a workgroup without a
+    candidate of its own -- the first ones hold triangulated features only -- leaves its verdicts pending for that last
+    one.  Landmarks mirrored behind the camera among the first 256 features (and further back) must come out as in the
+    oracle: dropped on the first frame that has candidates, counts and arrays equal."""
+    from vo import synthetic
+    H, W, N, hyp = 480, 640, 600, 256
+    stream = synthetic.Stream(6, H, W)
+    feats, T = start_state(stream, N)
+    n_tri = int((feats.state == 2).sum())
+    assert n_tri > 300, "the first workgroup of 256 features must hold triangulated features only"
+    Tcw = np.linalg.inv(T)
+    for i in (3, 50, 120, 200, 255, 256, 300, n_tri - 1):
+        Xc = Tcw[:3, :3] @ feats.landmarks[i, :, 0] + Tcw[:3, 3]
+        feats.landmarks[i, :, 0] = T[:3, :3] @ (-Xc) + T[:3, 3]      # same ray, behind the camera
+    pipe = make_pipe(ctx, stream, N, hyp)
+    pipe.set_state(0, feats, T, T)
+    orc = OracleLoop(stream, N, 15, 2, refine_iters=20)
+    orc.set_state(0, feats, T, T)
+    dropped = with_candidates = 0
+    for a, b in ((0, 3), (3, 4), (4, 5)):          # (a long first baseline: the matched tracks become candidates at once)
+        ref = orc.step(b)
+        r = pipe.step(a, b)
+        check_step(r, ref, pipe, orc.rs.rng)
+        dropped += r.n_dropped
+        with_candidates += 1 if r.n_candidates > 0 else 0
+        if r.n_candidates == 0:
+            assert r.n_dropped == 0
+    assert with_candidates >= 1 and dropped >= 8, (with_candidates, dropped)
+    pipe.close()
+
+
 def run_all(pipe, pairs, lookahead):
     out = []
     if lookahead:
