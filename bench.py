@@ -94,20 +94,23 @@ def algorithmic_bytes(kernel_name, n_in, n_tracked, n_tri):
         "state_candidates": n_tracked * (16 + 1 + 16 + 96 + 1) + ((n_tri + 63) // 64) * 8,
         "state_landmarks": n_tracked * (1 + 1 + 24 + 16 + 96 + 24),
     }
-    # the frame loop's pose kernel (kernel id "refine_pose"): replay + refinement + candidates + landmark stage in one launch
-    table["refine_pose"] = table["ransac_replay"] + table["refine_pose"] + table["state_candidates"] + table["state_landmarks"]
+    # the frame loop's pose kernel (kernel id "refine_pose"): replay + refinement in one launch of one workgroup; its walk
+    # (candidates) and the landmark stage in one launch of cap / 256 workgroups (kernel id "state_landmarks")
+    table["refine_pose"] = table["ransac_replay"] + table["refine_pose"]
+    table["state_landmarks"] = table["state_candidates"] + table["state_landmarks"]
     return table.get(kernel_name)
 
 
-KERNEL_LABEL = {"refine_pose": "frame_pose (RANSAC replay + pose refinement + State bookkeeping + candidate DLT + record, one workgroup)",
+KERNEL_LABEL = {"refine_pose": "frame_pose (RANSAC replay + pose refinement, one workgroup)",
+                "state_landmarks": "state_walk_landmarks (State bookkeeping of every feature + candidate DLT + cheirality + record)",
                 "p3p_solve": "p3p_hyp (P3P solve + inlier counts of all hypotheses)"}
 ROCPROF_NAMES = {"klt_track": "klt_track16_kernel<15, 16>", "nms_round": "nms_round_kernel<5, true>",
                  "nms_candidates": "nms_candidates_kernel<5>", "harris_response": "harris_response_kernel<9>",
-                 "p3p_solve": "p3p_hyp_kernel<8>", "p3p_score": "p3p_score_kernel", "nms_compact": "nms_compact_kernel",
+                 "p3p_solve": "p3p_hyp_kernel<4>", "p3p_score": "p3p_score_kernel", "nms_compact": "nms_compact_kernel",
                  "nms_rank": "nms_rank_kernel", "nms_select": "nms_finalize_kernel", "refine_pose": "frame_pose_kernel",
-                 "pyr_down": "pyramid3_tiled_kernel<32, 16>", "state_regroup": "state_regroup_klt_kernel",
+                 "pyr_down": "pyramid3_tiled_kernel<32, 16>", "state_regroup": "state_regroup_klt_kernel<false>",
                  "ransac_replay": "ransac_replay_kernel", "state_candidates": "state_candidates_kernel",
-                 "state_landmarks": "state_landmarks_kernel"}
+                 "state_landmarks": "state_walk_landmarks_kernel"}
 
 
 def pmc_traffic(kernel_name):
