@@ -881,6 +881,7 @@ def main():
             if pipe is not None:
                 pipe.close()
                 pipe = None
+            _native.release_cached()         # (and the closed pipeline's masked side streams gone, not kept for a next one)
             out["api"] = api_leg(ctx)
             try:
                 if S == 1:

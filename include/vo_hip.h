@@ -430,6 +430,10 @@ void vo_record_seal(vo_step_result* rec, unsigned seq);
 int vo_record_check(const vo_step_result* rec, unsigned seq);
 int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out);
 void vo_pipeline_destroy(vo_pipeline* p);
+/* A closed pipeline's two side streams and their workspace are kept for the next pipeline of the same configuration (creating
+ * and destroying them per pipeline stalled inside the runtime about once in 400 cycles); this destroys what is kept.  Nothing in
+ * the reference corresponds to it (its objects are garbage-collected).                                                      */
+void vo_pipeline_release_cached(void);
 /* frame store: copies a host image into slot idx of the frame store.  The caller's buffer is free on return (it is
  * copied into a pinned staging buffer of that slot); the transfer itself is queued in front of the pyramid that reads
  * the slot and the call does not wait for it.  A slot that a step in flight reads is refused (VO_EINVAL), and so is the

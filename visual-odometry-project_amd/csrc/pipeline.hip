@@ -33,6 +33,7 @@
 #include <chrono>
 #include <cmath>
 #include <string>
+#include <mutex>
 #include <thread>
 
 #include "vo_state.h"
@@ -147,6 +148,7 @@ struct vo_pipeline {
   // the launches of vo_pipeline_submit when the side streams keep off some compute units (one or two sequences), so
   // that a polling kernel can never keep the kernel it waits for from running.  After anything was enqueued again for
   // one sequence (host path, a continuing RANSAC loop, a rewind) the next submit also waits for the events.
+  std::string det_key, trk_key;      // what the side contexts' streams were created with (side_pool)
   bool gates = false, gate_resync = false;
   int gate_mode = 1;                 // vo_internal.h, vo_gate_wait
   bool ext_events = true;            // see enqueue_tracker
@@ -361,6 +363,92 @@ void sync_prof(vo_pipeline* p) {
 
 }  // namespace
 
+// ---- side contexts (the tracker's and the detector's stream + workspace) are kept, not destroyed ----
+// Destroying a pipeline's side streams after every pipeline and creating the next one's hung inside the runtime about once
+// in 400 create / destroy cycles (tools/dev/soak_fault_timing.py with VO_DEBUG_STAGES=1: the process sat in vo_destroy of a
+// side context -- hipStreamDestroy / hipFree -- with every stream idle).  A closed pipeline's side contexts go to a pool
+// keyed by what their streams were created with (compute-unit mask, priority); the next pipeline with the same keys takes
+// them -- streams, workspace and all.  Contexts of OTHER keys are destroyed when a pipeline is created (live CU-masked
+// queues slow every other queue of the process), so at most one configuration's contexts stay alive.
+// VO_SIDE_POOL=0: off.
+struct side_entry {
+  int device;
+  std::string key;
+  vo_ctx* c;
+};
+static std::mutex g_side_mu;
+static std::vector<side_entry>& side_pool() {
+  static std::vector<side_entry>* v = new std::vector<side_entry>();
+  return *v;
+}
+static bool side_pool_on() {
+  static const bool on = !(getenv("VO_SIDE_POOL") && getenv("VO_SIDE_POOL")[0] == '0');
+  return on;
+}
+static std::string side_key() {      // of a context created NOW (vo_create reads the same variables)
+  const char* cus = getenv("VO_STREAM_CUS");
+  const char* pr = getenv("VO_STREAM_PRIORITY");
+  return std::string("cus=") + (cus ? cus : "") + ";prio=" + (pr ? pr : "");
+}
+static void side_evict_except(int device, const std::string& ka, const std::string& kb) {
+  std::vector<vo_ctx*> gone;
+  {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto& v = side_pool();
+    for (size_t i = 0; i < v.size();) {
+      if (device < 0 || (v[i].device == device && v[i].key != ka && v[i].key != kb)) {
+        gone.push_back(v[i].c);
+        v.erase(v.begin() + (long)i);
+      } else {
+        ++i;
+      }
+    }
+  }
+  for (vo_ctx* c : gone) vo_destroy(c);
+}
+static int side_take(int device, const std::string& key, vo_ctx** out) {
+  if (side_pool_on()) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto& v = side_pool();
+    for (size_t i = 0; i < v.size(); ++i)
+      if (v[i].device == device && v[i].key == key) {
+        *out = v[i].c;
+        v.erase(v.begin() + (long)i);
+        return VO_OK;
+      }
+  }
+  return vo_create(device, nullptr, out);
+}
+static void side_give(vo_ctx* c, const std::string& key) {
+  if (!c) return;
+  if (side_pool_on() && c->own_stream) {
+    c->prof_on = false;
+    c->prof_kernel = -1;
+    c->prof_every = 1;
+    c->next_stop = nullptr;
+    c->nms_kp_f32 = nullptr;
+    c->err[0] = 0;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto& v = side_pool();
+    size_t same = 0;
+    for (const side_entry& e : v) same += e.device == c->device && e.key == key ? 1 : 0;
+    if (same < 4) {
+      v.push_back({c->device, key, c});
+      return;
+    }
+  }
+  vo_destroy(c);
+}
+
+// VO_DEBUG_STAGES=1: a line on stderr at every stage of create / destroy (which runtime call a stall sits in)
+static void dbg_stage(const char* what) {
+  static const bool on = getenv("VO_DEBUG_STAGES") != nullptr;
+  if (on) {
+    fprintf(stderr, "[stage] %s\n", what);
+    fflush(stderr);
+  }
+}
+
 static void worker_main(vo_pipeline* p);
 
 static int enqueue_pyramid(vo_pipeline* p, int frame, int s);
@@ -373,15 +461,18 @@ size_t vo_pyramid_bytes(int H, int W, int n_levels);
 void vo_pipeline_destroy(vo_pipeline* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
+  dbg_stage("destroy: enter");
   if (p->worker.joinable()) {          // the worker first: it enqueues on the detection stream
     p->quit.store(true, std::memory_order_seq_cst);
     futex_wake(&p->job_posted);
     p->worker.join();
   }
+  dbg_stage("destroy: worker joined");
   // every stream next: nothing may still read what is freed below
   (void)hipStreamSynchronize(p->ctx->stream);
   for (vo_ctx* q : {p->det, p->trk})
     if (q) (void)hipStreamSynchronize(q->stream);
+  dbg_stage("destroy: streams idle");
   void* dev[] = {p->d_det_go, p->d_img, p->d_pyr, p->d_kp, p->d_scores[0], p->d_scores[1], p->feat_mem, p->d_ctl, p->d_next, p->d_err,
                  p->d_status, p->d_R, p->d_t, p->d_valid, p->d_counts, p->d_samples, p->d_masks, p->d_best_mask, p->d_table,
                  p->d_raws, p->d_newkp, p->d_pairs, p->d_ckpt_feat, p->d_ckpt_ctl, p->d_skp, p->d_sdesc, p->d_sn, p->d_fdesc,
@@ -393,14 +484,17 @@ void vo_pipeline_destroy(vo_pipeline* p) {
     if (q) (void)hipHostFree(q);
   for (uint8_t* q : p->h_img)
     if (q) (void)hipHostFree(q);
+  dbg_stage("destroy: memory freed");
   if (p->up_stream) (void)hipStreamDestroy(p->up_stream);
   for (hipEvent_t e : p->evImg)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : {p->evPyr[0], p->evPyr[1], p->evPyr[2], p->evDet[0], p->evDet[1], p->evDet[2], p->evRaw, p->evA, p->evB,
                        p->evKlt[0], p->evKlt[1], p->evRegroup[0], p->evRegroup[1]})
     if (e) (void)hipEventDestroy(e);
-  for (vo_ctx* q : {p->det, p->trk})
-    if (q) vo_destroy(q);
+  dbg_stage("destroy: events destroyed");
+  if (p->det) (p->det->own_stream ? side_give(p->det, p->det_key) : vo_destroy(p->det));
+  if (p->trk) (p->trk->own_stream ? side_give(p->trk, p->trk_key) : vo_destroy(p->trk));
+  dbg_stage("destroy: side contexts handed back");
   if (getenv("VO_DEBUG_TIMING") && p->dbg_steps > 0)
     fprintf(stderr, "[vo_pipeline] %ld steps x %d sequence(s): host %.1f us enqueueing (worker wait %.1f, tracker %.1f, raws %.1f, "
             "chain %.1f), %.1f us waiting per step; %ld finished through the host path, %ld further batches of hypotheses\n",
@@ -411,6 +505,7 @@ void vo_pipeline_destroy(vo_pipeline* p) {
 }
 
 int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline** out) {
+  dbg_stage("create: enter");
   if (!ctx || !cfg || !out) return VO_EINVAL;
   *out = nullptr;
   VO_REQUIRE(ctx, cfg->H > 0 && cfg->W > 0 && cfg->n_frames >= 2, "pipeline: bad stream shape");
@@ -501,10 +596,18 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     const char* dc = getenv("VO_DET_CUS");     // (the detection stream's own range; default: VO_SIDE_CUS)
     if (dc || sc) setenv("VO_STREAM_CUS", dc ? dc : sc, 1);
     else unsetenv("VO_STREAM_CUS");
-    if (vo_create(ctx->device, side, &p->det) != VO_OK) rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
+    p->det_key = side_key();
+    const std::string det_cus = getenv("VO_STREAM_CUS") ? getenv("VO_STREAM_CUS") : "";
     if (sc) setenv("VO_STREAM_CUS", sc, 1);
     else unsetenv("VO_STREAM_CUS");
-    if (vo_create(ctx->device, side, &p->trk) != VO_OK) rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
+    p->trk_key = side_key();
+    if (!side) side_evict_except(ctx->device, p->det_key, p->trk_key);
+    if ((side ? vo_create(ctx->device, side, &p->trk) : side_take(ctx->device, p->trk_key, &p->trk)) != VO_OK)
+      rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
+    if (!det_cus.empty()) setenv("VO_STREAM_CUS", det_cus.c_str(), 1);
+    else unsetenv("VO_STREAM_CUS");
+    if ((side ? vo_create(ctx->device, side, &p->det) : side_take(ctx->device, p->det_key, &p->det)) != VO_OK)
+      rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
     if (sp) {
       if (saved) setenv("VO_STREAM_PRIORITY", keep.c_str(), 1);
       else unsetenv("VO_STREAM_PRIORITY");
@@ -512,6 +615,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     if (saved_c) setenv("VO_STREAM_CUS", keep_c.c_str(), 1);
     else unsetenv("VO_STREAM_CUS");
   }
+  dbg_stage("create: side streams made");
   const int N = cfg->n_keypoints, Hyp = cfg->hyp;
   const size_t px = (size_t)cfg->H * cfg->W, Sz = (size_t)S;
   p->px = px;
@@ -591,6 +695,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     if (q) memset(q, 0, (4 * Sz + 16) * sizeof(unsigned));
     p->h_seq = q;
   }
+  dbg_stage("create: allocations made");
   if (rc == VO_OK && (hipHostGetDevicePointer((void**)&p->m_res, (void*)p->h_res, 0) != hipSuccess ||
                       hipHostGetDevicePointer((void**)&p->m_seq, (void*)p->h_seq, 0) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "hipHostGetDevicePointer failed");
@@ -602,6 +707,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
       if (rc == VO_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
         rc = vo_set_error(ctx, VO_EHIP, "hipEventCreate failed");
   }
+  dbg_stage("create: events made");
   if (rc == VO_OK && (mcpy(ctx->stream, p->d_table, p->table.data(), p->table.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
                       mset(ctx->stream, p->d_ctl, 0, Sz * sizeof(vo_seq_ctl)) != hipSuccess))
     rc = vo_set_error(ctx, VO_EHIP, "pipeline: initial uploads failed");
@@ -609,6 +715,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     vo_pipeline_destroy(p);
     return rc;
   }
+  dbg_stage("create: uploads made");
   p->h_img.assign(Sz * cfg->n_frames, nullptr);
   p->evImg.assign((size_t)cfg->n_frames, nullptr);
   p->side.assign((size_t)cfg->n_frames, 0);
@@ -633,6 +740,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     for (hipStream_t q : order) {
       (void)hipMemsetAsync(p->d_status, 0, 4, q);
       (void)hipStreamSynchronize(q);
+      dbg_stage("create: a stream ran");
     }
   }
   if (const char* e = getenv("VO_HOST_THREADS_BUDGET")) p->threads_budget = atoi(e) <= 1 ? 1 : 2;
@@ -642,6 +750,10 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
   *out = p;
   return VO_OK;
 }
+
+// The side contexts kept from closed pipelines (side_pool above) are destroyed now.  For a process that goes on WITHOUT a
+// pipeline and wants its other queues at full speed (live CU-masked queues slow every queue of the process).
+void vo_pipeline_release_cached(void) { side_evict_except(-1, "", ""); }
 
 int vo_pipeline_feature_cap(vo_pipeline* p) { return p ? p->cap : 0; }
 int vo_pipeline_sequences(vo_pipeline* p) { return p ? p->S : 0; }

@@ -156,6 +156,7 @@ _SIGS = {
     "vo_pipeline_checkpoint": (_i, [_vp]),
     "vo_pipeline_rewind": (_i, [_vp]),
     "vo_pipeline_destroy": (None, [_vp]),
+    "vo_pipeline_release_cached": (None, []),
     "vo_pipeline_set_frame": (_i, [_vp, _i, _vp]),
     "vo_pipeline_seed": (_i, [_vp, _vp]),
     "vo_pipeline_get_rng": (_i, [_vp, _vp]),
@@ -658,6 +659,11 @@ from vo._pipeline import Pipeline  # noqa: E402,F401  (device-resident frame loo
 
 
 _default_ctx = None
+
+
+def release_cached():
+    """vo_pipeline_release_cached: destroy the side streams / workspace kept from closed pipelines."""
+    load().vo_pipeline_release_cached()
 
 
 def set_default_context(ctx):
