@@ -455,6 +455,47 @@ def test_prepare_hint_changes_nothing_but_the_schedule(ctx):
                 assert np.array_equal(st[key], st_ref[key], equal_nan=True), (hint, fe, key)
 
 
+def test_stream_ordering_variants_change_nothing_but_the_schedule(ctx):
+    """How the tracker's stream and the main stream are ordered is read per pipeline from the environment: the default (the
+    kernels' own completion signals as events), VO_EXT_EVENTS=0 (marker events), VO_GATES=2 (device-side gates, the
+    handed-over arrays through agent-scope accesses, no fences), VO_GATES=1 (gates with fences).  Same records, same state --
+    with look-ahead and with every fourth step forced through the host path."""
+    from vo import synthetic
+    H, W, N, hyp, F = 240, 320, 300, 256, 6
+    stream = synthetic.Stream(F, H, W)
+    feats, T = start_state(stream, N, 0.85)
+    order = stream.order(9)
+    pairs = list(zip(order[:-1], order[1:]))
+
+    def run(env, fault_every):
+        saved = {k: os.environ.get(k) for k in ("VO_EXT_EVENTS", "VO_GATES")}
+        try:
+            for k in saved:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            pipe = make_pipe(ctx, stream, N, hyp, debug_fault_every=fault_every)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        pipe.set_state(0, feats, T, T)
+        out = run_all(pipe, pairs, True)
+        st = pipe.get_state()
+        pipe.close()
+        return out, st
+
+    for fe in (0, 4):
+        ref, st_ref = run({}, fe)
+        for env in ({"VO_EXT_EVENTS": "0"}, {"VO_GATES": "2"}, {"VO_GATES": "1"}):
+            got, st = run(env, fe)
+            for a, b in zip(got, ref):
+                assert fields(a) == fields(b), (env, fe)
+            for key in ("keypoints", "state", "candidate_mask", "landmarks", "tracks", "poses", "curr_pose"):
+                assert np.array_equal(st[key], st_ref[key], equal_nan=True), (env, fe, key)
+
+
 def test_pipeline_stress_configuration_properties(ctx):
     """BASELINE.json configs[4] (3840x2160, 8000 keypoints, 4-level pyramid, 4000 hypotheses): beyond what the
     oracle finishes in seconds, so checked through properties that do not depend on size -- the greedy NMS rule
