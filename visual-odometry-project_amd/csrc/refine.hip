@@ -379,7 +379,8 @@ __global__ __launch_bounds__(RF_T) void refine_pose_kernel(const double* __restr
 //   4. (job.tail) main.py:279-286 as state_landmarks_kernel does it -- the candidates, compacted into a list, are
 //      triangulated one per work item with their track's own start pose (triangulation.py:38-86), inserted as landmarks
 //      (state.py:69-88), all landmarks checked for cheirality when there was a candidate (state.py:90-107) -- and the
-//      step's result record: two launches and a kernel boundary (5-7 us on the dependent chain) less per step.
+//      step's result record (VO_FUSED_TAIL=1; round 2's form: it saves launches, but one workgroup then triangulates every
+//      candidate -- the frame loop has used the many-workgroup launch since round 3, see pipeline.hip: enqueue_pose_half).
 constexpr int TAIL_LIST = 4096;   // candidates the LDS list holds (more: every work item walks its own features)
 __global__ __launch_bounds__(RF_T) void frame_pose_kernel(vo_pose_job job) {
   using namespace vo_state_dev;
