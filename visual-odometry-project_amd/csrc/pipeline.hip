@@ -32,6 +32,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <mutex>
 #include <thread>
@@ -428,6 +429,10 @@ static void side_give(vo_ctx* c, const std::string& key) {
     c->next_stop = nullptr;
     c->nms_kp_f32 = nullptr;
     c->err[0] = 0;
+    // what is still kept when the process ends is destroyed while the runtime is alive (streams left to the runtime's own
+    // teardown crashed it under rocprofv3); registered on first use, i.e. after the runtime's own exit handlers
+    static const bool at_exit = (std::atexit([] { side_evict_except(-1, "", ""); }), true);
+    (void)at_exit;
     std::lock_guard<std::mutex> lk(g_side_mu);
     auto& v = side_pool();
     size_t same = 0;

@@ -4,6 +4,7 @@ There is no CPU fallback: if the library is missing, or no GPU is present when a
 context is created, the caller gets an exception, never a silent slow path.
 """
 import ctypes as C
+import atexit
 import os
 import threading
 import weakref
@@ -663,7 +664,11 @@ _default_ctx = None
 
 def release_cached():
     """vo_pipeline_release_cached: destroy the side streams / workspace kept from closed pipelines."""
-    load().vo_pipeline_release_cached()
+    if _lib is not None:
+        _lib.vo_pipeline_release_cached()
+
+
+atexit.register(release_cached)        # (before the interpreter and the HIP runtime are torn down)
 
 
 def set_default_context(ctx):
