@@ -434,6 +434,9 @@ void vo_pipeline_destroy(vo_pipeline* p);
  * and destroying them per pipeline stalled inside the runtime about once in 400 cycles); this destroys what is kept.  Nothing in
  * the reference corresponds to it (its objects are garbage-collected).                                                      */
 void vo_pipeline_release_cached(void);
+/* 1 when a binding should call vo_pipeline_release_cached from its own exit hook (the library's own policy: under a profiler,
+ * or VO_SIDE_POOL_ATEXIT=1), 0 when what is kept is left to the end of the process.                                       */
+int vo_pipeline_release_cached_at_exit(void);
 /* frame store: copies a host image into slot idx of the frame store.  The caller's buffer is free on return (it is
  * copied into a pinned staging buffer of that slot); the transfer itself is queued in front of the pyramid that reads
  * the slot and the call does not wait for it.  A slot that a step in flight reads is refused (VO_EINVAL), and so is the

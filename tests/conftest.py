@@ -11,6 +11,11 @@ for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The suite switches pipeline configuration from test to test and does not time anything: the side streams of every
+# configuration stay alive until the process ends instead of being destroyed at each switch (pipeline.hip, side_pool --
+# destroying a side stream stalled inside the runtime about once in a few hundred calls).
+os.environ.setdefault("VO_SIDE_POOL_EVICT", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -386,6 +386,17 @@ static bool side_pool_on() {
   static const bool on = !(getenv("VO_SIDE_POOL") && getenv("VO_SIDE_POOL")[0] == '0');
   return on;
 }
+static bool side_pool_destroy_at_exit() {
+  if (const char* e = getenv("VO_SIDE_POOL_ATEXIT")) return e[0] != '0';
+  const char* pre = getenv("LD_PRELOAD");
+  return (pre && strstr(pre, "rocprof")) || getenv("ROCP_TOOL_LIBRARIES") != nullptr;
+}
+// VO_SIDE_POOL_EVICT=0: contexts of other configurations stay alive beside the new pipeline's (a test suite that switches
+// configuration from test to test and does not care about the speed of its queues: no stream is destroyed before the process ends)
+static bool side_pool_evicts() {
+  static const bool on = !(getenv("VO_SIDE_POOL_EVICT") && getenv("VO_SIDE_POOL_EVICT")[0] == '0');
+  return on;
+}
 static std::string side_key() {      // of a context created NOW (vo_create reads the same variables)
   const char* cus = getenv("VO_STREAM_CUS");
   const char* pr = getenv("VO_STREAM_PRIORITY");
@@ -429,9 +440,14 @@ static void side_give(vo_ctx* c, const std::string& key) {
     c->next_stop = nullptr;
     c->nms_kp_f32 = nullptr;
     c->err[0] = 0;
-    // what is still kept when the process ends is destroyed while the runtime is alive (streams left to the runtime's own
-    // teardown crashed it under rocprofv3); registered on first use, i.e. after the runtime's own exit handlers
-    static const bool at_exit = (std::atexit([] { side_evict_except(-1, "", ""); }), true);
+    // Under rocprofv3 what is still kept when the process ends is destroyed while the runtime is alive (streams left to the
+    // runtime's own teardown crashed it there); registered on first use, i.e. after the runtime's own exit handlers.  Without
+    // the profiler they are left alone: a process about to end gains nothing from a call that stalls once in a few hundred.
+    // VO_SIDE_POOL_ATEXIT=1 / 0 overrides.
+    static const bool at_exit = (std::atexit([] {
+                                   if (side_pool_destroy_at_exit()) side_evict_except(-1, "", "");
+                                 }),
+                                 true);
     (void)at_exit;
     std::lock_guard<std::mutex> lk(g_side_mu);
     auto& v = side_pool();
@@ -606,7 +622,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
     if (sc) setenv("VO_STREAM_CUS", sc, 1);
     else unsetenv("VO_STREAM_CUS");
     p->trk_key = side_key();
-    if (!side) side_evict_except(ctx->device, p->det_key, p->trk_key);
+    if (!side && side_pool_evicts()) side_evict_except(ctx->device, p->det_key, p->trk_key);
     if ((side ? vo_create(ctx->device, side, &p->trk) : side_take(ctx->device, p->trk_key, &p->trk)) != VO_OK)
       rc = vo_set_error(ctx, VO_EHIP, "pipeline: cannot create the side streams");
     if (!det_cus.empty()) setenv("VO_STREAM_CUS", det_cus.c_str(), 1);
@@ -759,6 +775,7 @@ int vo_pipeline_create(vo_ctx* ctx, const vo_pipeline_config* cfg, vo_pipeline**
 // The side contexts kept from closed pipelines (side_pool above) are destroyed now.  For a process that goes on WITHOUT a
 // pipeline and wants its other queues at full speed (live CU-masked queues slow every queue of the process).
 void vo_pipeline_release_cached(void) { side_evict_except(-1, "", ""); }
+int vo_pipeline_release_cached_at_exit(void) { return side_pool_destroy_at_exit() ? 1 : 0; }
 
 int vo_pipeline_feature_cap(vo_pipeline* p) { return p ? p->cap : 0; }
 int vo_pipeline_sequences(vo_pipeline* p) { return p ? p->S : 0; }

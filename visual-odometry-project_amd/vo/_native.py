@@ -158,6 +158,7 @@ _SIGS = {
     "vo_pipeline_rewind": (_i, [_vp]),
     "vo_pipeline_destroy": (None, [_vp]),
     "vo_pipeline_release_cached": (None, []),
+    "vo_pipeline_release_cached_at_exit": (_i, []),
     "vo_pipeline_set_frame": (_i, [_vp, _i, _vp]),
     "vo_pipeline_seed": (_i, [_vp, _vp]),
     "vo_pipeline_get_rng": (_i, [_vp, _vp]),
@@ -668,7 +669,12 @@ def release_cached():
         _lib.vo_pipeline_release_cached()
 
 
-atexit.register(release_cached)        # (before the interpreter and the HIP runtime are torn down)
+def _release_cached_at_exit():
+    if _lib is not None and _lib.vo_pipeline_release_cached_at_exit():
+        _lib.vo_pipeline_release_cached()
+
+
+atexit.register(_release_cached_at_exit)        # (before the interpreter and the HIP runtime are torn down)
 
 
 def set_default_context(ctx):
